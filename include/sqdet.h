@@ -1,0 +1,169 @@
+/*
+ * sqdet.h -- C ABI of libsqdet_hip.so: the MI355X (gfx950) SqueezeDet hot path.
+ *
+ * The reference (BichenWuUCB/squeezeDet, TF 1.0 / Python 2.7) has NO FFI or
+ * operator-plugin interface: its boundary is Python-level -- builder methods on
+ * ModelSkeleton plus the model-object contract used by demo.py/eval.py/train.py
+ * (SURVEY.md 8b).  This header is the C-ABI a maintainer would bind in place of
+ * the TF graph ops those builders emit; every entry point cites the reference
+ * interface it replaces (paths relative to the reference's src/).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / HIP C++ types.
+ *   - every data pointer is a CALLER-OWNED DEVICE pointer unless the name says
+ *     "host"; nothing here allocates device memory.
+ *   - sqdet_stream_t is a hipStream_t passed as void* (NULL = default stream);
+ *     calls enqueue work on that stream and return without synchronising.
+ *   - return value: SQDET_OK (0) or a negative SQDET_E* code; never throws.
+ *     sqdet_last_error() returns a thread-local message for the last failure.
+ *   - activations are NHWC; conv kernels are HWIO [kh,kw,Cin,Cout] float32
+ *     (the reference's '<layer>/kernels' variables, nn_skeleton.py:531-533) and
+ *     are re-laid-out once into MFMA fragment order by sqdet_conv_pack_weights.
+ *   - dtype is the STORAGE type of activations/weights (SQDET_F16 or SQDET_F32);
+ *     accumulation is always float32; biases are always float32.
+ */
+#ifndef SQDET_H
+#define SQDET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sqdet_stream_t;
+
+enum { SQDET_OK = 0, SQDET_EINVAL = -1, SQDET_EUNSUPPORTED = -2, SQDET_EHIP = -3, SQDET_ESTATE = -4 };
+enum { SQDET_F32 = 0, SQDET_F16 = 1 };
+enum { SQDET_PAD_SAME = 0, SQDET_PAD_VALID = 1 };
+enum { SQDET_ARCH_SQUEEZEDET = 0, SQDET_ARCH_SQUEEZEDET_PLUS = 1 };
+
+const char* sqdet_version(void);
+const char* sqdet_last_error(void);
+
+/* ------------------------------------------------------------------ conv --
+ * Replaces ModelSkeleton._conv_layer (nn_skeleton.py:471-563):
+ *   relu?(conv2d(x, W, [1,s,s,1], padding) + b), TF SAME/VALID semantics
+ *   (asymmetric SAME: the extra pad cell goes bottom/right).
+ */
+
+/* Bytes of the packed (MFMA fragment order) form of a [k,k,cin,cout] kernel. */
+size_t sqdet_conv_packed_bytes(int k, int cin, int cout, int dtype);
+
+/* w_hwio_f32: device float32 [k,k,cin,cout] -> packed (dtype storage). */
+int sqdet_conv_pack_weights(const float* w_hwio_f32, void* packed, int k, int cin, int cout, int dtype,
+                            sqdet_stream_t stream);
+
+/* x: [n,h,w,cin] -> y: [n,ho,wo,*] written at channel offset y_coffset of rows
+ * y_cstride channels wide (y_cstride=cout, y_coffset=0 for a plain conv; a fire
+ * module's two expand convs write the two halves of one concat tensor,
+ * nets/squeezeDet.py:106).  bias: float32 [cout].  relu: 0/1. */
+int sqdet_conv2d_nhwc_fwd(const void* x, const void* w_packed, const float* bias, void* y,
+                          int n, int h, int w, int cin, int cout, int k, int stride, int pad_mode, int relu,
+                          int dtype, int y_cstride, int y_coffset, sqdet_stream_t stream);
+
+/* ------------------------------------------------------------------ pool --
+ * Replaces ModelSkeleton._pooling_layer (nn_skeleton.py:565-586): tf.nn.max_pool,
+ * SAME-padded cells never win.  x: [n,h,w,c] -> y: [n,ho,wo,c]. */
+int sqdet_maxpool_nhwc_fwd(const void* x, void* y, int n, int h, int w, int c, int k, int stride, int pad_mode,
+                           int dtype, sqdet_stream_t stream);
+
+/* ------------------------------------------------------------------ fire --
+ * Replaces SqueezeDet._fire_layer (nets/squeezeDet.py:81-106):
+ *   sq = relu(conv1x1(x)); y = concat(relu(conv1x1(sq)), relu(conv3x3(sq))).
+ * w_* are packed kernels; sq_scratch: [n,h,w,s1x1] scratch in dtype storage. */
+int sqdet_fire_fwd(const void* x, const void* w_s, const float* b_s, const void* w_e1, const float* b_e1,
+                   const void* w_e3, const float* b_e3, void* sq_scratch, void* y,
+                   int n, int h, int w, int cin, int s1x1, int e1x1, int e3x3, int dtype, sqdet_stream_t stream);
+
+/* ---------------------------------------------------- interpret_output --
+ * Replaces ModelSkeleton._add_interpretation_graph (nn_skeleton.py:142-283) +
+ * util.safe_exp / bbox_transform / bbox_transform_inv (utils/util.py:167-231).
+ * preds: [n,gh,gw,apg*(classes+1+4)] (dtype storage); anchors: float32
+ * [gh*gw*apg,4] = float32(mc.ANCHOR_BOX).  Outputs (all [n,A,...], A=gh*gw*apg):
+ * det_boxes float32 [n,A,4] (cx,cy,w,h), det_probs float32 [n,A], det_class
+ * int64 [n,A]; optional (may be NULL) pred_class_probs float32 [n,A,classes],
+ * pred_conf float32 [n,A].  Separate mul/add float32 ops (no FMA contraction). */
+int sqdet_interpret_output(const void* preds, const float* anchors, float* det_boxes, float* det_probs,
+                           int64_t* det_class, float* pred_class_probs, float* pred_conf,
+                           int n, int gh, int gw, int apg, int classes, float img_w, float img_h, float exp_thresh,
+                           int dtype, sqdet_stream_t stream);
+
+/* --------------------------------------------------- filter_prediction --
+ * Replaces ModelSkeleton.filter_prediction (nn_skeleton.py:696-734) +
+ * util.nms / util.batch_iou (utils/util.py:32-76), batched over n images.
+ * Inputs: boxes float32 [n,A,4] (cx,cy,w,h), probs float32 [n,A], cls int64 [n,A].
+ * top_n > 0 and < A: the top_n highest probs (ties: higher anchor index first)
+ *   enter NMS, prob_thresh is ignored (nn_skeleton.py:711-715);
+ * otherwise: entries with prob > prob_thresh enter NMS (nn_skeleton.py:716-720).
+ * NMS is the reference's NON-greedy rule: j is dropped iff some same-class i
+ * with higher prob has (double)IoU(i,j) > nms_thresh.
+ * Outputs, capacity max_out per image (>= top_n in the top-N branch), ordered
+ * by class then descending prob: out_boxes float32 [n,max_out,4], out_probs
+ * float32 [n,max_out], out_cls int32 [n,max_out], out_index int32 [n,max_out]
+ * (anchor index), out_count int32 [n] (number of valid rows; if the threshold
+ * branch yields more than max_out candidates the call reports it through
+ * out_count[i] = -(number of candidates)). */
+int sqdet_filter_prediction(const float* boxes, const float* probs, const int64_t* cls,
+                            float* out_boxes, float* out_probs, int32_t* out_cls, int32_t* out_index,
+                            int32_t* out_count, int n, int num_anchors, int classes, int top_n, int max_out,
+                            double nms_thresh, float prob_thresh, sqdet_stream_t stream);
+
+/* ------------------------------------------------------------- network --
+ * Replaces SqueezeDet.__init__/_add_forward_graph (nets/squeezeDet.py:19-79,
+ * nets/squeezeDetPlus.py:19-79) + the sess.run([det_boxes,det_probs,det_class])
+ * call shape of demo.py:193-195 / eval.py:75-77.  A net is a host-side plan; its
+ * device memory (packed parameters + activation workspace) is caller-owned. */
+typedef struct sqdet_net sqdet_net_t;
+
+int sqdet_net_create(sqdet_net_t** out, int arch, int dtype, int batch, int img_h, int img_w, int classes,
+                     int anchors_per_grid);
+void sqdet_net_destroy(sqdet_net_t* net);
+
+/* Parameters, in graph order, named like the reference's variables
+ * ('conv1/kernels', 'fire2/squeeze1x1/biases', ...; nn_skeleton.py:531-536). */
+int sqdet_net_num_params(const sqdet_net_t* net);
+int sqdet_net_param_info(const sqdet_net_t* net, int index, char* name, size_t name_cap, int shape[4], int* ndim);
+
+size_t sqdet_net_param_bytes(const sqdet_net_t* net);      /* packed kernels + float32 biases */
+size_t sqdet_net_workspace_bytes(const sqdet_net_t* net);  /* activation buffers */
+int sqdet_net_bind(sqdet_net_t* net, void* param_mem, void* workspace_mem);
+
+/* value: device float32, HWIO for kernels / [cout] for biases. */
+int sqdet_net_set_param(sqdet_net_t* net, const char* name, const float* value_f32, sqdet_stream_t stream);
+
+int sqdet_net_output_dims(const sqdet_net_t* net, int* gh, int* gw, int* channels);
+
+/* image_input: [batch,img_h,img_w,3] (dtype storage, BGR mean-subtracted:
+ * demo.py:187-190) -> preds [batch,gh,gw,channels] (dtype storage). */
+int sqdet_net_forward(sqdet_net_t* net, const void* image_input, void* preds, sqdet_stream_t stream);
+
+/* Layer table for measurement: name, 2*MAC flops and algorithmic bytes (every
+ * tensor touched once) of each launch of sqdet_net_forward. */
+int sqdet_net_num_layers(const sqdet_net_t* net);
+int sqdet_net_layer_info(const sqdet_net_t* net, int index, char* name, size_t name_cap, double* flops,
+                         double* bytes);
+/* Same as sqdet_net_forward but brackets every launch with HIP events on
+ * `stream` and, after synchronising, writes per-launch milliseconds to
+ * host_ms[num_layers]. */
+int sqdet_net_forward_timed(sqdet_net_t* net, const void* image_input, void* preds, float* host_ms,
+                            sqdet_stream_t stream);
+
+/* Live measurement inside the normal forward: after sqdet_net_set_probe(net, i, cap) every
+ * sqdet_net_forward records a HIP event pair around layer i's launch on the launch stream
+ * (up to cap records); sqdet_net_read_probe synchronises those events, returns the per-launch
+ * milliseconds and resets the record count.  layer_index -1 disables the probe. */
+int sqdet_net_set_probe(sqdet_net_t* net, int layer_index, int max_records);
+int sqdet_net_read_probe(sqdet_net_t* net, float* host_ms, int capacity, int* count);
+
+/* ------------------------------------------------------------ utilities --
+ * Hardware self-test used by the GPU test-suite: runs one MFMA of each shape
+ * the kernels rely on with index-encoded operands and writes the observed
+ * (row, col) of every accumulator register to host_out (see csrc/probe.hip). */
+int sqdet_probe_mfma_layout(int32_t* host_out, int capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SQDET_H */

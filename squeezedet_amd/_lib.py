@@ -1,0 +1,97 @@
+"""ctypes binding of libsqdet_hip.so (include/sqdet.h).  There is NO CPU fallback: if the
+library is missing or a call fails this raises -- the product path never routes around the
+HIP kernels."""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libsqdet_hip.so")
+
+SQDET_OK = 0
+F32, F16 = 0, 1
+PAD_SAME, PAD_VALID = 0, 1
+ARCH_SQUEEZEDET, ARCH_SQUEEZEDET_PLUS = 0, 1
+
+_lib = None
+
+vp, ci, cf, cd, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes): every symbol include/sqdet.h declares
+SIGNATURES = {
+    "sqdet_version": (C.c_char_p, []),
+    "sqdet_last_error": (C.c_char_p, []),
+    "sqdet_conv_packed_bytes": (sz, [ci, ci, ci, ci]),
+    "sqdet_conv_pack_weights": (ci, [vp, vp, ci, ci, ci, ci, vp]),
+    "sqdet_conv2d_nhwc_fwd": (ci, [vp, vp, vp, vp] + [ci] * 12 + [vp]),
+    "sqdet_maxpool_nhwc_fwd": (ci, [vp, vp] + [ci] * 8 + [vp]),
+    "sqdet_fire_fwd": (ci, [vp] * 9 + [ci] * 8 + [vp]),
+    "sqdet_interpret_output": (ci, [vp] * 7 + [ci] * 5 + [cf, cf, cf, ci, vp]),
+    "sqdet_filter_prediction": (ci, [vp] * 8 + [ci] * 5 + [cd, cf, vp]),
+    "sqdet_net_create": (ci, [C.POINTER(vp), ci, ci, ci, ci, ci, ci, ci]),
+    "sqdet_net_destroy": (None, [vp]),
+    "sqdet_net_num_params": (ci, [vp]),
+    "sqdet_net_param_info": (ci, [vp, ci, C.c_char_p, sz, C.POINTER(ci), C.POINTER(ci)]),
+    "sqdet_net_param_bytes": (sz, [vp]),
+    "sqdet_net_workspace_bytes": (sz, [vp]),
+    "sqdet_net_bind": (ci, [vp, vp, vp]),
+    "sqdet_net_set_param": (ci, [vp, C.c_char_p, vp, vp]),
+    "sqdet_net_output_dims": (ci, [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]),
+    "sqdet_net_forward": (ci, [vp, vp, vp, vp]),
+    "sqdet_net_num_layers": (ci, [vp]),
+    "sqdet_net_layer_info": (ci, [vp, ci, C.c_char_p, sz, C.POINTER(cd), C.POINTER(cd)]),
+    "sqdet_net_forward_timed": (ci, [vp, vp, vp, C.POINTER(cf), vp]),
+    "sqdet_net_set_probe": (ci, [vp, ci, ci]),
+    "sqdet_net_read_probe": (ci, [vp, C.POINTER(cf), ci, C.POINTER(ci)]),
+    "sqdet_probe_mfma_layout": (ci, [C.POINTER(C.c_int32), ci]),
+}
+
+
+class SqdetError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads the library once.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SqdetError(
+                "libsqdet_hip.so not found at %s -- build it with `python -m squeezedet_amd.build` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError = library/header mismatch: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != SQDET_OK:
+        msg = lib().sqdet_last_error()
+        raise SqdetError("%s failed (code %d): %s" % (what or "sqdet call", rc, msg.decode() if msg else "?"))
+
+
+def dtype_code(torch_dtype):
+    import torch
+    if torch_dtype == torch.float16:
+        return F16
+    if torch_dtype == torch.float32:
+        return F32
+    raise SqdetError("unsupported dtype %s (float16 / float32 only)" % torch_dtype)
+
+
+def pad_code(padding):
+    p = padding.upper()
+    if p == "SAME":
+        return PAD_SAME
+    if p == "VALID":
+        return PAD_VALID
+    raise SqdetError("padding must be 'SAME' or 'VALID', got %r" % padding)
+
+
+def stream_ptr():
+    """The current torch HIP stream as a hipStream_t value."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

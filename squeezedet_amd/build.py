@@ -1,0 +1,78 @@
+"""Builds squeezedet_amd/libsqdet_hip.so (the C-ABI library, include/sqdet.h) with hipcc
+for gfx950.  hipcc cross-compiles without a GPU; the .so stays in-tree so it travels to the
+GPU box with the repo snapshot.
+
+    python -m squeezedet_amd.build [--force]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(PKG, "csrc", "build")
+LIB = os.path.join(PKG, "libsqdet_hip.so")
+
+# (source, extra flags).  postproc.hip must not contract mul+add (bit-exact decode / IoU).
+SOURCES = [
+    ("common.cpp", []),
+    ("conv.hip", []),
+    ("pool.hip", []),
+    ("postproc.hip", ["-ffp-contract=off"]),
+    ("probe.hip", []),
+    ("net.cpp", []),
+]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(ROOT, "include", "sqdet.h"))
+    headers.append(os.path.abspath(__file__))
+    hipcc = _hipcc()
+    jobs = []
+    objs = []
+    for src, extra in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + headers):
+            cmd = [hipcc] + COMMON + extra + ["-x", "hip", "-c", s, "-o", o]
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print("[sqdet build]", " ".join(cmd[-4:]), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-8000:]))
+        if r.stderr.strip() and verbose:
+            print(r.stderr[-4000:], file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if jobs or force or _newer(LIB, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

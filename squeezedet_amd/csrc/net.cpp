@@ -1,0 +1,376 @@
+// Host-side executor: the plan that replaces SqueezeDet._add_forward_graph /
+// SqueezeDetPlus._add_forward_graph (reference src/nets/squeezeDet.py:30-79,
+// src/nets/squeezeDetPlus.py:30-79).  It owns no device memory: packed parameters and the
+// activation workspace are bound by the caller (sqdet_net_bind).
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace sqdet {
+int conv2d_launch(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
+                  int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
+                  hipStream_t st);
+int maxpool_launch(const void* x, void* y, int n, int h, int w, int c, int k, int stride, int pad_mode, int dtype,
+                   hipStream_t st);
+}  // namespace sqdet
+
+using namespace sqdet;
+
+namespace {
+
+enum { BUF_INPUT = -1, BUF_PREDS = -2, BUF_A = 0, BUF_B = 1, BUF_S = 2 };
+enum { L_CONV = 0, L_POOL = 1 };
+
+struct Param {
+  std::string name;
+  int shape[4];
+  int ndim;
+  size_t offset;  // into param_mem
+  size_t bytes;
+};
+
+struct Layer {
+  int type;
+  std::string name;
+  int in_buf, out_buf;
+  int h, w, cin, cout, k, stride, pad_mode, relu;
+  int ho, wo;
+  int y_cstride, y_coffset;
+  int kparam, bparam;  // indices into params (conv)
+  double flops, bytes;
+};
+
+struct FireSpec { const char* name; int s, e1, e3; };
+
+}  // namespace
+
+struct sqdet_net {
+  int arch, dtype, batch, img_h, img_w, classes, apg;
+  std::vector<Param> params;
+  std::vector<Layer> layers;
+  size_t param_bytes = 0;
+  size_t buf_elems[3] = {0, 0, 0};
+  size_t buf_off[3] = {0, 0, 0};
+  size_t workspace_bytes = 0;
+  int gh = 0, gw = 0, out_ch = 0;
+  char* param_mem = nullptr;
+  char* workspace = nullptr;
+  std::vector<hipEvent_t> events;
+  // live probe: start/stop events around ONE layer's launch inside sqdet_net_forward
+  int probe_layer = -1;
+  int probe_count = 0;
+  std::vector<hipEvent_t> probe_events;  // 2 per record
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Builder {
+  sqdet_net* net;
+  int h, w, c;      // current activation dims
+  int cur;          // current buffer id
+  size_t esz;
+
+  int add_param(const std::string& name, int ndim, const int* shape, size_t bytes) {
+    Param p;
+    p.name = name;
+    p.ndim = ndim;
+    for (int i = 0; i < 4; ++i) p.shape[i] = i < ndim ? shape[i] : 1;
+    p.offset = net->param_bytes;
+    p.bytes = bytes;
+    net->param_bytes = align_up(net->param_bytes + bytes, 256);
+    net->params.push_back(p);
+    return (int)net->params.size() - 1;
+  }
+
+  void note_buf(int buf, size_t elems) {
+    if (buf >= 0 && elems > net->buf_elems[buf]) net->buf_elems[buf] = elems;
+  }
+
+  // conv reading `in_buf` (dims h,w,cin) writing channels [coff, coff+cout) of out_buf rows of cstride channels
+  void conv(const std::string& name, int in_buf, int out_buf, int cin, int cout, int k, int stride, int pad_mode,
+            int relu, int cstride, int coff) {
+    Layer L;
+    L.type = L_CONV;
+    L.name = name;
+    L.in_buf = in_buf; L.out_buf = out_buf;
+    L.h = h; L.w = w; L.cin = cin; L.cout = cout; L.k = k; L.stride = stride; L.pad_mode = pad_mode; L.relu = relu;
+    L.ho = out_size(h, k, stride, pad_mode);
+    L.wo = out_size(w, k, stride, pad_mode);
+    L.y_cstride = cstride; L.y_coffset = coff;
+    const int kshape[4] = {k, k, cin, cout};
+    L.kparam = add_param(name + "/kernels", 4, kshape, sqdet_conv_packed_bytes(k, cin, cout, net->dtype));
+    const int bshape[1] = {cout};
+    L.bparam = add_param(name + "/biases", 1, bshape, (size_t)cout * 4);
+    const double npix = (double)net->batch * L.ho * L.wo;
+    L.flops = 2.0 * k * k * cin * cout * npix;
+    L.bytes = ((double)net->batch * h * w * cin + npix * cout + (double)k * k * cin * cout) * (double)esz + cout * 4.0;
+    note_buf(out_buf, (size_t)net->batch * L.ho * L.wo * cstride);
+    net->layers.push_back(L);
+  }
+
+  int other(int buf) { return buf == BUF_A ? BUF_B : BUF_A; }
+
+  void conv_layer(const std::string& name, int cout, int k, int stride, int pad_mode, int relu, bool last) {
+    const int out = last ? BUF_PREDS : (cur == BUF_INPUT ? BUF_A : other(cur));
+    conv(name, cur, out, c, cout, k, stride, pad_mode, relu, cout, 0);
+    const Layer& L = net->layers.back();
+    h = L.ho; w = L.wo; c = cout; cur = out;
+  }
+
+  void pool_layer(const std::string& name, int k, int stride, int pad_mode) {
+    Layer L;
+    L.type = L_POOL;
+    L.name = name;
+    L.in_buf = cur; L.out_buf = other(cur);
+    L.h = h; L.w = w; L.cin = c; L.cout = c; L.k = k; L.stride = stride; L.pad_mode = pad_mode; L.relu = 0;
+    L.ho = out_size(h, k, stride, pad_mode);
+    L.wo = out_size(w, k, stride, pad_mode);
+    L.y_cstride = c; L.y_coffset = 0; L.kparam = L.bparam = -1;
+    L.flops = 0;
+    L.bytes = ((double)net->batch * h * w * c + (double)net->batch * L.ho * L.wo * c) * (double)esz;
+    note_buf(L.out_buf, (size_t)net->batch * L.ho * L.wo * c);
+    net->layers.push_back(L);
+    h = L.ho; w = L.wo; cur = L.out_buf;
+  }
+
+  // SqueezeDet._fire_layer (nets/squeezeDet.py:81-106): squeeze -> S; expand1x1 / expand3x3
+  // write the two halves of the concat tensor directly (no concat pass).
+  void fire_layer(const FireSpec& f) {
+    const std::string n = f.name;
+    const int out = other(cur);
+    conv(n + "/squeeze1x1", cur, BUF_S, c, f.s, 1, 1, SQDET_PAD_SAME, 1, f.s, 0);
+    conv(n + "/expand1x1", BUF_S, out, f.s, f.e1, 1, 1, SQDET_PAD_SAME, 1, f.e1 + f.e3, 0);
+    conv(n + "/expand3x3", BUF_S, out, f.s, f.e3, 3, 1, SQDET_PAD_SAME, 1, f.e1 + f.e3, f.e1);
+    c = f.e1 + f.e3;
+    cur = out;
+  }
+};
+
+const FireSpec kSqueezeDetFires[] = {{"fire2", 16, 64, 64},    {"fire3", 16, 64, 64},    {"fire4", 32, 128, 128},
+                                     {"fire5", 32, 128, 128},  {"fire6", 48, 192, 192},  {"fire7", 48, 192, 192},
+                                     {"fire8", 64, 256, 256},  {"fire9", 64, 256, 256},  {"fire10", 96, 384, 384},
+                                     {"fire11", 96, 384, 384}};
+const FireSpec kSqueezeDetPlusFires[] = {{"fire2", 96, 64, 64},     {"fire3", 96, 64, 64},     {"fire4", 192, 128, 128},
+                                         {"fire5", 192, 128, 128},  {"fire6", 288, 192, 192},  {"fire7", 288, 192, 192},
+                                         {"fire8", 384, 256, 256},  {"fire9", 384, 256, 256},  {"fire10", 384, 256, 256},
+                                         {"fire11", 384, 256, 256}};
+
+void* buf_ptr(const sqdet_net* net, int buf, const void* input, void* preds) {
+  if (buf == BUF_INPUT) return const_cast<void*>(input);
+  if (buf == BUF_PREDS) return preds;
+  return net->workspace + net->buf_off[buf];
+}
+
+int run_layer(sqdet_net* net, const Layer& L, const void* input, void* preds, hipStream_t st) {
+  const void* x = buf_ptr(net, L.in_buf, input, preds);
+  void* y = buf_ptr(net, L.out_buf, input, preds);
+  if (L.type == L_CONV) {
+    const void* wp = net->param_mem + net->params[L.kparam].offset;
+    const float* b = reinterpret_cast<const float*>(net->param_mem + net->params[L.bparam].offset);
+    return conv2d_launch(x, wp, b, y, net->batch, L.h, L.w, L.cin, L.cout, L.k, L.stride, L.pad_mode, L.relu,
+                         net->dtype, L.y_cstride, L.y_coffset, st);
+  }
+  return maxpool_launch(x, y, net->batch, L.h, L.w, L.cin, L.k, L.stride, L.pad_mode, net->dtype, st);
+}
+
+}  // namespace
+
+extern "C" int sqdet_net_create(sqdet_net_t** out, int arch, int dtype, int batch, int img_h, int img_w, int classes,
+                                int anchors_per_grid) {
+  SQDET_REQUIRE(out, "net_create: null out");
+  SQDET_REQUIRE(arch == SQDET_ARCH_SQUEEZEDET || arch == SQDET_ARCH_SQUEEZEDET_PLUS, "net_create: bad arch %d", arch);
+  SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "net_create: bad dtype %d", dtype);
+  SQDET_REQUIRE(batch > 0 && img_h >= 64 && img_w >= 64 && classes > 0 && anchors_per_grid > 0, "net_create: bad dims");
+  sqdet_net* net = new sqdet_net();
+  net->arch = arch; net->dtype = dtype; net->batch = batch; net->img_h = img_h; net->img_w = img_w;
+  net->classes = classes; net->apg = anchors_per_grid;
+  Builder b;
+  b.net = net; b.h = img_h; b.w = img_w; b.c = 3; b.cur = BUF_INPUT; b.esz = dtype_size(dtype);
+  const int nout = anchors_per_grid * (classes + 1 + 4);  // nets/squeezeDet.py:76
+  if (arch == SQDET_ARCH_SQUEEZEDET) {
+    const FireSpec* f = kSqueezeDetFires;
+    b.conv_layer("conv1", 64, 3, 2, SQDET_PAD_SAME, 1, false);
+    b.pool_layer("pool1", 3, 2, SQDET_PAD_SAME);
+    b.fire_layer(f[0]); b.fire_layer(f[1]);
+    b.pool_layer("pool3", 3, 2, SQDET_PAD_SAME);
+    b.fire_layer(f[2]); b.fire_layer(f[3]);
+    b.pool_layer("pool5", 3, 2, SQDET_PAD_SAME);
+    for (int i = 4; i < 10; ++i) b.fire_layer(f[i]);
+  } else {
+    const FireSpec* f = kSqueezeDetPlusFires;
+    b.conv_layer("conv1", 96, 7, 2, SQDET_PAD_VALID, 1, false);
+    b.pool_layer("pool1", 3, 2, SQDET_PAD_VALID);
+    b.fire_layer(f[0]); b.fire_layer(f[1]); b.fire_layer(f[2]);
+    b.pool_layer("pool4", 3, 2, SQDET_PAD_VALID);
+    b.fire_layer(f[3]); b.fire_layer(f[4]); b.fire_layer(f[5]); b.fire_layer(f[6]);
+    b.pool_layer("pool8", 3, 2, SQDET_PAD_VALID);
+    b.fire_layer(f[7]); b.fire_layer(f[8]); b.fire_layer(f[9]);
+  }
+  // dropout11 is the identity at inference (keep_prob = 1.0, nn_skeleton.py:78)
+  b.conv_layer("conv12", nout, 3, 1, SQDET_PAD_SAME, 0, true);
+  net->gh = b.h; net->gw = b.w; net->out_ch = nout;
+  size_t off = 0;
+  for (int i = 0; i < 3; ++i) {
+    net->buf_off[i] = off;
+    off = align_up(off + net->buf_elems[i] * b.esz, 256);
+  }
+  net->workspace_bytes = off;
+  *out = net;
+  return SQDET_OK;
+}
+
+extern "C" void sqdet_net_destroy(sqdet_net_t* net) {
+  if (!net) return;
+  for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : net->probe_events) (void)hipEventDestroy(e);
+  delete net;
+}
+
+extern "C" int sqdet_net_num_params(const sqdet_net_t* net) { return net ? (int)net->params.size() : 0; }
+
+extern "C" int sqdet_net_param_info(const sqdet_net_t* net, int index, char* name, size_t name_cap, int shape[4],
+                                    int* ndim) {
+  SQDET_REQUIRE(net && index >= 0 && index < (int)net->params.size(), "param_info: bad index");
+  const Param& p = net->params[index];
+  if (name && name_cap) {
+    strncpy(name, p.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (shape) for (int i = 0; i < 4; ++i) shape[i] = p.shape[i];
+  if (ndim) *ndim = p.ndim;
+  return SQDET_OK;
+}
+
+extern "C" size_t sqdet_net_param_bytes(const sqdet_net_t* net) { return net ? net->param_bytes : 0; }
+extern "C" size_t sqdet_net_workspace_bytes(const sqdet_net_t* net) { return net ? net->workspace_bytes : 0; }
+
+extern "C" int sqdet_net_bind(sqdet_net_t* net, void* param_mem, void* workspace_mem) {
+  SQDET_REQUIRE(net && param_mem && workspace_mem, "net_bind: null pointer");
+  SQDET_REQUIRE(((uintptr_t)param_mem % 256) == 0 && ((uintptr_t)workspace_mem % 256) == 0,
+                "net_bind: buffers must be 256-byte aligned");
+  net->param_mem = reinterpret_cast<char*>(param_mem);
+  net->workspace = reinterpret_cast<char*>(workspace_mem);
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_net_set_param(sqdet_net_t* net, const char* name, const float* value_f32, sqdet_stream_t stream) {
+  SQDET_REQUIRE(net && name && value_f32, "net_set_param: null pointer");
+  if (!net->param_mem) { set_error("net_set_param: call sqdet_net_bind first"); return SQDET_ESTATE; }
+  for (const Param& p : net->params) {
+    if (p.name != name) continue;
+    if (p.ndim == 4)
+      return sqdet_conv_pack_weights(value_f32, net->param_mem + p.offset, p.shape[0], p.shape[2], p.shape[3],
+                                     net->dtype, stream);
+    SQDET_CHECK_HIP(hipMemcpyAsync(net->param_mem + p.offset, value_f32, (size_t)p.shape[0] * 4,
+                                   hipMemcpyDeviceToDevice, as_stream(stream)));
+    return SQDET_OK;
+  }
+  set_error("net_set_param: no parameter named '%s'", name);
+  return SQDET_EINVAL;
+}
+
+extern "C" int sqdet_net_output_dims(const sqdet_net_t* net, int* gh, int* gw, int* channels) {
+  SQDET_REQUIRE(net, "net_output_dims: null net");
+  if (gh) *gh = net->gh;
+  if (gw) *gw = net->gw;
+  if (channels) *channels = net->out_ch;
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_net_forward(sqdet_net_t* net, const void* image_input, void* preds, sqdet_stream_t stream) {
+  SQDET_REQUIRE(net && image_input && preds, "net_forward: null pointer");
+  if (!net->param_mem || !net->workspace) { set_error("net_forward: call sqdet_net_bind first"); return SQDET_ESTATE; }
+  hipStream_t st = as_stream(stream);
+  const int nl = (int)net->layers.size();
+  for (int i = 0; i < nl; ++i) {
+    const bool probe = i == net->probe_layer && 2 * (net->probe_count + 1) <= (int)net->probe_events.size();
+    if (probe) SQDET_CHECK_HIP(hipEventRecord(net->probe_events[2 * net->probe_count], st));
+    const int rc = run_layer(net, net->layers[i], image_input, preds, st);
+    if (rc != SQDET_OK) return rc;
+    if (probe) {
+      SQDET_CHECK_HIP(hipEventRecord(net->probe_events[2 * net->probe_count + 1], st));
+      ++net->probe_count;
+    }
+  }
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_net_set_probe(sqdet_net_t* net, int layer_index, int max_records) {
+  SQDET_REQUIRE(net && layer_index >= -1 && layer_index < (int)net->layers.size() && max_records >= 0,
+                "net_set_probe: bad arguments");
+  net->probe_layer = layer_index;
+  net->probe_count = 0;
+  while ((int)net->probe_events.size() < 2 * max_records) {
+    hipEvent_t e;
+    SQDET_CHECK_HIP(hipEventCreate(&e));
+    net->probe_events.push_back(e);
+  }
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_net_read_probe(sqdet_net_t* net, float* host_ms, int capacity, int* count) {
+  SQDET_REQUIRE(net && host_ms && count, "net_read_probe: null pointer");
+  int n = net->probe_count < capacity ? net->probe_count : capacity;
+  for (int i = 0; i < n; ++i) {
+    SQDET_CHECK_HIP(hipEventSynchronize(net->probe_events[2 * i + 1]));
+    SQDET_CHECK_HIP(hipEventElapsedTime(&host_ms[i], net->probe_events[2 * i], net->probe_events[2 * i + 1]));
+  }
+  *count = n;
+  net->probe_count = 0;
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_net_num_layers(const sqdet_net_t* net) { return net ? (int)net->layers.size() : 0; }
+
+extern "C" int sqdet_net_layer_info(const sqdet_net_t* net, int index, char* name, size_t name_cap, double* flops,
+                                    double* bytes) {
+  SQDET_REQUIRE(net && index >= 0 && index < (int)net->layers.size(), "layer_info: bad index");
+  const Layer& L = net->layers[index];
+  if (name && name_cap) {
+    strncpy(name, L.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (flops) *flops = L.flops;
+  if (bytes) *bytes = L.bytes;
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_net_forward_timed(sqdet_net_t* net, const void* image_input, void* preds, float* host_ms,
+                                       sqdet_stream_t stream) {
+  SQDET_REQUIRE(net && image_input && preds && host_ms, "net_forward_timed: null pointer");
+  if (!net->param_mem || !net->workspace) { set_error("net_forward_timed: call sqdet_net_bind first"); return SQDET_ESTATE; }
+  const size_t nl = net->layers.size();
+  while (net->events.size() < nl + 1) {
+    hipEvent_t e;
+    SQDET_CHECK_HIP(hipEventCreate(&e));
+    net->events.push_back(e);
+  }
+  hipStream_t st = as_stream(stream);
+  SQDET_CHECK_HIP(hipEventRecord(net->events[0], st));
+  for (size_t i = 0; i < nl; ++i) {
+    const int rc = run_layer(net, net->layers[i], image_input, preds, st);
+    if (rc != SQDET_OK) return rc;
+    SQDET_CHECK_HIP(hipEventRecord(net->events[i + 1], st));
+  }
+  SQDET_CHECK_HIP(hipEventSynchronize(net->events[nl]));
+  for (size_t i = 0; i < nl; ++i) SQDET_CHECK_HIP(hipEventElapsedTime(&host_ms[i], net->events[i], net->events[i + 1]));
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_fire_fwd(const void* x, const void* w_s, const float* b_s, const void* w_e1, const float* b_e1,
+                              const void* w_e3, const float* b_e3, void* sq_scratch, void* y, int n, int h, int w,
+                              int cin, int s1x1, int e1x1, int e3x3, int dtype, sqdet_stream_t stream) {
+  SQDET_REQUIRE(sq_scratch, "fire_fwd: null scratch");
+  hipStream_t st = as_stream(stream);
+  int rc = conv2d_launch(x, w_s, b_s, sq_scratch, n, h, w, cin, s1x1, 1, 1, SQDET_PAD_SAME, 1, dtype, s1x1, 0, st);
+  if (rc != SQDET_OK) return rc;
+  rc = conv2d_launch(sq_scratch, w_e1, b_e1, y, n, h, w, s1x1, e1x1, 1, 1, SQDET_PAD_SAME, 1, dtype, e1x1 + e3x3, 0, st);
+  if (rc != SQDET_OK) return rc;
+  return conv2d_launch(sq_scratch, w_e3, b_e3, y, n, h, w, s1x1, e3x3, 3, 1, SQDET_PAD_SAME, 1, dtype, e1x1 + e3x3,
+                       e1x1, st);
+}

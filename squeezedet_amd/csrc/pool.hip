@@ -1,0 +1,74 @@
+// NHWC max-pool for gfx950, replacing ModelSkeleton._pooling_layer
+// (reference src/nn_skeleton.py:565-586): tf.nn.max_pool with TF SAME/VALID semantics --
+// SAME-padded cells never win (they are skipped, which equals -inf padding).
+// Pure HBM streaming: one thread owns one output pixel x 16 bytes of channels.
+#include "common.h"
+
+namespace sqdet {
+
+template <typename T> struct PoolTr;
+template <> struct PoolTr<f16> { static constexpr int V = 8; typedef f16x8 vec; };
+template <> struct PoolTr<float> { static constexpr int V = 4; typedef f32x4 vec; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
+                                                      int C, int k, int stride, int pt, int pl, int Ho, int Wo) {
+  constexpr int V = PoolTr<T>::V;
+  typedef typename PoolTr<T>::vec vec;
+  const int cv = C / V;
+  const size_t total = (size_t)N * Ho * Wo * cv;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cv);
+    size_t p = idx / cv;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const int y0 = oy * stride - pt, x0 = ox * stride - pl;
+    vec m;
+#pragma unroll
+    for (int e = 0; e < V; ++e) m[e] = (T)(-__builtin_huge_valf());
+    for (int dy = 0; dy < k; ++dy) {
+      const int iy = y0 + dy;
+      if (iy < 0 || iy >= H) continue;
+      for (int dx = 0; dx < k; ++dx) {
+        const int ix = x0 + dx;
+        if (ix < 0 || ix >= W) continue;
+        const vec v = *reinterpret_cast<const vec*>(x + (((size_t)n * H + iy) * W + ix) * C + c * V);
+#pragma unroll
+        for (int e = 0; e < V; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+      }
+    }
+    *reinterpret_cast<vec*>(y + idx * V) = m;
+  }
+}
+
+int maxpool_launch(const void* x, void* y, int n, int h, int w, int c, int k, int stride, int pad_mode, int dtype,
+                   hipStream_t st) {
+  SQDET_REQUIRE(x && y, "maxpool: null pointer");
+  SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "maxpool: bad dtype %d", dtype);
+  SQDET_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && k > 0 && stride > 0, "maxpool: bad dims");
+  SQDET_REQUIRE(pad_mode == SQDET_PAD_SAME || pad_mode == SQDET_PAD_VALID, "maxpool: bad pad_mode");
+  SQDET_REQUIRE(pad_mode == SQDET_PAD_SAME || (h >= k && w >= k), "maxpool: VALID needs h,w >= k");
+  const int V = dtype == SQDET_F16 ? 8 : 4;
+  SQDET_UNSUPPORTED(c % V != 0, "maxpool: channels %d not a multiple of %d", c, V);
+  const int Ho = out_size(h, k, stride, pad_mode), Wo = out_size(w, k, stride, pad_mode);
+  const int pt = pad_before(h, k, stride, pad_mode), pl = pad_before(w, k, stride, pad_mode);
+  const size_t total = (size_t)n * Ho * Wo * (c / V);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (dtype == SQDET_F16)
+    hipLaunchKernelGGL(maxpool_kernel<f16>, dim3((unsigned)blocks), dim3(256), 0, st, (const f16*)x, (f16*)y, n, h, w,
+                       c, k, stride, pt, pl, Ho, Wo);
+  else
+    hipLaunchKernelGGL(maxpool_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (float*)y, n,
+                       h, w, c, k, stride, pt, pl, Ho, Wo);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
+}  // namespace sqdet
+
+extern "C" int sqdet_maxpool_nhwc_fwd(const void* x, void* y, int n, int h, int w, int c, int k, int stride,
+                                      int pad_mode, int dtype, sqdet_stream_t stream) {
+  return sqdet::maxpool_launch(x, y, n, h, w, c, k, stride, pad_mode, dtype, sqdet::as_stream(stream));
+}

@@ -1,0 +1,60 @@
+// Hardware self-test: observes the MFMA fragment layouts the conv kernels rely on
+// (guide: cdna_hip_programming.md section 3) so a wrong assumption shows up as a clear
+// test failure instead of silently transposed activations.
+//
+// For each shape we run ONE MFMA with A = "row selector" and B = "col selector" encodings
+// chosen so that D[i][j] = 64*i + j + 1 exactly, then report for every (lane, reg) the
+// observed (row, col).  host_out layout: [shape(2)][lane(64)][reg(4)][2].
+#include "common.h"
+
+namespace sqdet {
+
+// shape 0: mfma_f32_16x16x32_f16, assumed operand layout: A lane l holds row i=l&15,
+// k-slots 8*(l>>4)..+7 ; B lane l holds col j=l&15, same k-slots.
+// Encoding: k-slot 0 carries (64*i+1) in A and 1 in B; k-slot 1 carries 1 in A and j in B.
+// Then D[i][j] = (64i+1)*1 + 1*j exactly (values < 2048 are exact in f16).
+__global__ void probe_kernel(float* out) {
+  const int l = threadIdx.x;
+  const int i = l & 15, g = l >> 4;
+  {
+    f16x8 a = {0, 0, 0, 0, 0, 0, 0, 0}, b = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (g == 0) {
+      a[0] = (f16)(64 * i + 1); b[0] = (f16)1;
+      a[1] = (f16)1;            b[1] = (f16)i;  // i == this lane's column index for B
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) out[(0 * 64 + l) * 4 + r] = acc[r];
+  }
+  {
+    // shape 1: mfma_f32_16x16x4f32: A lane l = A[i=l&15][k=l>>4], B lane l = B[k=l>>4][j=l&15]
+    float a = 0.f, b = 0.f;
+    if (g == 0) { a = (float)(64 * i + 1); b = 1.f; }
+    if (g == 1) { a = 1.f; b = (float)i; }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) out[(1 * 64 + l) * 4 + r] = acc[r];
+  }
+}
+
+}  // namespace sqdet
+
+extern "C" int sqdet_probe_mfma_layout(int32_t* host_out, int capacity) {
+  using namespace sqdet;
+  SQDET_REQUIRE(host_out && capacity >= 2 * 64 * 4 * 2, "probe: need capacity >= 1024 int32");
+  float* d = nullptr;
+  SQDET_CHECK_HIP(hipMalloc(&d, 2 * 64 * 4 * sizeof(float)));
+  hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, 0, d);
+  float h[2 * 64 * 4];
+  hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  SQDET_CHECK_HIP(e);
+  for (int s = 0; s < 2; ++s)
+    for (int l = 0; l < 64; ++l)
+      for (int r = 0; r < 4; ++r) {
+        const int v = (int)h[(s * 64 + l) * 4 + r] - 1;  // 64*row + col
+        host_out[((s * 64 + l) * 4 + r) * 2 + 0] = v / 64;
+        host_out[((s * 64 + l) * 4 + r) * 2 + 1] = v % 64;
+      }
+  return SQDET_OK;
+}

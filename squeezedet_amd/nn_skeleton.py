@@ -1,0 +1,327 @@
+"""Host-side mirror of the reference's ModelSkeleton (reference src/nn_skeleton.py): the same
+builder methods (`_conv_layer`, `_pooling_layer`, `_fire_layer` in the nets), the same model
+attributes (`image_input, preds, pred_class_probs, pred_conf, pred_box_delta, det_boxes,
+det_probs, det_class, model_params`) and `filter_prediction`, but every op is a HIP kernel of
+libsqdet_hip.so.  Like TF 1.0 it is define-then-run: builders record symbolic nodes, and
+`Session.run(fetches, feed_dict)` (the call shape of demo.py:193-195 / eval.py:75-77)
+executes them on the GPU.  There is no CPU execution path.
+"""
+import collections
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import SqdetError
+
+
+class Node:
+    """A symbolic tensor of the model graph (what a tf.Tensor is to the reference)."""
+
+    def __init__(self, model, op, inputs=(), shape=None, name=None, **attrs):
+        self.model, self.op, self.inputs, self.shape, self.name, self.attrs = model, op, tuple(inputs), shape, name, attrs
+        self.consumers = 0
+        for i in self.inputs:
+            i.consumers += 1
+
+    def get_shape(self):
+        return tuple(self.shape)
+
+    def __repr__(self):
+        return "<Node %s %s %s>" % (self.op, self.name, self.shape)
+
+    # hashable by identity so nodes can key feed_dict like TF tensors do
+    __hash__ = object.__hash__
+
+
+class Session:
+    """Stand-in for tf.Session for demo.py / eval.py shaped callers: `run(fetches, feed_dict)`
+    returns fresh NumPy arrays owned by the caller (eval.py:83-84 mutates them in place)."""
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def run(self, fetches, feed_dict=None):
+        single = isinstance(fetches, Node)
+        fl = [fetches] if single else list(fetches)
+        outs = fl[0].model.run(fl, feed_dict or {}, as_numpy=True)
+        return outs[0] if single else outs
+
+
+def _truncated_normal(shape, stddev, generator, device):
+    """tf.truncated_normal_initializer: N(0, stddev) re-drawn outside 2 sigma (nn_skeleton.py:527-528)."""
+    t = torch.empty(shape, dtype=torch.float32)
+    torch.nn.init.trunc_normal_(t, mean=0.0, std=stddev, a=-2 * stddev, b=2 * stddev, generator=generator)
+    return t.to(device)
+
+
+def _out_size(n, k, s, padding):
+    return -(-n // s) if padding.upper() == "SAME" else (n - k) // s + 1
+
+
+class ModelSkeleton:
+    """Base class of NN detection models (nn_skeleton.py:72-135)."""
+
+    # set by subclasses whose _add_forward_graph has a native plan (sqdet_net_*)
+    NATIVE_ARCH = None
+
+    def __init__(self, mc, gpu_id=0, dtype=torch.float32, seed=0):
+        self.mc = mc
+        # FLAGS.gpu arrives as a string (demo.py:174).  Without a HIP device the graph can still be
+        # BUILT (shapes, parameter table, analytical counters) but nothing can run: no CPU path.
+        self.has_device = torch.cuda.is_available()
+        self.device = torch.device("cuda", int(gpu_id)) if self.has_device else torch.device("cpu")
+        self.dtype = dtype
+        # nn_skeleton.py:78
+        self.keep_prob = 0.5 if mc.IS_TRAINING else 1.0
+        self._gen = torch.Generator().manual_seed(seed)
+        # nn_skeleton.py:81-84,121: [BATCH, H, W, 3] float32 BGR mean-subtracted NHWC
+        self.ph_image_input = Node(self, "placeholder", shape=(mc.BATCH_SIZE, mc.IMAGE_HEIGHT, mc.IMAGE_WIDTH, 3), name="image_input")
+        self.image_input = self.ph_image_input
+        self.params = collections.OrderedDict()   # '<layer>/kernels' (HWIO f32) / '<layer>/biases'
+        self.trainable = {}
+        self.model_params = []                    # nn_skeleton.py:128
+        self.model_size_counter = []
+        self.flop_counter = []
+        self.activation_counter = [("input", mc.IMAGE_WIDTH * mc.IMAGE_HEIGHT * 3)]
+        self._packed = {}
+        self._plan = None
+        self._plan_stale = True
+        self._anchors_f32 = None
+        self.caffemodel_weight = None
+
+    # ------------------------------------------------------------------ builders
+    def _add_forward_graph(self):
+        """NN architecture specification."""
+        raise NotImplementedError
+
+    def _new_param(self, name, value, trainable):
+        self.params[name] = value.to(self.device, torch.float32).contiguous()
+        self.trainable[name] = trainable
+        self.model_params.append(self.params[name])
+
+    def _conv_layer(self, layer_name, inputs, filters, size, stride, padding="SAME", freeze=False, xavier=False,
+                    relu=True, stddev=0.001):
+        """Convolutional layer constructor (nn_skeleton.py:471-563): kernel '<layer>/kernels'
+        [size,size,Cin,filters] HWIO, '<layer>/biases' [filters]; conv2d -> bias_add -> relu."""
+        mc = self.mc
+        channels = int(inputs.get_shape()[3])
+        use_pretrained_param = False
+        if mc.LOAD_PRETRAINED_MODEL:
+            cw = self.caffemodel_weight
+            if layer_name in cw:
+                kernel_val = np.transpose(cw[layer_name][0], [2, 3, 1, 0])  # OIHW -> HWIO (:496)
+                bias_val = cw[layer_name][1]
+                if kernel_val.shape == (size, size, channels, filters) and bias_val.shape == (filters,):
+                    use_pretrained_param = True
+                else:
+                    print("Shape of the pretrained parameter of {} does not match, "
+                          "use randomly initialized parameter".format(layer_name))
+            else:
+                print("Cannot find {} in the pretrained model. Use randomly initialized parameters".format(layer_name))
+        if use_pretrained_param:
+            kernel = torch.from_numpy(np.ascontiguousarray(kernel_val, dtype=np.float32))
+            biases = torch.from_numpy(np.ascontiguousarray(bias_val, dtype=np.float32))
+        elif xavier:
+            fan_in, fan_out = size * size * channels, size * size * filters
+            lim = (6.0 / (fan_in + fan_out)) ** 0.5
+            kernel = (torch.rand((size, size, channels, filters), generator=self._gen) * 2 - 1) * lim
+            biases = torch.zeros(filters)
+        else:
+            kernel = _truncated_normal((size, size, channels, filters), stddev, self._gen, "cpu")
+            biases = torch.zeros(filters)
+        self._new_param(layer_name + "/kernels", kernel, not freeze)
+        self._new_param(layer_name + "/biases", biases, not freeze)
+
+        n, h, w, _ = inputs.get_shape()
+        out_shape = (n, _out_size(h, size, stride, padding), _out_size(w, size, stride, padding), filters)
+        out = Node(self, "conv", [inputs], out_shape, layer_name, size=size, stride=stride, padding=padding, relu=relu)
+        # nn_skeleton.py:549-561 analytical counters
+        self.model_size_counter.append((layer_name, (1 + size * size * channels) * filters))
+        num_flops = (1 + 2 * channels * size * size) * filters * out_shape[1] * out_shape[2]
+        if relu:
+            num_flops += 2 * filters * out_shape[1] * out_shape[2]
+        self.flop_counter.append((layer_name, num_flops))
+        self.activation_counter.append((layer_name, out_shape[1] * out_shape[2] * out_shape[3]))
+        return out
+
+    def _pooling_layer(self, layer_name, inputs, size, stride, padding="SAME"):
+        """Pooling layer constructor (nn_skeleton.py:565-586)."""
+        n, h, w, c = inputs.get_shape()
+        out_shape = (n, _out_size(h, size, stride, padding), _out_size(w, size, stride, padding), c)
+        out = Node(self, "pool", [inputs], out_shape, layer_name, size=size, stride=stride, padding=padding)
+        self.activation_counter.append((layer_name, int(np.prod(out_shape[1:]))))
+        return out
+
+    def _concat(self, values, axis, name=None):
+        """tf.concat on the channel axis (nets/squeezeDet.py:106)."""
+        assert axis == 3
+        s = values[0].get_shape()
+        return Node(self, "concat", values, (s[0], s[1], s[2], sum(v.get_shape()[3] for v in values)), name)
+
+    def _dropout(self, inputs, keep_prob, name=None):
+        """tf.nn.dropout (nets/squeezeDet.py:74); identity at inference (keep_prob == 1.0)."""
+        if keep_prob != 1.0:
+            raise SqdetError("training-mode dropout is not part of the inference hot path")
+        return inputs
+
+    # ------------------------------------------------------------------ interpretation
+    def _add_interpretation_graph(self):
+        """Interpret NN output (nn_skeleton.py:142-283)."""
+        mc = self.mc
+        n, gh, gw, ch = self.preds.get_shape()
+        assert ch == mc.ANCHOR_PER_GRID * (mc.CLASSES + 1 + 4)
+        assert gh * gw * mc.ANCHOR_PER_GRID == mc.ANCHORS, "grid %dx%d does not match mc.ANCHORS" % (gh, gw)
+        interp = Node(self, "interpret", [self.preds], None, "interpret_output")
+        B, A = mc.BATCH_SIZE, mc.ANCHORS
+        mk = lambda i, shape, nm: Node(self, "interpret_out", [interp], shape, nm, index=i)
+        self.det_boxes = mk(0, (B, A, 4), "bbox")
+        self.det_probs = mk(1, (B, A), "score")
+        self.det_class = mk(2, (B, A), "class_idx")
+        self.pred_class_probs = mk(3, (B, A, mc.CLASSES), "pred_class_probs")
+        self.pred_conf = mk(4, (B, A), "pred_confidence_score")
+        self.pred_box_delta = Node(self, "box_delta", [self.preds], (B, A, 4), "bbox_delta")
+
+    def anchors_f32(self):
+        """float32(mc.ANCHOR_BOX) on the device -- cast first, then compute (nn_skeleton.py:187-201)."""
+        if self._anchors_f32 is None:
+            self._anchors_f32 = torch.from_numpy(np.asarray(self.mc.ANCHOR_BOX).astype(np.float32)).to(self.device)
+        return self._anchors_f32
+
+    # ------------------------------------------------------------------ parameters
+    def load_params(self, values):
+        """values: {name: array/tensor} with the reference's names and layouts ('<layer>/kernels'
+        HWIO, '<layer>/biases')."""
+        for name, v in values.items():
+            if name not in self.params:
+                raise SqdetError("unknown parameter %r" % name)
+            t = torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).to(self.device, torch.float32)
+            if tuple(t.shape) != tuple(self.params[name].shape):
+                raise SqdetError("parameter %r: shape %s != %s" % (name, tuple(t.shape), tuple(self.params[name].shape)))
+            self.params[name].copy_(t)
+        self._packed.clear()
+        self._plan_stale = True
+
+    def _packed_conv(self, name):
+        if name not in self._packed:
+            self._packed[name] = ops.pack_conv_weights(self.params[name + "/kernels"], self.dtype)
+        return self._packed[name]
+
+    # ------------------------------------------------------------------ execution
+    def _native_plan(self, batch):
+        if self._plan is None or self._plan.batch != batch:
+            mc = self.mc
+            self._plan = ops.NetPlan(self.NATIVE_ARCH, self.dtype, batch, mc.IMAGE_HEIGHT, mc.IMAGE_WIDTH, mc.CLASSES,
+                                     mc.ANCHOR_PER_GRID, self.device)
+            self._plan_stale = True
+        if self._plan_stale:
+            specs = dict(self._plan.param_specs())
+            if set(specs) != set(self.params):
+                raise SqdetError("native plan parameters do not match the python graph")
+            for name, t in self.params.items():
+                self._plan.set_param(name, t)
+            self._plan_stale = False
+        return self._plan
+
+    def _to_input(self, value):
+        x = value if isinstance(value, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(value, dtype=np.float32)))
+        x = x.to(self.device, self.dtype).contiguous()
+        mc = self.mc
+        if x.dim() != 4 or tuple(x.shape[1:]) != (mc.IMAGE_HEIGHT, mc.IMAGE_WIDTH, 3):
+            raise SqdetError("image_input must be [B,%d,%d,3] NHWC, got %s" % (mc.IMAGE_HEIGHT, mc.IMAGE_WIDTH, tuple(x.shape)))
+        return x
+
+    def _eval(self, node, env, use_plan):
+        if node in env:
+            return env[node]
+        mc = self.mc
+        if node.op == "placeholder":
+            raise SqdetError("placeholder %s was not fed" % node.name)
+        if use_plan and node is self.preds and self.NATIVE_ARCH is not None:
+            x = self._eval(self.image_input, env, use_plan)
+            v = self._native_plan(int(x.shape[0])).forward(x)
+        elif node.op == "conv":
+            x = self._eval(node.inputs[0], env, use_plan)
+            v = ops.conv2d_nhwc(x, self._packed_conv(node.name), self.params[node.name + "/biases"], node.attrs["stride"],
+                                node.attrs["padding"], node.attrs["relu"])
+        elif node.op == "pool":
+            x = self._eval(node.inputs[0], env, use_plan)
+            v = ops.maxpool_nhwc(x, node.attrs["size"], node.attrs["stride"], node.attrs["padding"])
+        elif node.op == "concat":
+            if all(i.op == "conv" and i.consumers == 1 for i in node.inputs):
+                # the producing convs write their channel range of the concat tensor directly
+                xs = [self._eval(i.inputs[0], env, use_plan) for i in node.inputs]
+                b = int(xs[0].shape[0])
+                v = torch.empty((b,) + tuple(node.shape[1:]), dtype=self.dtype, device=self.device)
+                off = 0
+                for i, x in zip(node.inputs, xs):
+                    ops.conv2d_nhwc(x, self._packed_conv(i.name), self.params[i.name + "/biases"], i.attrs["stride"],
+                                    i.attrs["padding"], i.attrs["relu"], out=v, out_coffset=off)
+                    off += i.shape[3]
+            else:
+                v = torch.cat([self._eval(i, env, use_plan) for i in node.inputs], dim=3).contiguous()
+        elif node.op == "interpret":
+            preds = self._eval(node.inputs[0], env, use_plan)
+            v = ops.interpret_output(preds, self.anchors_f32(), mc.CLASSES, mc.ANCHOR_PER_GRID, mc.IMAGE_WIDTH,
+                                     mc.IMAGE_HEIGHT, mc.EXP_THRESH, with_class_probs=True)
+        elif node.op == "interpret_out":
+            v = self._eval(node.inputs[0], env, use_plan)[node.attrs["index"]]
+        elif node.op == "box_delta":
+            preds = self._eval(node.inputs[0], env, use_plan)
+            k = mc.ANCHOR_PER_GRID * (mc.CLASSES + 1)
+            v = preds[..., k:].reshape(preds.shape[0], -1, 4)
+        else:
+            raise SqdetError("unknown op %s" % node.op)
+        env[node] = v
+        return v
+
+    def run(self, fetches, feed_dict, as_numpy=False, use_plan=True):
+        """Evaluates graph nodes.  feed_dict: {model.image_input: array or device tensor}."""
+        if not self.has_device:
+            raise SqdetError("squeezedet_amd needs a HIP device to run: there is no CPU path")
+        env = {}
+        for k, v in feed_dict.items():
+            if k is not self.image_input and k is not self.ph_image_input:
+                raise SqdetError("only image_input can be fed")
+            env[self.image_input] = self._to_input(v)
+        outs = [self._eval(f, env, use_plan) for f in fetches]
+        if as_numpy:
+            torch.cuda.current_stream().synchronize()
+            outs = [o.float().cpu().numpy() if o.dtype == torch.float16 else o.cpu().numpy() for o in outs]
+        return outs
+
+    def detect(self, images, use_plan=True):
+        """Device-resident hot path: images [B,H,W,3] -> (det_boxes [B,A,4] f32, det_probs [B,A] f32,
+        det_class [B,A] i64) device tensors (nothing is copied to the host)."""
+        return tuple(self.run([self.det_boxes, self.det_probs, self.det_class], {self.image_input: images},
+                              use_plan=use_plan))
+
+    # ------------------------------------------------------------------ filter_prediction
+    def filter_prediction_batch(self, det_boxes, det_probs, det_class, max_out=None):
+        """Batched, device-resident filter_prediction: returns (boxes [B,M,4], probs [B,M], cls [B,M] i32,
+        anchor_index [B,M] i32, count [B] i32) device tensors."""
+        mc = self.mc
+        return ops.filter_prediction(det_boxes, det_probs, det_class, mc.CLASSES, mc.TOP_N_DETECTION, mc.NMS_THRESH,
+                                     mc.PROB_THRESH, max_out)
+
+    def filter_prediction(self, boxes, probs, cls_idx):
+        """Filter bounding box predictions with probability threshold and non-maximum
+        supression (nn_skeleton.py:696-734).  Same arguments and return value as the reference:
+          boxes: array of [cx, cy, w, h]; probs: array of probabilities; cls_idx: array of class indices
+          -> (final_boxes, final_probs, final_cls_idx) Python lists, ordered by class.
+        Runs on the GPU (top-N select + per-class NMS kernel)."""
+        if not self.has_device:
+            raise SqdetError("squeezedet_amd needs a HIP device to run: there is no CPU path")
+        b = torch.as_tensor(np.ascontiguousarray(boxes, dtype=np.float32)).to(self.device).reshape(1, -1, 4)
+        p = torch.as_tensor(np.ascontiguousarray(probs, dtype=np.float32)).to(self.device).reshape(1, -1)
+        c = torch.as_tensor(np.ascontiguousarray(cls_idx, dtype=np.int64)).to(self.device).reshape(1, -1)
+        ob, op, oc, oi, cnt = self.filter_prediction_batch(b, p, c)
+        n = int(cnt[0].item())
+        if n < 0:
+            ob, op, oc, oi, cnt = self.filter_prediction_batch(b, p, c, max_out=-n)
+            n = int(cnt[0].item())
+        ob, op, oc = ob[0, :n].cpu().numpy(), op[0, :n].cpu().numpy(), oc[0, :n].cpu().numpy()
+        return [ob[i] for i in range(n)], [op[i] for i in range(n)], [int(oc[i]) for i in range(n)]

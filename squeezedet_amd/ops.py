@@ -1,0 +1,291 @@
+"""Tensor-level entry points of the HIP hot path (torch is plumbing only: device memory and
+streams).  Every function launches a kernel of libsqdet_hip.so through the C ABI
+(include/sqdet.h) on the current torch stream; none has a CPU implementation.
+
+Also registered as PyTorch custom ops under ``torch.ops.sqdet.*`` (see the bottom of the
+file) so graph-level callers can use them.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, dtype_code, lib, pad_code, stream_ptr
+
+
+def _dev(t, name, dtype=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.SqdetError("%s must be a CUDA(HIP) tensor -- there is no CPU path" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.SqdetError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise _lib.SqdetError("%s must be contiguous" % name)
+    return C.c_void_p(t.data_ptr())
+
+
+def _out_size(n, k, s, padding):
+    return -(-n // s) if padding.upper() == "SAME" else (n - k) // s + 1
+
+
+# ---------------------------------------------------------------- conv
+class PackedConv:
+    """A conv kernel re-laid-out in MFMA fragment order (sqdet_conv_pack_weights)."""
+
+    def __init__(self, w_hwio, dtype):
+        w = w_hwio.detach().to(torch.float32).contiguous()
+        self.k, k2, self.cin, self.cout = [int(v) for v in w.shape]
+        assert self.k == k2, "square kernels only"
+        self.dtype = dtype
+        code = dtype_code(dtype)
+        nbytes = lib().sqdet_conv_packed_bytes(self.k, self.cin, self.cout, code)
+        self.data = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        check(lib().sqdet_conv_pack_weights(_dev(w, "w_hwio"), _dev(self.data, "packed"), self.k, self.cin, self.cout,
+                                            code, stream_ptr()), "sqdet_conv_pack_weights")
+
+
+def pack_conv_weights(w_hwio, dtype):
+    return PackedConv(w_hwio, dtype)
+
+
+def conv2d_nhwc(x, packed, bias, stride=1, padding="SAME", relu=True, out=None, out_coffset=0):
+    """relu?(conv2d(x, W) + b) with TF SAME/VALID semantics (nn_skeleton.py:471-563).
+    x: [N,H,W,Cin] f16/f32 NHWC; packed: PackedConv; bias: f32 [Cout].  ``out`` (optional)
+    is a [N,Ho,Wo,Ctot] tensor whose channels [out_coffset, out_coffset+Cout) are written
+    (fire-module concat without a concat pass)."""
+    n, h, w, cin = [int(v) for v in x.shape]
+    if cin != packed.cin or x.dtype != packed.dtype:
+        raise _lib.SqdetError("conv2d_nhwc: input [%d ch, %s] does not match packed kernel [%d ch, %s]"
+                              % (cin, x.dtype, packed.cin, packed.dtype))
+    ho, wo = _out_size(h, packed.k, stride, padding), _out_size(w, packed.k, stride, padding)
+    if out is None:
+        out = torch.empty((n, ho, wo, packed.cout), dtype=x.dtype, device=x.device)
+        out_coffset = 0
+    elif tuple(out.shape[:3]) != (n, ho, wo) or out.dtype != x.dtype:
+        raise _lib.SqdetError("conv2d_nhwc: bad `out` shape/dtype")
+    check(lib().sqdet_conv2d_nhwc_fwd(_dev(x, "x"), _dev(packed.data, "packed"), _dev(bias, "bias", torch.float32),
+                                      _dev(out, "out"), n, h, w, cin, packed.cout, packed.k, int(stride),
+                                      pad_code(padding), int(bool(relu)), dtype_code(x.dtype), int(out.shape[3]),
+                                      int(out_coffset), stream_ptr()), "sqdet_conv2d_nhwc_fwd")
+    return out
+
+
+def maxpool_nhwc(x, size, stride, padding="SAME"):
+    """tf.nn.max_pool semantics (nn_skeleton.py:565-586)."""
+    n, h, w, c = [int(v) for v in x.shape]
+    ho, wo = _out_size(h, size, stride, padding), _out_size(w, size, stride, padding)
+    y = torch.empty((n, ho, wo, c), dtype=x.dtype, device=x.device)
+    check(lib().sqdet_maxpool_nhwc_fwd(_dev(x, "x"), _dev(y, "y"), n, h, w, c, int(size), int(stride),
+                                       pad_code(padding), dtype_code(x.dtype), stream_ptr()), "sqdet_maxpool_nhwc_fwd")
+    return y
+
+
+def fire(x, p_s, b_s, p_e1, b_e1, p_e3, b_e3):
+    """SqueezeDet._fire_layer (nets/squeezeDet.py:81-106)."""
+    n, h, w, cin = [int(v) for v in x.shape]
+    sq = torch.empty((n, h, w, p_s.cout), dtype=x.dtype, device=x.device)
+    y = torch.empty((n, h, w, p_e1.cout + p_e3.cout), dtype=x.dtype, device=x.device)
+    check(lib().sqdet_fire_fwd(_dev(x, "x"), _dev(p_s.data, "w_s"), _dev(b_s, "b_s", torch.float32),
+                               _dev(p_e1.data, "w_e1"), _dev(b_e1, "b_e1", torch.float32),
+                               _dev(p_e3.data, "w_e3"), _dev(b_e3, "b_e3", torch.float32),
+                               _dev(sq, "sq"), _dev(y, "y"), n, h, w, cin, p_s.cout, p_e1.cout, p_e3.cout,
+                               dtype_code(x.dtype), stream_ptr()), "sqdet_fire_fwd")
+    return y
+
+
+# ---------------------------------------------------------------- post-processing
+def interpret_output(preds, anchors_f32, classes, anchors_per_grid, img_w, img_h, exp_thresh=1.0,
+                     with_class_probs=False):
+    """_add_interpretation_graph (nn_skeleton.py:142-283).  preds [N,gh,gw,K*(C+5)] f16/f32;
+    anchors_f32 [A,4] float32 device tensor.  Returns det_boxes [N,A,4] f32, det_probs [N,A] f32,
+    det_class [N,A] int64 (+ pred_class_probs [N,A,C], pred_conf [N,A] when asked)."""
+    n, gh, gw, ch = [int(v) for v in preds.shape]
+    if ch != anchors_per_grid * (classes + 5):
+        raise _lib.SqdetError("interpret_output: %d channels != %d*(%d+5)" % (ch, anchors_per_grid, classes))
+    A = gh * gw * anchors_per_grid
+    if tuple(anchors_f32.shape) != (A, 4):
+        raise _lib.SqdetError("interpret_output: anchors must be [%d,4]" % A)
+    dev = preds.device
+    boxes = torch.empty((n, A, 4), dtype=torch.float32, device=dev)
+    probs = torch.empty((n, A), dtype=torch.float32, device=dev)
+    cls = torch.empty((n, A), dtype=torch.int64, device=dev)
+    pcp = torch.empty((n, A, classes), dtype=torch.float32, device=dev) if with_class_probs else None
+    pconf = torch.empty((n, A), dtype=torch.float32, device=dev) if with_class_probs else None
+    check(lib().sqdet_interpret_output(_dev(preds, "preds"), _dev(anchors_f32, "anchors", torch.float32),
+                                       _dev(boxes, "boxes"), _dev(probs, "probs"), _dev(cls, "cls"),
+                                       _dev(pcp, "pcp") if pcp is not None else None,
+                                       _dev(pconf, "pconf") if pconf is not None else None,
+                                       n, gh, gw, int(anchors_per_grid), int(classes), float(img_w), float(img_h),
+                                       float(exp_thresh), dtype_code(preds.dtype), stream_ptr()),
+          "sqdet_interpret_output")
+    if with_class_probs:
+        return boxes, probs, cls, pcp, pconf
+    return boxes, probs, cls
+
+
+def filter_prediction(boxes, probs, cls, classes, top_n, nms_thresh, prob_thresh, max_out=None):
+    """Batched ModelSkeleton.filter_prediction (nn_skeleton.py:696-734).  boxes [N,A,4] f32,
+    probs [N,A] f32, cls [N,A] int64 (device).  Returns device tensors
+    (out_boxes [N,M,4], out_probs [N,M], out_cls [N,M] i32, out_index [N,M] i32, out_count [N] i32)
+    with rows [0,count) valid, ordered by class then descending prob."""
+    n, A = int(probs.shape[0]), int(probs.shape[1])
+    use_topn = 0 < top_n < A
+    if max_out is None:
+        max_out = top_n if use_topn else min(A, 1024)
+    dev = probs.device
+    ob = torch.empty((n, max_out, 4), dtype=torch.float32, device=dev)
+    op = torch.empty((n, max_out), dtype=torch.float32, device=dev)
+    oc = torch.empty((n, max_out), dtype=torch.int32, device=dev)
+    oi = torch.empty((n, max_out), dtype=torch.int32, device=dev)
+    cnt = torch.empty((n,), dtype=torch.int32, device=dev)
+    check(lib().sqdet_filter_prediction(_dev(boxes, "boxes", torch.float32), _dev(probs, "probs", torch.float32),
+                                        _dev(cls, "cls", torch.int64), _dev(ob, "ob"), _dev(op, "op"), _dev(oc, "oc"),
+                                        _dev(oi, "oi"), _dev(cnt, "cnt"), n, A, int(classes), int(top_n), int(max_out),
+                                        float(nms_thresh), float(prob_thresh), stream_ptr()), "sqdet_filter_prediction")
+    return ob, op, oc, oi, cnt
+
+
+def probe_mfma_layout():
+    """[2 shapes][64 lanes][4 regs][row, col] observed accumulator layout."""
+    import numpy as np
+    buf = (C.c_int32 * 1024)()
+    check(lib().sqdet_probe_mfma_layout(buf, 1024), "sqdet_probe_mfma_layout")
+    return np.frombuffer(buf, dtype=np.int32).reshape(2, 64, 4, 2).copy()
+
+
+# ---------------------------------------------------------------- compiled network plan
+class NetPlan:
+    """sqdet_net_*: the whole forward graph (nets/squeezeDet.py:30-79 /
+    nets/squeezeDetPlus.py:30-79) as one native plan; device memory is torch-allocated."""
+
+    ARCH = {"squeezeDet": _lib.ARCH_SQUEEZEDET, "squeezeDet+": _lib.ARCH_SQUEEZEDET_PLUS}
+
+    def __init__(self, arch, dtype, batch, img_h, img_w, classes, anchors_per_grid, device):
+        self.arch, self.dtype, self.batch, self.img_h, self.img_w = arch, dtype, batch, img_h, img_w
+        self.device = torch.device(device)
+        self._h = C.c_void_p()
+        check(lib().sqdet_net_create(C.byref(self._h), self.ARCH[arch], dtype_code(dtype), batch, img_h, img_w,
+                                     classes, anchors_per_grid), "sqdet_net_create")
+        gh, gw, ch = C.c_int(), C.c_int(), C.c_int()
+        check(lib().sqdet_net_output_dims(self._h, C.byref(gh), C.byref(gw), C.byref(ch)))
+        self.gh, self.gw, self.out_ch = gh.value, gw.value, ch.value
+        self.param_mem = torch.zeros(max(int(lib().sqdet_net_param_bytes(self._h)), 256), dtype=torch.uint8, device=self.device)
+        self.workspace = torch.empty(max(int(lib().sqdet_net_workspace_bytes(self._h)), 256), dtype=torch.uint8, device=self.device)
+        check(lib().sqdet_net_bind(self._h, _dev(self.param_mem, "param_mem"), _dev(self.workspace, "workspace")),
+              "sqdet_net_bind")
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().sqdet_net_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def param_specs(self):
+        out = []
+        name = C.create_string_buffer(128)
+        shape = (C.c_int * 4)()
+        nd = C.c_int()
+        for i in range(lib().sqdet_net_num_params(self._h)):
+            check(lib().sqdet_net_param_info(self._h, i, name, 128, shape, C.byref(nd)))
+            out.append((name.value.decode(), tuple(shape[j] for j in range(nd.value))))
+        return out
+
+    def set_param(self, name, value):
+        v = value.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        check(lib().sqdet_net_set_param(self._h, name.encode(), _dev(v, name), stream_ptr()), "sqdet_net_set_param(%s)" % name)
+        torch.cuda.current_stream().synchronize()  # `v` may be a temporary
+
+    def forward(self, image_input, preds=None):
+        exp = (self.batch, self.img_h, self.img_w, 3)
+        if tuple(image_input.shape) != exp or image_input.dtype != self.dtype:
+            raise _lib.SqdetError("forward: image_input must be %s %s, got %s %s"
+                                  % (exp, self.dtype, tuple(image_input.shape), image_input.dtype))
+        if preds is None:
+            preds = torch.empty((self.batch, self.gh, self.gw, self.out_ch), dtype=self.dtype, device=self.device)
+        check(lib().sqdet_net_forward(self._h, _dev(image_input, "image_input"), _dev(preds, "preds"), stream_ptr()),
+              "sqdet_net_forward")
+        return preds
+
+    def layer_table(self):
+        out = []
+        name = C.create_string_buffer(128)
+        fl, by = C.c_double(), C.c_double()
+        for i in range(lib().sqdet_net_num_layers(self._h)):
+            check(lib().sqdet_net_layer_info(self._h, i, name, 128, C.byref(fl), C.byref(by)))
+            out.append((name.value.decode(), fl.value, by.value))
+        return out
+
+    def set_probe(self, layer_index, max_records):
+        check(lib().sqdet_net_set_probe(self._h, int(layer_index), int(max_records)), "sqdet_net_set_probe")
+
+    def read_probe(self, capacity):
+        ms = (C.c_float * capacity)()
+        cnt = C.c_int()
+        check(lib().sqdet_net_read_probe(self._h, ms, capacity, C.byref(cnt)), "sqdet_net_read_probe")
+        return [float(ms[i]) for i in range(cnt.value)]
+
+    def forward_timed(self, image_input, preds=None):
+        """Per-launch milliseconds measured with HIP events on the launch stream."""
+        if preds is None:
+            preds = torch.empty((self.batch, self.gh, self.gw, self.out_ch), dtype=self.dtype, device=self.device)
+        nl = lib().sqdet_net_num_layers(self._h)
+        ms = (C.c_float * nl)()
+        check(lib().sqdet_net_forward_timed(self._h, _dev(image_input, "image_input"), _dev(preds, "preds"), ms,
+                                            stream_ptr()), "sqdet_net_forward_timed")
+        return preds, [float(v) for v in ms]
+
+
+# ---------------------------------------------------------------- torch.ops.sqdet.*
+def _register_custom_ops():
+    try:
+        from torch.library import custom_op
+    except Exception:  # pragma: no cover - very old torch
+        return
+
+    @custom_op("sqdet::maxpool_nhwc", mutates_args=())
+    def _maxpool(x: torch.Tensor, size: int, stride: int, same: bool) -> torch.Tensor:
+        return maxpool_nhwc(x, size, stride, "SAME" if same else "VALID")
+
+    @_maxpool.register_fake
+    def _(x, size, stride, same):
+        p = "SAME" if same else "VALID"
+        return x.new_empty((x.shape[0], _out_size(x.shape[1], size, stride, p), _out_size(x.shape[2], size, stride, p), x.shape[3]))
+
+    @custom_op("sqdet::conv2d_nhwc", mutates_args=())
+    def _conv(x: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, k: int, cout: int, stride: int, same: bool,
+              relu: bool) -> torch.Tensor:
+        pc = PackedConv.__new__(PackedConv)
+        pc.k, pc.cin, pc.cout, pc.dtype, pc.data = k, int(x.shape[3]), cout, x.dtype, packed
+        return conv2d_nhwc(x, pc, bias, stride, "SAME" if same else "VALID", relu)
+
+    @_conv.register_fake
+    def _(x, packed, bias, k, cout, stride, same, relu):
+        p = "SAME" if same else "VALID"
+        return x.new_empty((x.shape[0], _out_size(x.shape[1], k, stride, p), _out_size(x.shape[2], k, stride, p), cout))
+
+    @custom_op("sqdet::interpret_output", mutates_args=())
+    def _interp(preds: torch.Tensor, anchors: torch.Tensor, classes: int, apg: int, img_w: float, img_h: float,
+                exp_thresh: float) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        return interpret_output(preds, anchors, classes, apg, img_w, img_h, exp_thresh)
+
+    @_interp.register_fake
+    def _(preds, anchors, classes, apg, img_w, img_h, exp_thresh):
+        n, A = preds.shape[0], anchors.shape[0]
+        return (preds.new_empty((n, A, 4), dtype=torch.float32), preds.new_empty((n, A), dtype=torch.float32),
+                preds.new_empty((n, A), dtype=torch.int64))
+
+    @custom_op("sqdet::filter_prediction", mutates_args=())
+    def _filt(boxes: torch.Tensor, probs: torch.Tensor, cls: torch.Tensor, classes: int, top_n: int, nms_thresh: float,
+              prob_thresh: float, max_out: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        return filter_prediction(boxes, probs, cls, classes, top_n, nms_thresh, prob_thresh, max_out)
+
+    @_filt.register_fake
+    def _(boxes, probs, cls, classes, top_n, nms_thresh, prob_thresh, max_out):
+        n = probs.shape[0]
+        return (probs.new_empty((n, max_out, 4)), probs.new_empty((n, max_out)),
+                probs.new_empty((n, max_out), dtype=torch.int32), probs.new_empty((n, max_out), dtype=torch.int32),
+                probs.new_empty((n,), dtype=torch.int32))
+
+
+_register_custom_ops()

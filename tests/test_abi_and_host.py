@@ -1,0 +1,143 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/sqdet.h declares
+(no compute calls without a GPU), argument validation returns error codes instead of
+crashing, and the host-side mirror (config, graph builders, counters) matches the reference's
+numbers."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import squeezedet_amd as S
+from squeezedet_amd import _lib, nets
+from squeezedet_amd import build as sqbuild
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    sqbuild.build(verbose=False)
+    return _lib.lib()
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "sqdet.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sqdet_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_header_symbol(lib):
+    names = header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "libsqdet_hip.so does not export %s" % n
+        assert n in _lib.SIGNATURES, "ctypes binding missing for %s" % n
+    assert set(_lib.SIGNATURES) == set(names)
+    assert b"gfx950" in lib.sqdet_version()
+
+
+def test_argument_validation_returns_codes(lib):
+    assert lib.sqdet_conv2d_nhwc_fwd(None, None, None, None, 1, 8, 8, 8, 8, 3, 1, 0, 1, 1, 8, 0, None) == -1
+    assert b"null" in lib.sqdet_last_error()
+    assert lib.sqdet_maxpool_nhwc_fwd(None, None, 1, 8, 8, 8, 3, 2, 0, 1, None) == -1
+    h = C.c_void_p()
+    assert lib.sqdet_net_create(C.byref(h), 7, 1, 1, 384, 1248, 3, 9) == -1      # bad arch
+    assert lib.sqdet_net_create(C.byref(h), 0, 5, 1, 384, 1248, 3, 9) == -1      # bad dtype
+    assert lib.sqdet_conv_packed_bytes(0, 3, 3, 1) == 0
+
+
+def test_net_plan_tables_without_gpu(lib):
+    """The plan is host-side: parameter table, workspace sizes and the layer table can be
+    inspected without a device."""
+    h = C.c_void_p()
+    assert lib.sqdet_net_create(C.byref(h), _lib.ARCH_SQUEEZEDET, _lib.F16, 32, 375, 1242, 3, 9) == 0
+    gh, gw, ch = C.c_int(), C.c_int(), C.c_int()
+    assert lib.sqdet_net_output_dims(h, C.byref(gh), C.byref(gw), C.byref(ch)) == 0
+    assert (gh.value, gw.value, ch.value) == (24, 78, 72)
+    name = C.create_string_buffer(128)
+    shape = (C.c_int * 4)()
+    nd = C.c_int()
+    names, nparam = [], 0
+    for i in range(lib.sqdet_net_num_params(h)):
+        assert lib.sqdet_net_param_info(h, i, name, 128, shape, C.byref(nd)) == 0
+        names.append(name.value.decode())
+        nparam += int(np.prod([shape[j] for j in range(nd.value)]))
+    assert nparam == 2082120                       # SqueezeDet parameters
+    assert names[0] == "conv1/kernels" and names[-1] == "conv12/biases" and "fire7/expand3x3/kernels" in names
+    fl, by = C.c_double(), C.c_double()
+    tot_f = tot_b = 0.0
+    nl = lib.sqdet_net_num_layers(h)
+    assert nl == 35                                # 32 convs + 3 pools
+    for i in range(nl):
+        assert lib.sqdet_net_layer_info(h, i, name, 128, C.byref(fl), C.byref(by)) == 0
+        tot_f += fl.value
+        tot_b += by.value
+    assert abs(tot_f / 32 / 1e9 - 10.492) < 0.01   # GFLOP / image @375x1242
+    # MB / image fp16, every tensor touched once: 133.2 MB at batch 1; at batch 32 the
+    # 4.16 MB of weights are read once per launch, not once per image
+    assert abs(tot_b / 32 / 1e6 - (133.244 - 4.164 * 31 / 32)) < 0.05
+    assert lib.sqdet_net_workspace_bytes(h) > 32 * 188 * 621 * 64 * 2
+    x = C.c_void_p(256)
+    assert lib.sqdet_net_forward(h, x, x, None) == -4    # SQDET_ESTATE: not bound
+    lib.sqdet_net_destroy(h)
+    assert lib.sqdet_net_create(C.byref(h), _lib.ARCH_SQUEEZEDET_PLUS, _lib.F16, 1, 375, 1242, 3, 9) == 0
+    assert lib.sqdet_net_output_dims(h, C.byref(gh), C.byref(gw), C.byref(ch)) == 0
+    assert (gh.value, gw.value) == (22, 76)
+    lib.sqdet_net_destroy(h)
+
+
+def test_packed_bytes_geometry(lib):
+    # [groups][steps][NT][64 lanes][16 B]
+    assert lib.sqdet_conv_packed_bytes(1, 64, 16, _lib.F16) == 1 * 2 * 1 * 1024       # K=64 -> 2 chunk-steps, NT=1
+    assert lib.sqdet_conv_packed_bytes(3, 96, 384, _lib.F16) == 4 * 27 * 6 * 1024     # 9 taps x 3 chunks, NT=6 x 4 groups
+    assert lib.sqdet_conv_packed_bytes(3, 3, 64, _lib.F16) == 1 * 1 * 4 * 1024        # gather: K'=27 -> 1 step
+    assert lib.sqdet_conv_packed_bytes(3, 768, 72, _lib.F32) == 1 * (9 * 48) * 5 * 1024
+    assert lib.sqdet_conv_packed_bytes(7, 3, 96, _lib.F32) == 1 * 10 * 6 * 1024       # K'=147 -> 10 steps of 16
+
+
+def test_config_matches_reference_fields(golden_dir):
+    import hashlib
+    g = np.load(os.path.join(golden_dir, "anchors.npz"))
+    for key, fn in (("squeezeDet", S.kitti_squeezeDet_config), ("squeezeDetPlus", S.kitti_squeezeDetPlus_config),
+                    ("res50", S.kitti_res50_config)):
+        mc = fn()
+        ab = mc.ANCHOR_BOX
+        assert ab.dtype == np.float64 and mc.ANCHORS == len(ab) and mc.ANCHOR_PER_GRID == 9
+        assert hashlib.sha256(np.ascontiguousarray(ab).tobytes()).hexdigest() == str(g["anchors_%s_sha256" % key])
+    mc = S.kitti_squeezeDet_config()
+    assert (mc.IMAGE_WIDTH, mc.IMAGE_HEIGHT, mc.TOP_N_DETECTION, mc.NMS_THRESH, mc.PROB_THRESH, mc.PLOT_PROB_THRESH,
+            mc.EXP_THRESH, mc.CLASSES) == (1248, 384, 64, 0.4, 0.005, 0.4, 1.0, 3)
+    assert mc.CLASS_NAMES == ("car", "pedestrian", "cyclist")
+    mc2 = S.kitti_squeezeDet_config_for_input(375, 1242)
+    assert mc2.ANCHORS == 16848 and mc2.ANCHOR_BOX[0][0] == 1242.0 / 79 and mc2.ANCHOR_BOX[0][1] == 375.0 / 25
+
+
+def test_graph_builders_and_reference_counters():
+    """The builder graph reproduces the reference's analytical counters
+    (nn_skeleton.py:549-561): params (1+k^2 C)F, flops (1+2Ck^2)FHW (+2FHW relu)."""
+    mc = S.kitti_squeezeDet_config()
+    mc.LOAD_PRETRAINED_MODEL = False
+    mc.BATCH_SIZE = 1
+    m = nets.SqueezeDet(mc, gpu_id="0")
+    assert m.preds.get_shape() == (1, 24, 78, 72)
+    assert m.det_boxes.get_shape() == (1, 16848, 4) and m.det_class.get_shape() == (1, 16848)
+    assert sum(c for _, c in m.model_size_counter) == 2082120
+    assert abs(sum(c for _, c in m.flop_counter) / 1e9 - 10.649) < 1e-3     # BASELINE.md, reference formula
+    assert len(m.model_params) == 64 and list(m.params)[:2] == ["conv1/kernels", "conv1/biases"]
+    assert tuple(m.params["fire2/expand3x3/kernels"].shape) == (3, 3, 16, 64)
+    assert m.trainable["conv1/kernels"] is False and m.trainable["conv12/kernels"] is True   # conv1 frozen
+    k = m.params["fire2/squeeze1x1/kernels"]
+    assert float(k.abs().max()) <= 0.02 + 1e-6 and 0.005 < float(k.std()) < 0.012               # trunc normal, sigma 0.01
+    mcp = S.kitti_squeezeDetPlus_config()
+    mcp.LOAD_PRETRAINED_MODEL = False
+    mp = nets.SqueezeDetPlus(mcp)
+    assert sum(c for _, c in mp.model_size_counter) == 7021640
+    assert abs(sum(c for _, c in mp.flop_counter) / 1e9 - 77.246) < 1e-3
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.SqdetError):   # no CPU execution path
+            m.run([m.preds], {m.image_input: np.zeros((1, 384, 1248, 3), np.float32)})
+        with pytest.raises(_lib.SqdetError):
+            m.filter_prediction(np.zeros((10, 4), np.float32), np.zeros(10, np.float32), np.zeros(10, np.int64))

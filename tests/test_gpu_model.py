@@ -1,0 +1,159 @@
+"""GPU parity tests, model level: the native plan (sqdet_net_forward) and the builder graph
+(ModelSkeleton._conv_layer/_pooling_layer/_fire_layer) against the CPU oracle; the demo.py
+call shape; stage-wise bit-exact picks; size-independent properties at BASELINE.json's full
+config (batch 32, 375x1242, fp16)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sqdet_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(arch="squeezeDet", dtype=torch.float32, batch=1, size=None, seed=0):
+    import squeezedet_amd as S
+    from squeezedet_amd import nets
+    if arch == "squeezeDet":
+        mc = S.kitti_squeezeDet_config() if size is None else S.kitti_squeezeDet_config_for_input(*size)
+        cls = nets.SqueezeDet
+    else:
+        mc = S.kitti_squeezeDetPlus_config()
+        cls = nets.SqueezeDetPlus
+    mc.LOAD_PRETRAINED_MODEL = False
+    mc.BATCH_SIZE = batch
+    m = cls(mc, gpu_id="0", dtype=dtype)
+    storage = "fp16" if dtype == torch.float16 else "fp32"
+    params = O.init_params(arch, seed=seed, storage=storage)
+    m.load_params(params)
+    return m, mc, params, storage
+
+
+def _check_layers(got, ref, dtype, what):
+    got = got.float().cpu().numpy()
+    ref = ref.numpy() if isinstance(ref, torch.Tensor) else ref
+    assert got.shape == ref.shape, what
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    if dtype == torch.float32:
+        assert err <= 1e-3 * scale + 1e-5, "%s: max err %g vs scale %g" % (what, err, scale)  # north_star 1e-3 rel
+    else:
+        # fp16 storage: both sides round every activation to fp16; rounding decisions can flip
+        # by one fp16 ulp and propagate -> allow 1% of the tensor scale
+        assert err <= 1e-2 * scale + 1e-3, "%s: max err %g vs scale %g" % (what, err, scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("size", [(384, 1248), (375, 1242)], ids=["384x1248", "375x1242"])
+def test_squeezedet_layer_by_layer_vs_oracle(dtype, size):
+    """Builder-graph path: every intermediate tensor against the oracle's, so a wrong layer is
+    named.  Covers both the reference input (1248x384) and BASELINE.json's 1242x375 with its
+    irregular SAME paddings (conv1 (1,1,0,1), pool1 (0,1,1,1), pool5 (1,1,0,1))."""
+    m, mc, params, storage = _model("squeezeDet", dtype, 1, size)
+    x = O.synthetic_images(1, size[0], size[1], seed=1, storage=storage)
+    col = {}
+    O.forward("squeezeDet", params, x, storage, collect=col)
+    # walk the graph: every conv / pool / concat node by name
+    nodes = {}
+    stack = [m.preds]
+    while stack:
+        n = stack.pop()
+        if n.name and n.name not in nodes:
+            nodes[n.name] = n
+        stack.extend(n.inputs)
+    names = [k for k in col if k in nodes or (k + "/concat") in nodes]
+    fetch = [nodes.get(k, nodes.get(k + "/concat")) for k in names]
+    outs = m.run(fetch, {m.image_input: x}, use_plan=False)
+    torch.cuda.synchronize()
+    for k, o in zip(names, outs):
+        _check_layers(o, col[k], dtype, k)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+def test_native_plan_equals_builder_graph_and_oracle(dtype):
+    m, mc, params, storage = _model("squeezeDet", dtype, 2, (375, 1242))
+    x = O.synthetic_images(2, 375, 1242, seed=2, storage=storage)
+    p_plan = m.run([m.preds], {m.image_input: x}, use_plan=True)[0]
+    p_graph = m.run([m.preds], {m.image_input: x}, use_plan=False)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(p_plan, p_graph), "native plan and op-by-op graph must run the same kernels"
+    ref = O.forward("squeezeDet", params, x, storage)
+    _check_layers(p_plan, ref, dtype, "preds")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+def test_squeezedet_plus_vs_oracle(dtype):
+    m, mc, params, storage = _model("squeezeDet+", dtype, 1)
+    x = O.synthetic_images(1, 375, 1242, seed=3, storage=storage)
+    got = m.run([m.preds], {m.image_input: x})[0]
+    torch.cuda.synchronize()
+    assert tuple(got.shape) == (1, 22, 76, 72)
+    ref = O.forward("squeezeDet+", params, x, storage)
+    _check_layers(got, ref, dtype, "squeezeDet+ preds")
+
+
+def test_demo_call_shape_and_stagewise_bit_exact_picks():
+    """demo.py:193-205 shaped caller: sess.run([det_boxes, det_probs, det_class], feed_dict) ->
+    model.filter_prediction(...).  Stage-wise parity: the SAME float32
+    det_boxes/probs/class fed to the oracle's filter_prediction give identical picks."""
+    from squeezedet_amd.nn_skeleton import Session
+    m, mc, params, storage = _model("squeezeDet", torch.float32, 1)
+    x = O.synthetic_images(1, 384, 1248, seed=4)
+    with Session() as sess:
+        det_boxes, det_probs, det_class = sess.run([m.det_boxes, m.det_probs, m.det_class],
+                                                   feed_dict={m.image_input: [x[0].numpy()]})
+    assert det_boxes.shape == (1, 16848, 4) and det_boxes.dtype == np.float32
+    assert det_probs.shape == (1, 16848) and det_class.dtype == np.int64
+    final_boxes, final_probs, final_class = m.filter_prediction(det_boxes[0], det_probs[0], det_class[0])
+    assert isinstance(final_boxes, list) and len(final_boxes) == len(final_probs) == len(final_class) <= 64
+    fb, fp, fc = O.filter_prediction(O.kitti_squeezeDet_config(), det_boxes[0], det_probs[0], det_class[0])
+    assert final_class == fc
+    np.testing.assert_array_equal(np.array(final_probs, np.float32), np.array(fp, np.float32))
+    np.testing.assert_array_equal(np.array(final_boxes, np.float32).reshape(-1, 4), np.array(fb, np.float32).reshape(-1, 4))
+    keep_idx = [i for i in range(len(final_probs)) if final_probs[i] > mc.PLOT_PROB_THRESH]  # demo.py:201-205
+    assert all(0 <= final_class[i] < 3 for i in keep_idx)
+    # end-to-end vs the oracle run from the image: decoded outputs within float tolerance
+    _, out, _ = O.detect("squeezeDet", O.kitti_squeezeDet_config(), params, x)
+    np.testing.assert_allclose(det_probs, out["det_probs"], rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(det_boxes, out["det_boxes"], rtol=2e-3, atol=5e-2)
+
+
+def test_full_config_properties_batch32_fp16():
+    """BASELINE.json configs[1]: SqueezeDet fp16, batch 32, synthetic 1242x375.  The oracle
+    needs seconds per image, so here: (i) images 0 and 17 against the oracle, (ii) batch
+    independence -- every image's result equals the same image run in a batch of 1 (bitwise),
+    (iii) the post-processing invariants every image must satisfy."""
+    m, mc, params, storage = _model("squeezeDet", torch.float16, 32, (375, 1242))
+    x = O.synthetic_images(32, 375, 1242, seed=5, storage="fp16")
+    xd = x.to(DEV, torch.float16)
+    preds = m.run([m.preds], {m.image_input: xd})[0]
+    boxes, probs, cls = m.detect(xd)
+    ob, op, oc, oi, cnt = m.filter_prediction_batch(boxes, probs, cls)
+    torch.cuda.synchronize()
+    for i in (0, 17):
+        ref = O.forward("squeezeDet", params, x[i:i + 1], "fp16")
+        _check_layers(preds[i:i + 1], ref, torch.float16, "preds[%d]" % i)
+    m1, _, _, _ = _model("squeezeDet", torch.float16, 1, (375, 1242))
+    for i in (3, 31):
+        p1 = m1.run([m1.preds], {m1.image_input: xd[i:i + 1].contiguous()})[0]
+        assert torch.equal(p1[0], preds[i]), "image %d differs between batch 32 and batch 1" % i
+    n = cnt.cpu().numpy()
+    assert (n >= 1).all() and (n <= 64).all()
+    oc_, op_, oi_ = oc.cpu().numpy(), op.cpu().numpy(), oi.cpu().numpy()
+    pr = probs.cpu().numpy()
+    for i in range(32):
+        k = n[i]
+        c = oc_[i, :k]
+        assert (np.diff(c) >= 0).all()                                   # ordered by class
+        for cc in range(3):
+            pp = op_[i, :k][c == cc]
+            assert (np.diff(pp) <= 0).all()                              # then descending prob
+        assert len(set(oi_[i, :k].tolist())) == k                        # distinct anchors
+        thr = np.sort(pr[i])[-64]
+        assert (pr[i][oi_[i, :k]] >= thr).all()                          # all from the top-64
+        np.testing.assert_array_equal(pr[i][oi_[i, :k]], op_[i, :k])
+    # idempotence: filtering the already-filtered detections changes nothing
+    fb, fp, fc, fi = O.filter_prediction(O.squeezeDet_config_for_input(375, 1242), boxes[7].cpu().numpy(),
+                                         probs[7].cpu().numpy(), cls[7].cpu().numpy(), return_index=True)
+    np.testing.assert_array_equal(oi_[7, :n[7]], np.array(fi, np.int32))

@@ -1,0 +1,279 @@
+"""GPU parity tests, op level: every HIP kernel called through the C ABI (squeezedet_amd.ops
+-> ctypes -> libsqdet_hip.so) against the CPU oracle on the same seeded inputs.
+
+Tolerances (stated per test):
+  * fp32 convs: 1e-3 relative (BASELINE.json north_star); observed error is ~1e-6 (exact-f32 MFMA).
+  * fp16 convs: compared with the oracle in fp16-storage mode (same fp16 operands, fp32
+    accumulate, one fp16 rounding of the result) -> 2 fp16 ulps (2^-9 relative) + 1e-3 abs.
+  * max-pool, top-N/NMS picks, indices, classes: bit-exact.
+  * interpret_output floats: 2e-6 relative (device expf vs NumPy exp differ in the last ulp).
+"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sqdet_oracle as O
+from tests.golden import cases
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _ops():
+    from squeezedet_amd import ops
+    return ops
+
+
+def _rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def test_mfma_fragment_layout_probe():
+    """The conv kernels assume: operand lane l = (row/col l&15, k-group l>>4); accumulator
+    register r of lane l = D[4*(l>>4)+r][l&15] (cdna_hip_programming.md section 3)."""
+    lay = _ops().probe_mfma_layout()
+    for shape in range(2):
+        for l in range(64):
+            for r in range(4):
+                row, col = lay[shape, l, r]
+                assert (row, col) == (4 * (l >> 4) + r, l & 15), "shape %d lane %d reg %d -> (%d,%d)" % (shape, l, r, row, col)
+
+
+# (name, N, H, W, Cin, Cout, k, stride, padding, relu)
+CONV_CASES = [
+    ("conv1_375x1242_like", 2, 37, 53, 3, 64, 3, 2, "SAME", True),      # pads (1,1)/(0,1): odd/odd sizes
+    ("conv1_384x1248_like", 1, 36, 48, 3, 64, 3, 2, "SAME", True),      # pads (0,1)
+    ("conv1_plus_7x7_valid", 1, 41, 57, 3, 96, 7, 2, "VALID", True),
+    ("fire2_squeeze", 2, 23, 31, 64, 16, 1, 1, "SAME", True),
+    ("fire3_squeeze", 1, 23, 31, 128, 16, 1, 1, "SAME", True),
+    ("fire2_expand1x1", 2, 23, 31, 16, 64, 1, 1, "SAME", True),
+    ("fire2_expand3x3", 2, 23, 31, 16, 64, 3, 1, "SAME", True),
+    ("fire4_expand3x3", 1, 12, 39, 32, 128, 3, 1, "SAME", True),
+    ("fire6_squeeze", 1, 12, 20, 256, 48, 1, 1, "SAME", True),
+    ("fire6_expand1x1", 1, 12, 20, 48, 192, 1, 1, "SAME", True),
+    ("fire6_expand3x3", 1, 12, 20, 48, 192, 3, 1, "SAME", True),
+    ("fire8_expand3x3", 1, 9, 14, 64, 256, 3, 1, "SAME", True),
+    ("fire11_squeeze", 1, 9, 14, 768, 96, 1, 1, "SAME", True),
+    ("fire10_expand3x3", 1, 9, 14, 96, 384, 3, 1, "SAME", True),
+    ("conv12_convdet", 2, 7, 13, 768, 72, 3, 1, "SAME", False),
+    ("plus_fire6_squeeze", 1, 9, 11, 256, 288, 1, 1, "SAME", True),
+    ("stride2_3x3_valid", 1, 15, 17, 16, 32, 3, 2, "VALID", True),
+    ("stride2_3x3_same_even", 1, 16, 18, 8, 20, 3, 2, "SAME", False),
+    ("one_pixel", 1, 1, 1, 16, 16, 3, 1, "SAME", True),
+]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_parity(case, dtype):
+    ops = _ops()
+    name, N, H, W, Cin, Cout, k, s, pad, relu = case
+    rs = np.random.RandomState(zlib.crc32(name.encode()) % (2 ** 31))
+    x = rs.randn(N, H, W, Cin).astype(np.float32)
+    w = (rs.randn(k, k, Cin, Cout) * (2.0 / (k * k * Cin)) ** 0.5).astype(np.float32)
+    b = rs.uniform(-0.5, 0.5, Cout).astype(np.float32)
+    tdt = torch.float16 if dtype == "fp16" else torch.float32
+    xt, wt, bt = torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b)
+    if dtype == "fp16":
+        xt, wt = xt.half().float(), wt.half().float()
+    ref = O.conv_layer(xt, wt, bt, s, pad, relu, storage=dtype).numpy()
+    packed = ops.pack_conv_weights(wt.to(DEV), tdt)
+    y = ops.conv2d_nhwc(xt.to(DEV, tdt).contiguous(), packed, bt.to(DEV), s, pad, relu)
+    torch.cuda.synchronize()
+    got = y.float().cpu().numpy()
+    assert got.shape == ref.shape
+    if dtype == "fp32":
+        # north_star tolerance: 1e-3 relative; the exact-f32 MFMA path lands around 1e-6
+        np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-4)
+        assert _rel_err(got, ref) < 1e-4
+    else:
+        np.testing.assert_allclose(got, ref, rtol=2 ** -9, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_conv2d_concat_offset_and_fire(dtype):
+    """expand1x1 / expand3x3 write the two halves of one concat tensor (nets/squeezeDet.py:106);
+    sqdet_fire_fwd == the three convs."""
+    ops = _ops()
+    tdt = torch.float16 if dtype == "fp16" else torch.float32
+    p = {k: v for k, v in O.init_params("squeezeDet", seed=3, storage=dtype).items() if k.startswith("fire4/")}
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy(np.maximum(rs.randn(2, 13, 21, 128), 0).astype(np.float32))
+    if dtype == "fp16":
+        x = x.half().float()
+    ref = O.fire_layer(p, "fire4", x, storage=dtype).numpy()
+    pk = {n: ops.pack_conv_weights(p["fire4/%s/kernels" % n].to(DEV), tdt) for n in ("squeeze1x1", "expand1x1", "expand3x3")}
+    bs = {n: p["fire4/%s/biases" % n].to(DEV) for n in pk}
+    y = ops.fire(x.to(DEV, tdt).contiguous(), pk["squeeze1x1"], bs["squeeze1x1"], pk["expand1x1"], bs["expand1x1"],
+                 pk["expand3x3"], bs["expand3x3"])
+    torch.cuda.synchronize()
+    got = y.float().cpu().numpy()
+    assert got.shape == ref.shape == (2, 13, 21, 256)
+    tol = dict(rtol=1e-3, atol=1e-4) if dtype == "fp32" else dict(rtol=2 ** -8, atol=2e-3)
+    np.testing.assert_allclose(got, ref, **tol)
+
+
+POOL_CASES = [(2, 37, 53, 64, 3, 2, "SAME"), (1, 188, 621, 8, 3, 2, "SAME"), (1, 47, 156, 16, 3, 2, "SAME"),
+              (1, 94, 311, 8, 3, 2, "SAME"), (1, 41, 57, 96, 3, 2, "VALID"), (1, 12, 14, 8, 2, 2, "SAME"), (1, 3, 3, 8, 3, 2, "SAME")]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("case", POOL_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_maxpool_parity_bit_exact(case, dtype):
+    ops = _ops()
+    N, H, W, C, k, s, pad = case
+    rs = np.random.RandomState(H * 1000 + W)
+    x = torch.from_numpy((rs.randn(N, H, W, C) - 1.0).astype(np.float32))  # mostly negative: zero padding would win
+    tdt = torch.float16 if dtype == "fp16" else torch.float32
+    xq = x.to(tdt)
+    ref = O.pooling_layer(xq.float(), k, s, pad).numpy()
+    y = ops.maxpool_nhwc(xq.to(DEV).contiguous(), k, s, pad)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(y.float().cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("cfg", ["squeezeDet", "squeezeDet+"])
+def test_interpret_output_parity(cfg, dtype):
+    ops = _ops()
+    mc = O.kitti_squeezeDet_config() if cfg == "squeezeDet" else O.kitti_squeezeDetPlus_config()
+    gh, gw = (24, 78) if cfg == "squeezeDet" else (22, 76)
+    rs = np.random.RandomState(11)
+    preds = (rs.randn(3, gh, gw, 72) * 1.7).astype(np.float32)
+    preds[0, :, :, 36:] *= 2.0  # push some dw/dh beyond EXP_THRESH so both safe_exp branches run
+    tdt = torch.float16 if dtype == "fp16" else torch.float32
+    pt = torch.from_numpy(preds).to(tdt)
+    ref = O.interpret_output(pt.float().numpy(), mc)
+    anchors = torch.from_numpy(mc.ANCHOR_BOX.astype(np.float32)).to(DEV)
+    boxes, probs, cls, pcp, pconf = ops.interpret_output(pt.to(DEV).contiguous(), anchors, mc.CLASSES, mc.ANCHOR_PER_GRID,
+                                                         mc.IMAGE_WIDTH, mc.IMAGE_HEIGHT, mc.EXP_THRESH, with_class_probs=True)
+    torch.cuda.synchronize()
+    assert boxes.dtype == torch.float32 and probs.dtype == torch.float32 and cls.dtype == torch.int64
+    # 2e-6 relative: device expf vs NumPy exp may differ in the last ulp
+    np.testing.assert_allclose(pcp.cpu().numpy(), ref["pred_class_probs"], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(pconf.cpu().numpy(), ref["pred_conf"], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(probs.cpu().numpy(), ref["det_probs"], rtol=3e-6, atol=1e-9)
+    np.testing.assert_allclose(boxes.cpu().numpy(), ref["det_boxes"], rtol=2e-6, atol=2e-4)
+    # classes: exact wherever the top-2 class scores are separated by more than the exp ulp noise
+    pr = ref["pred_class_probs"] * ref["pred_conf"][..., None]
+    srt = np.sort(pr, axis=2)
+    clear = (srt[..., -1] - srt[..., -2]) > 1e-5 * srt[..., -1]
+    got_cls = cls.cpu().numpy()
+    assert clear.mean() > 0.99
+    np.testing.assert_array_equal(got_cls[clear], ref["det_class"][clear])
+    # boxes that do not touch an exp() are bit-exact: cx/cy only depend on mul/add when unclipped
+    assert (boxes.cpu().numpy()[..., 2:] >= 1.0).all()
+
+
+def _gpu_filter(boxes, probs, cls, mc, max_out=None):
+    ops = _ops()
+    b = torch.from_numpy(boxes).to(DEV).reshape(1, -1, 4).contiguous()
+    p = torch.from_numpy(probs).to(DEV).reshape(1, -1).contiguous()
+    c = torch.from_numpy(cls).to(DEV).reshape(1, -1).contiguous()
+    ob, op, oc, oi, cnt = ops.filter_prediction(b, p, c, mc.CLASSES, mc.TOP_N_DETECTION, mc.NMS_THRESH, mc.PROB_THRESH, max_out)
+    torch.cuda.synchronize()
+    n = int(cnt[0])
+    return ob[0, :n].cpu().numpy(), op[0, :n].cpu().numpy(), oc[0, :n].cpu().numpy(), oi[0, :n].cpu().numpy(), n
+
+
+@pytest.mark.parametrize("name", cases.FILTER_CASES)
+def test_filter_prediction_vs_reference_golden(golden_dir, name):
+    """Bit-exact against the outputs of the reference's own filter_prediction."""
+    g = np.load(os.path.join(golden_dir, "filter_prediction.npz"))
+    boxes, probs, cls, overrides = cases.make_filter_case(name)
+    mc = O.kitti_squeezeDet_config()
+    for k, v in overrides.items():
+        mc[k] = v
+    ob, op, oc, oi, n = _gpu_filter(boxes, probs, cls, mc)
+    assert n == len(g[name + "_probs"])
+    np.testing.assert_array_equal(ob, g[name + "_boxes"])
+    np.testing.assert_array_equal(op, g[name + "_probs"])
+    np.testing.assert_array_equal(oc.astype(np.int64), g[name + "_cls"])
+    # anchor indices: bit-exact against the oracle (the reference does not return them)
+    _, _, _, idx = O.filter_prediction(mc, boxes, probs, cls, return_index=True)
+    np.testing.assert_array_equal(oi, np.array(idx, np.int32))
+    np.testing.assert_array_equal(boxes[oi], ob)
+
+
+def test_filter_prediction_batched_random_vs_oracle():
+    ops = _ops()
+    mc = O.kitti_squeezeDet_config()
+    B, A = 5, 16848
+    rs = np.random.RandomState(123)
+    centers = rs.uniform([100, 60, 40, 30], [1100, 320, 250, 150], size=(B, 8, 4))
+    which = rs.randint(0, 8, (B, A))
+    boxes = np.take_along_axis(centers, which[..., None].repeat(4, 2), 1) + rs.normal(0, 1, (B, A, 4)) * [14, 9, 12, 9]
+    boxes[..., 2:] = np.maximum(boxes[..., 2:], 1.0)
+    boxes = boxes.astype(np.float32)
+    probs = (rs.uniform(0, 1, (B, A)) ** 6).astype(np.float32)
+    cls = rs.randint(0, 3, (B, A)).astype(np.int64)
+    ob, op, oc, oi, cnt = ops.filter_prediction(torch.from_numpy(boxes).to(DEV), torch.from_numpy(probs).to(DEV),
+                                                torch.from_numpy(cls).to(DEV), 3, 64, 0.4, 0.005)
+    torch.cuda.synchronize()
+    for i in range(B):
+        fb, fp, fc, fi = O.filter_prediction(mc, boxes[i], probs[i], cls[i], return_index=True)
+        n = int(cnt[i])
+        assert n == len(fp)
+        np.testing.assert_array_equal(oi[i, :n].cpu().numpy(), np.array(fi, np.int32))
+        np.testing.assert_array_equal(op[i, :n].cpu().numpy(), np.array(fp, np.float32))
+        np.testing.assert_array_equal(ob[i, :n].cpu().numpy(), np.array(fb, np.float32).reshape(-1, 4))
+        np.testing.assert_array_equal(oc[i, :n].cpu().numpy(), np.array(fc, np.int32))
+        assert (oc[i, n:].cpu().numpy() == -1).all()
+
+
+def test_filter_prediction_tie_rule_and_small_inputs():
+    """Ties: descending prob, then HIGHER anchor index first -- the rule the
+    oracle's stable_desc_order states.  Also A < TOP_N (threshold branch) and A == 1."""
+    mc = O.kitti_squeezeDet_config()
+    rs = np.random.RandomState(9)
+    A = 500
+    boxes = np.stack([rs.uniform(0, 1247, A), rs.uniform(0, 383, A), rs.uniform(1, 40, A), rs.uniform(1, 40, A)], 1).astype(np.float32)
+    probs = np.round(rs.uniform(0, 1, A), 2).astype(np.float32)  # heavy ties
+    cls = rs.randint(0, 3, A).astype(np.int64)
+    ob, op, oc, oi, n = _gpu_filter(boxes, probs, cls, mc)
+    fb, fp, fc, fi = O.filter_prediction(mc, boxes, probs, cls, return_index=True)
+    np.testing.assert_array_equal(oi, np.array(fi, np.int32))
+    np.testing.assert_array_equal(op, np.array(fp, np.float32))
+    for A in (1, 7, 64):  # A <= TOP_N -> nn_skeleton.py:716-720 threshold branch
+        ob, op, oc, oi, n = _gpu_filter(boxes[:A], probs[:A], cls[:A], mc, max_out=64)
+        fb, fp, fc, fi = O.filter_prediction(mc, boxes[:A], probs[:A], cls[:A], return_index=True)
+        np.testing.assert_array_equal(oi, np.array(fi, np.int32))
+
+
+def test_filter_prediction_threshold_overflow_reports_count():
+    mc = O.kitti_squeezeDet_config()
+    mc.TOP_N_DETECTION = 0
+    mc.PROB_THRESH = 0.5
+    boxes, probs, cls, _ = cases.make_filter_case("uniform0")
+    ops = _ops()
+    out = ops.filter_prediction(torch.from_numpy(boxes).to(DEV)[None], torch.from_numpy(probs).to(DEV)[None],
+                                torch.from_numpy(cls).to(DEV)[None], 3, 0, 0.4, 0.5, max_out=128)
+    torch.cuda.synchronize()
+    assert int(out[4][0]) == -int((probs > 0.5).sum())
+
+
+def test_util_nms_known_answers(golden_dir):
+    from squeezedet_amd import util
+    g = np.load(os.path.join(golden_dir, "util_kat.npz"))
+    assert util.nms(g["iou_boxes"], g["nms_probs"], 0.4) == [True, False, True, False]
+    assert util.nms(g["chain_boxes"], g["chain_probs"], 0.4) == [True, False, False]  # non-greedy
+    rs = np.random.RandomState(4)
+    n = 300
+    bx = np.stack([rs.uniform(0, 400, n), rs.uniform(0, 300, n), rs.uniform(1, 200, n), rs.uniform(1, 150, n)], 1).astype(np.float32)
+    pr = rs.uniform(0, 1, n).astype(np.float32)
+    assert util.nms(bx, pr, 0.4) == O.nms(bx, pr, 0.4)
+
+
+def test_cpu_tensors_are_rejected():
+    from squeezedet_amd._lib import SqdetError
+    ops = _ops()
+    with pytest.raises(SqdetError):
+        ops.maxpool_nhwc(torch.zeros(1, 8, 8, 8), 3, 2, "SAME")
+    with pytest.raises(SqdetError):
+        ops.maxpool_nhwc(torch.zeros(1, 8, 8, 6, device=DEV), 3, 2, "SAME")  # channels not a multiple of 4
