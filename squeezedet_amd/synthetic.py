@@ -23,8 +23,10 @@ def synthetic_params(model, seed=0):
         shp = tuple(p.shape)
         if name.endswith("/kernels"):
             sigma = math.sqrt(2.0 / (shp[0] * shp[1] * shp[2]))
+            if name.startswith("conv1/"):
+                sigma /= 64.0   # inputs are pixel-scale (rms ~74): bring activations to O(1)
             if name.startswith("conv12"):
-                sigma *= 2.0
+                sigma *= 2.0    # preds of std ~2: scores spread without saturating
             z = np.clip(rng.standard_normal(size=shp), -2.0, 2.0)
             out[name] = torch.from_numpy((z * sigma).astype(np.float32))
         else:

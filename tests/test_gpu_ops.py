@@ -159,7 +159,8 @@ def test_interpret_output_parity(cfg, dtype):
     np.testing.assert_allclose(pcp.cpu().numpy(), ref["pred_class_probs"], rtol=2e-6, atol=1e-9)
     np.testing.assert_allclose(pconf.cpu().numpy(), ref["pred_conf"], rtol=2e-6, atol=1e-9)
     np.testing.assert_allclose(probs.cpu().numpy(), ref["det_probs"], rtol=3e-6, atol=1e-9)
-    np.testing.assert_allclose(boxes.cpu().numpy(), ref["det_boxes"], rtol=2e-6, atol=2e-4)
+    # box corners are differences of ~1e3-magnitude terms through exp(): a last-ulp exp difference is ~1e-4 absolute
+    np.testing.assert_allclose(boxes.cpu().numpy(), ref["det_boxes"], rtol=2e-6, atol=1e-3)
     # classes: exact wherever the top-2 class scores are separated by more than the exp ulp noise
     pr = ref["pred_class_probs"] * ref["pred_conf"][..., None]
     srt = np.sort(pr, axis=2)
