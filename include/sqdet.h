@@ -41,6 +41,9 @@ enum { SQDET_ARCH_SQUEEZEDET = 0, SQDET_ARCH_SQUEEZEDET_PLUS = 1 };
 
 const char* sqdet_version(void);
 const char* sqdet_last_error(void);
+/* Tuning knobs (process-wide).  "conv_algo": 0 = auto (specialised kernels when eligible,
+ * default), 1 = generic implicit-GEMM kernels only (also env SQDET_CONV_ALGO=generic). */
+int sqdet_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------ conv --
  * Replaces ModelSkeleton._conv_layer (nn_skeleton.py:471-563):

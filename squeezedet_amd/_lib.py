@@ -20,6 +20,7 @@ vp, ci, cf, cd, sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
 SIGNATURES = {
     "sqdet_version": (C.c_char_p, []),
     "sqdet_last_error": (C.c_char_p, []),
+    "sqdet_set_option": (ci, [C.c_char_p, ci]),
     "sqdet_conv_packed_bytes": (sz, [ci, ci, ci, ci]),
     "sqdet_conv_pack_weights": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "sqdet_conv2d_nhwc_fwd": (ci, [vp, vp, vp, vp] + [ci] * 12 + [vp]),

@@ -18,7 +18,10 @@ LIB = os.path.join(PKG, "libsqdet_hip.so")
 # (source, extra flags).  postproc.hip must not contract mul+add (bit-exact decode / IoU).
 SOURCES = [
     ("common.cpp", []),
-    ("conv.hip", []),
+    # MFMA accumulators in VGPRs (unified gfx950 register file): hipcc's default AGPR form keeps a
+    # second copy of the accumulators in VGPRs around the epilogue and halves occupancy.
+    ("conv.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    ("conv3x3.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("pool.hip", []),
     ("postproc.hip", ["-ffp-contract=off"]),
     ("probe.hip", []),

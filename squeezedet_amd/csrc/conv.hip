@@ -17,52 +17,12 @@
 //   conv_direct<T,MT,NT>  any k/stride/pad, Cin % (16/sizeof(T)) == 0; B fragments read from
 //                         global/L1/L2 with per-tap bounds predication (zero padding).
 //   conv_gather<T,MT,NT>  tiny Cin (the 3-channel stems): K' = k*k*Cin im2col-gathered.
-#include "common.h"
+#include <stdlib.h>
+#include <string.h>
+
+#include "conv_common.h"
 
 namespace sqdet {
-
-template <typename T> struct Tr;
-template <> struct Tr<f16> { static constexpr int KG = 8; };
-template <> struct Tr<float> { static constexpr int KG = 4; };
-
-template <typename T>
-__device__ __forceinline__ void mma16(f32x4& acc, const i32x4& a, const i32x4& b);
-template <>
-__device__ __forceinline__ void mma16<f16>(f32x4& acc, const i32x4& a, const i32x4& b) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
-}
-template <>
-__device__ __forceinline__ void mma16<float>(f32x4& acc, const i32x4& a, const i32x4& b) {
-  f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc, 0, 0, 0);
-}
-
-struct ConvArgs {
-  const void* x;
-  const void* wp;
-  const float* bias;
-  void* y;
-  int N, H, W, Cin, Cout, k, stride, pt, pl, Ho, Wo;
-  int P;        // N*Ho*Wo output pixels
-  int ntiles;   // ceil(P / (16*MT))
-  int nchunk, steps, ngroups;
-  int y_cstride, y_coffset, relu;
-};
-
-template <typename T>
-__device__ __forceinline__ void store4(T* dst, const f32x4& v);
-template <>
-__device__ __forceinline__ void store4<f16>(f16* dst, const f32x4& v) {
-  f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-  *reinterpret_cast<f16x4*>(dst) = h;
-}
-template <>
-__device__ __forceinline__ void store4<float>(float* dst, const f32x4& v) {
-  *reinterpret_cast<f32x4*>(dst) = v;
-}
 
 template <typename T, int MT, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][NT], const int (&pix)[MT],
@@ -310,15 +270,39 @@ int conv2d_launch(const void* x, const void* w_packed, const float* bias, void* 
   a.ntiles = 0;
   a.nchunk = g.nchunk; a.steps = g.steps; a.ngroups = g.ngroups;
   a.y_cstride = y_cstride; a.y_coffset = y_coffset; a.relu = relu;
-  int rc = dtype == SQDET_F16 ? dispatch_mt<f16>(a, g.nt, g.gather, st) : dispatch_mt<float>(a, g.nt, g.gather, st);
+  bool handled = false;
+  int rc = conv3x3_tile_launch(a, g, dtype, st, &handled);
+  if (rc != SQDET_OK || handled) return rc;
+  rc = dtype == SQDET_F16 ? dispatch_mt<f16>(a, g.nt, g.gather, st) : dispatch_mt<float>(a, g.nt, g.gather, st);
   if (rc != SQDET_OK) return rc;
   SQDET_CHECK_HIP(hipGetLastError());
   return SQDET_OK;
 }
 
+static int g_conv_algo = -1;
+int conv_algo() {
+  if (g_conv_algo < 0) {
+    const char* e = getenv("SQDET_CONV_ALGO");
+    g_conv_algo = (e && !strcmp(e, "generic")) ? 1 : 0;
+  }
+  return g_conv_algo;
+}
+void set_conv_algo(int v) { g_conv_algo = v; }
+
 }  // namespace sqdet
 
 using namespace sqdet;
+
+extern "C" int sqdet_set_option(const char* name, int value) {
+  SQDET_REQUIRE(name, "set_option: null name");
+  if (!strcmp(name, "conv_algo")) {
+    SQDET_REQUIRE(value == 0 || value == 1, "set_option: conv_algo must be 0 (auto) or 1 (generic kernels only)");
+    set_conv_algo(value);
+    return SQDET_OK;
+  }
+  set_error("set_option: unknown option '%s'", name);
+  return SQDET_EINVAL;
+}
 
 extern "C" size_t sqdet_conv_packed_bytes(int k, int cin, int cout, int dtype) {
   if (k <= 0 || cin <= 0 || cout <= 0 || (dtype != SQDET_F16 && dtype != SQDET_F32)) return 0;

@@ -1,0 +1,272 @@
+// 3x3 / stride-1 / SAME convolution with an LDS-staged halo tile (the expand3x3 layers of the
+// fire modules and the ConvDet head; reference src/nn_skeleton.py:471-563 via
+// nets/squeezeDet.py:103-105 and :76-79).
+//
+// One 256-thread workgroup owns an 8-row x 16-column output tile of one image.
+//   * The (8+2) x (16+2) input halo tile is staged ONCE into LDS (zero-filled outside the image =
+//     TF SAME padding), laid out [64-byte K-chunk][pixel][4 x 16 B] with the 16-byte slot of lane
+//     group g stored at  g ^ ((pixel>>1)&3).  With that XOR every ds_read_b128 of a B fragment
+//     (16 consecutive pixels of one row, 16 B each) is bank-conflict free for any alignment of the
+//     first pixel (checked exhaustively against the ds_read_b128 lane-group model of
+//     MI355X_MICROARCH.md section LDS).  All 9 taps then read LDS: no re-read of the input through L1/L2.
+//   * Weights stay the MFMA A operand, read as 1-KiB fragments straight from global (L1/L2);
+//     every wave computes ALL 8 pixel blocks of the tile (MT = 8), so one A fragment feeds 8
+//     MFMAs (128 B of L1 traffic per MFMA) and one B fragment feeds NTW.
+//   * COUT-split mode (expand3x3): the 4 waves own different cout tiles (NTW = 1..3 tiles each).
+//   * SPLIT-K mode (ConvDet, Cin = 768, 72 couts = 5 tiles): every wave owns all 5 cout tiles
+//     and a quarter of K -- the input is staged in stages of 4 K-chunks, wave w taking chunk w --
+//     and the 4 partial accumulators are summed through LDS at the end.
+#include "conv_common.h"
+
+namespace sqdet {
+
+constexpr int TROWS = 8;                      // output rows per tile
+constexpr int TCOLS = 16;                     // output cols per tile (one MFMA pixel block per row)
+constexpr int HP = (TROWS + 2) * (TCOLS + 2); // halo pixels = 180
+constexpr int CHUNK_BYTES = HP * 64;          // one 64-byte K-chunk of the halo tile = 11520 B
+
+struct TileArgs {
+  ConvArgs c;
+  int tiles_x, tiles_y;
+  int nt_pack;      // tiles per packed group
+  int total_tiles;  // cout tiles over all groups
+  int nchunk;       // 64-byte K chunks per pixel (ceil)
+  int pieces;       // 16-byte pieces per pixel actually present = Cin*sizeof(T)/16
+};
+
+// Stage `nload` K-chunks starting at chunk c0 of the halo tile into LDS.
+template <typename T>
+__device__ __forceinline__ void stage_tile(const TileArgs& a, unsigned char* lds, int n, int oy0, int ox0, int c0,
+                                           int nload) {
+  const unsigned char* x = reinterpret_cast<const unsigned char*>(a.c.x);
+  const int row_bytes = a.pieces * 16;  // bytes per pixel in global memory
+  const int ppc = nload * 4;            // pieces per pixel in this stage
+  const int total = HP * ppc;
+  for (int idx = threadIdx.x; idx < total; idx += 256) {
+    const int P = idx / ppc;
+    const int q = idx - P * ppc;          // piece within the staged range
+    const int gq = c0 * 4 + q;            // piece within the pixel
+    const int r = P / (TCOLS + 2), cc = P - r * (TCOLS + 2);
+    const int iy = oy0 - 1 + r, ix = ox0 - 1 + cc;
+    i32x4 v = {0, 0, 0, 0};
+    if (gq < a.pieces && iy >= 0 && iy < a.c.H && ix >= 0 && ix < a.c.W)
+      v = *reinterpret_cast<const i32x4*>(x + (((size_t)n * a.c.H + iy) * a.c.W + ix) * row_bytes + gq * 16);
+    const int c = q >> 2, g = q & 3;
+    *reinterpret_cast<i32x4*>(lds + c * CHUNK_BYTES + P * 64 + ((g ^ ((P >> 1) & 3)) << 4)) = v;
+  }
+}
+
+template <typename T, int NTW, bool SPLITK>
+__global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int MT = TROWS;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+
+  int b = blockIdx.x;
+  const int tx = b % a.tiles_x; b /= a.tiles_x;
+  const int ty = b % a.tiles_y;
+  const int n = b / a.tiles_y;
+  const int oy0 = ty * TROWS, ox0 = tx * TCOLS;
+
+  // which cout tiles this wave owns
+  const int tile0 = SPLITK ? 0 : (blockIdx.y * 4 + wave) * NTW;
+  const bool active = tile0 < a.total_tiles;
+  const int group = tile0 / a.nt_pack;
+  const int n0 = tile0 - group * a.nt_pack;
+
+  f32x4 acc[MT][NTW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const i32x4* wbase = reinterpret_cast<const i32x4*>(a.c.wp) + ((size_t)group * a.c.steps * a.nt_pack + n0) * 64 + lane;
+  const int nstages = SPLITK ? (a.nchunk + 3) / 4 : 1;
+
+  for (int stage = 0; stage < nstages; ++stage) {
+    const int c0 = SPLITK ? stage * 4 : 0;
+    const int nload = SPLITK ? (a.nchunk - c0 < 4 ? a.nchunk - c0 : 4) : a.nchunk;
+    if (stage > 0) __syncthreads();  // everyone done reading the previous stage
+    stage_tile<T>(a, lds, n, oy0, ox0, c0, nload);
+    __syncthreads();
+    if (!active) continue;
+
+    // chunks this wave walks in this stage
+    const int cl_begin = SPLITK ? wave : 0;
+    const int cl_end = SPLITK ? (wave < nload ? wave + 1 : wave) : nload;
+    for (int cl = cl_begin; cl < cl_end; ++cl) {
+      const int c = c0 + cl;                         // global chunk index
+      // (16-byte pieces beyond Cin were zero-filled by stage_tile, so every read is unconditional)
+      const unsigned char* lchunk = lds + cl * CHUNK_BYTES;
+#pragma unroll 1
+      for (int t9 = 0; t9 < 9; ++t9) {
+        const int dy = t9 / 3, dx = t9 - dy * 3;
+        const int P0 = dy * (TCOLS + 2) + j + dx;    // halo pixel of output (row 0, col j) at this tap
+        const int h0 = P0 >> 1;
+        i32x4 bf[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          // pixel P = P0 + 18*m ; (P>>1)&3 == (h0 + 9m)&3 == (h0 + m)&3
+          const int slot = g ^ ((h0 + m) & 3);
+          bf[m] = *reinterpret_cast<const i32x4*>(lchunk + (P0 + (TCOLS + 2) * m) * 64 + (slot << 4));
+        }
+        const i32x4* wp = wbase + (size_t)(t9 * a.nchunk + c) * a.nt_pack * 64;
+        i32x4 af[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) af[t] = wp[t * 64];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], af[t], bf[m]);
+      }
+    }
+  }
+
+  // epilogue: lane = pixel (row m, col j); couts group*16*NTp + g*4*NTp + (n0+t)*4 .. +4 : 4*NTW consecutive
+  T* y = reinterpret_cast<T*>(a.c.y);
+  const int ox = ox0 + j;
+  const int cb = group * 16 * a.nt_pack + g * 4 * a.nt_pack + n0 * 4;
+  f32x4 bias[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+    bias[t] = cb + t * 4 < a.c.Cout ? *reinterpret_cast<const f32x4*>(a.c.bias + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (SPLITK) {
+    // Deterministic sum of the 4 K-partial accumulators through LDS: wave 0 writes, waves 1..3 add in
+    // turn ((w0+w1)+w2)+w3; the accumulators are only ever READ here (they stay in AGPRs).  Then all
+    // four waves share the epilogue, two tile rows each.
+    float* red = reinterpret_cast<float*>(lds);
+    // Every wave passes exactly 5 barriers: `wu` before its turn, 5-wu after it.  (A loop over rounds
+    // with `if (wave == round)` lets LICM hoist all 160 accumulator copies out of the loop.)
+    const int wu = __builtin_amdgcn_readfirstlane(wave);
+    __syncthreads();  // all waves are done reading the input tile (the buffer is reused)
+    for (int r = 0; r < wu; ++r) __syncthreads();
+    {
+      const bool first = wu == 0;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          f32x4* p = reinterpret_cast<f32x4*>(red + ((m * NTW + t) * 64 + lane) * 4);
+          f32x4 v = acc[m][t];
+          if (!first) v += *p;
+          *p = v;
+        }
+        asm volatile("" ::: "memory");  // small batches of accumulator copies
+      }
+    }
+    for (int r = wu; r < 3; ++r) __syncthreads();
+    __syncthreads();
+    if (ox < a.c.W) {
+#pragma unroll
+      for (int mm = 0; mm < MT / 4; ++mm) {
+        const int m = wave * (MT / 4) + mm;
+        const int oy = oy0 + m;
+        if (oy >= a.c.H) break;
+        T* dst = y + (((size_t)n * a.c.H + oy) * a.c.W + ox) * a.c.y_cstride + a.c.y_coffset + cb;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          if (cb + t * 4 < a.c.Cout) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(red + ((m * NTW + t) * 64 + lane) * 4) + bias[t];
+            if (a.c.relu) {
+              v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            }
+            store4<T>(dst + t * 4, v);
+          }
+        }
+      }
+    }
+    return;
+  }
+  if (!active) return;
+
+  if (ox < a.c.W) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int oy = oy0 + m;
+      if (oy >= a.c.H) break;
+      T* dst = y + (((size_t)n * a.c.H + oy) * a.c.W + ox) * a.c.y_cstride + a.c.y_coffset + cb;
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        if (cb + t * 4 < a.c.Cout) {
+          f32x4 v = acc[m][t] + bias[t];
+          if (a.c.relu) {
+            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+          }
+          store4<T>(dst + t * 4, v);
+        }
+      }
+      asm volatile("" ::: "memory");
+    }
+  }
+}
+
+template <typename T, int NTW, bool SPLITK>
+static void launch_tile(const TileArgs& a, int grid_y, size_t lds, hipStream_t st) {
+  const dim3 grid((unsigned)(a.c.N * a.tiles_x * a.tiles_y), (unsigned)grid_y);
+  hipLaunchKernelGGL((conv3x3_tile<T, NTW, SPLITK>), grid, dim3(256), lds, st, a);
+}
+
+template <typename T>
+static bool dispatch_tile(const TileArgs& a, int ntw, bool splitk, int grid_y, size_t lds, hipStream_t st) {
+  if (splitk) {
+    if (ntw == 5) { launch_tile<T, 5, true>(a, 1, lds, st); return true; }
+    return false;
+  }
+  switch (ntw) {
+    case 1: launch_tile<T, 1, false>(a, grid_y, lds, st); return true;
+    case 2: launch_tile<T, 2, false>(a, grid_y, lds, st); return true;
+    case 3: launch_tile<T, 3, false>(a, grid_y, lds, st); return true;
+    default: return false;
+  }
+}
+
+// Eligibility + configuration.  *handled = false means "use the generic kernels".
+int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (conv_algo() != 0) return SQDET_OK;
+  if (c.k != 3 || c.stride != 1 || c.pt != 1 || c.pl != 1 || g.gather) return SQDET_OK;
+  if (c.Ho != c.H || c.Wo != c.W) return SQDET_OK;
+  const int esz = dtype == SQDET_F16 ? 2 : 4;
+  if ((c.Cin * esz) % 16 != 0) return SQDET_OK;
+  TileArgs a;
+  a.c = c;
+  a.tiles_x = (c.W + TCOLS - 1) / TCOLS;
+  a.tiles_y = (c.H + TROWS - 1) / TROWS;
+  a.nt_pack = g.nt;
+  a.total_tiles = g.nt * g.ngroups;
+  a.nchunk = g.nchunk;
+  a.pieces = c.Cin * esz / 16;
+  if ((long)c.N * a.tiles_x * a.tiles_y > 0x7fffffffL) return SQDET_OK;
+
+  int ntw = 0;
+  bool splitk = false;
+  size_t lds = 0;
+  int grid_y = 1;
+  if (g.nt == 5 && g.ngroups == 1 && g.nchunk >= 8) {
+    // ConvDet-like: few couts, deep K -> split K over the 4 waves, 4 chunks per stage
+    ntw = 5; splitk = true;
+    lds = 4 * (size_t)CHUNK_BYTES;                         // 46080 B
+    const size_t red = (size_t)TROWS * 5 * 64 * 16;        // 40960 B reduction buffer
+    if (red > lds) lds = red;
+  } else if (g.nchunk <= 5) {
+    if (g.nt == 4) ntw = g.ngroups == 1 ? 1 : 2;
+    else if (g.nt == 6) ntw = 3;
+    else if (g.nt == 2) ntw = 1;
+    else return SQDET_OK;
+    lds = (size_t)g.nchunk * CHUNK_BYTES;                  // <= 57600 B
+    grid_y = (a.total_tiles + 4 * ntw - 1) / (4 * ntw);
+  } else {
+    return SQDET_OK;
+  }
+  const bool ok = dtype == SQDET_F16 ? dispatch_tile<f16>(a, ntw, splitk, grid_y, lds, st)
+                                     : dispatch_tile<float>(a, ntw, splitk, grid_y, lds, st);
+  if (!ok) return SQDET_OK;
+  SQDET_CHECK_HIP(hipGetLastError());
+  *handled = true;
+  return SQDET_OK;
+}
+
+}  // namespace sqdet

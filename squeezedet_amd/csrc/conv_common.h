@@ -1,0 +1,57 @@
+// Shared device helpers of the conv kernels (conv.hip, conv3x3.hip).
+#pragma once
+#include "common.h"
+
+namespace sqdet {
+
+template <typename T> struct Tr;
+template <> struct Tr<f16> { static constexpr int KG = 8; };
+template <> struct Tr<float> { static constexpr int KG = 4; };
+
+template <typename T>
+__device__ __forceinline__ void mma16(f32x4& acc, const i32x4& a, const i32x4& b);
+template <>
+__device__ __forceinline__ void mma16<f16>(f32x4& acc, const i32x4& a, const i32x4& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma16<float>(f32x4& acc, const i32x4& a, const i32x4& b) {
+  f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc, 0, 0, 0);
+}
+
+struct ConvArgs {
+  const void* x;
+  const void* wp;
+  const float* bias;
+  void* y;
+  int N, H, W, Cin, Cout, k, stride, pt, pl, Ho, Wo;
+  int P;        // N*Ho*Wo output pixels
+  int ntiles;   // ceil(P / (16*MT))
+  int nchunk, steps, ngroups;
+  int y_cstride, y_coffset, relu;
+};
+
+template <typename T>
+__device__ __forceinline__ void store4(T* dst, const f32x4& v);
+template <>
+__device__ __forceinline__ void store4<f16>(f16* dst, const f32x4& v) {
+  f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  *reinterpret_cast<f16x4*>(dst) = h;
+}
+template <>
+__device__ __forceinline__ void store4<float>(float* dst, const f32x4& v) {
+  *reinterpret_cast<f32x4*>(dst) = v;
+}
+
+
+// Which kernel family conv2d_launch may pick: 0 = auto (fast paths when eligible),
+// 1 = generic only (conv_direct / conv_gather).  Set from SQDET_CONV_ALGO=generic (tests, A/B).
+int conv_algo();
+
+int conv3x3_tile_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);
+
+}  // namespace sqdet

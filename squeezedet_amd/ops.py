@@ -144,6 +144,11 @@ def filter_prediction(boxes, probs, cls, classes, top_n, nms_thresh, prob_thresh
     return ob, op, oc, oi, cnt
 
 
+def set_option(name, value):
+    """Process-wide tuning knob (sqdet_set_option), e.g. set_option("conv_algo", 1) = generic kernels only."""
+    check(lib().sqdet_set_option(name.encode(), int(value)), "sqdet_set_option")
+
+
 def probe_mfma_layout():
     """[2 shapes][64 lanes][4 regs][row, col] observed accumulator layout."""
     import numpy as np

@@ -66,12 +66,30 @@ CONV_CASES = [
     ("stride2_3x3_valid", 1, 15, 17, 16, 32, 3, 2, "VALID", True),
     ("stride2_3x3_same_even", 1, 16, 18, 8, 20, 3, 2, "SAME", False),
     ("one_pixel", 1, 1, 1, 16, 16, 3, 1, "SAME", True),
+    # multi-tile shapes for the LDS-tiled 3x3 kernels (8x16 tiles, ragged right/bottom edges)
+    ("e3_multitile_32_128", 2, 19, 37, 32, 128, 3, 1, "SAME", True),
+    ("e3_multitile_48_192", 1, 24, 78, 48, 192, 3, 1, "SAME", True),
+    ("e3_multitile_16_64", 1, 47, 63, 16, 64, 3, 1, "SAME", True),
+    ("e3_multitile_64_256", 1, 24, 40, 64, 256, 3, 1, "SAME", True),
+    ("e3_multitile_96_384", 1, 17, 30, 96, 384, 3, 1, "SAME", True),
+    ("convdet_full_24x78", 1, 24, 78, 768, 72, 3, 1, "SAME", False),
+    ("plus_convdet_22x76", 1, 22, 76, 512, 72, 3, 1, "SAME", False),
 ]
+
+
+@pytest.fixture(params=["auto", "generic"])
+def conv_algo(request):
+    """auto = specialised kernels where eligible (LDS-tiled 3x3, split-K ConvDet, ...);
+    generic = the implicit-GEMM conv_direct / conv_gather kernels only.  Both must match the oracle."""
+    ops = _ops()
+    ops.set_option("conv_algo", 1 if request.param == "generic" else 0)
+    yield request.param
+    ops.set_option("conv_algo", 0)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv2d_parity(case, dtype):
+def test_conv2d_parity(case, dtype, conv_algo):
     ops = _ops()
     name, N, H, W, Cin, Cout, k, s, pad, relu = case
     rs = np.random.RandomState(zlib.crc32(name.encode()) % (2 ** 31))
