@@ -72,6 +72,13 @@ int sqdet_conv2d_nhwc_fwd(const void* x, const void* w_packed, const float* bias
 int sqdet_maxpool_nhwc_fwd(const void* x, void* y, int n, int h, int w, int c, int k, int stride, int pad_mode,
                            int dtype, sqdet_stream_t stream);
 
+/* ------------------------------------------------------------------ stem --
+ * conv1 + pool1 in one launch: relu(conv2d(x, W, stride 2) + b) followed by max_pool 3x3/s2
+ * (nets/squeezeDet.py:40-44: k=3, 64 filters, SAME/SAME; nets/squeezeDetPlus.py:40-44: k=7,
+ * 96 filters, VALID/VALID).  x: [n,h,w,3]; y: [n,hp,wp,cout].  Only those two stems are fused. */
+int sqdet_stem_conv_pool_fwd(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w,
+                             int cout, int k, int conv_pad_mode, int pool_pad_mode, int dtype, sqdet_stream_t stream);
+
 /* ------------------------------------------------------------------ fire --
  * Replaces SqueezeDet._fire_layer (nets/squeezeDet.py:81-106):
  *   sq = relu(conv1x1(x)); y = concat(relu(conv1x1(sq)), relu(conv3x3(sq))).

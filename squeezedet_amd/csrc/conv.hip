@@ -273,6 +273,8 @@ int conv2d_launch(const void* x, const void* w_packed, const float* bias, void* 
   bool handled = false;
   int rc = conv3x3_tile_launch(a, g, dtype, st, &handled);
   if (rc != SQDET_OK || handled) return rc;
+  rc = conv1x1_stream_launch(a, g, dtype, st, &handled);
+  if (rc != SQDET_OK || handled) return rc;
   rc = dtype == SQDET_F16 ? dispatch_mt<f16>(a, g.nt, g.gather, st) : dispatch_mt<float>(a, g.nt, g.gather, st);
   if (rc != SQDET_OK) return rc;
   SQDET_CHECK_HIP(hipGetLastError());

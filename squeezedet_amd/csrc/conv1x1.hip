@@ -1,0 +1,205 @@
+// 1x1 convolution (+bias +ReLU) as a persistent streaming GEMM for gfx950: the squeeze1x1 and
+// expand1x1 layers of the fire modules (reference src/nets/squeezeDet.py:95-102 through
+// src/nn_skeleton.py:471-563).  These layers are HBM-bound (13-82 FLOP/B in fp16), so the kernel
+// is organised around memory traffic, not MFMA rate:
+//   * every wave owns ONE cout group (<= 6 tiles of 16 couts) and keeps that group's weights --
+//     all NCH K-chunks x NT tiles of A fragments -- in REGISTERS for its whole life;
+//   * it then grid-strides over pixel tiles (MT blocks of 16 NHWC pixels): B fragments are
+//     16-byte loads straight from the activation tensor (a 1x1 conv needs no halo, no LDS), the
+//     NEXT tile's loads are issued before the current tile's MFMAs (register double buffer);
+//   * the epilogue stores 4*NT consecutive channels per lane as 16-byte vectors.
+// Waves of different cout groups read the same pixels; K << Cout for the expand layers, so that
+// re-read (served by L2) is small next to the output stream.
+#include "conv_common.h"
+
+namespace sqdet {
+
+template <typename T, int NT>
+__device__ __forceinline__ void store_row(T* dst, const f32x4 (&v)[NT]);
+
+template <int NT>
+struct StoreRow16 {
+  static __device__ __forceinline__ void run(f16* dst, const f32x4 (&v)[NT]) {
+#pragma unroll
+    for (int t = 0; t + 1 < NT; t += 2) {
+      f16x8 h = {(f16)v[t][0], (f16)v[t][1], (f16)v[t][2], (f16)v[t][3],
+                 (f16)v[t + 1][0], (f16)v[t + 1][1], (f16)v[t + 1][2], (f16)v[t + 1][3]};
+      *reinterpret_cast<f16x8*>(dst + t * 4) = h;
+    }
+    if (NT & 1) store4<f16>(dst + (NT - 1) * 4, v[NT - 1]);
+  }
+};
+
+struct C1Args {
+  ConvArgs c;
+  int ntiles;      // pixel tiles of MT*16
+  int nstreams;    // waves per cout group
+};
+
+template <typename T, int NCH, int NT, int MT>
+__global__ __launch_bounds__(256) void conv1x1_stream(C1Args a) {
+  constexpr int KG = Tr<T>::KG;
+  constexpr int KC = 4 * KG;
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);   // global wave id
+  const int group = gw % a.c.ngroups;
+  const int stream = gw / a.c.ngroups;
+  if (stream >= a.nstreams) return;
+  const int j = lane & 15, g = lane >> 4;
+
+  // this wave's weights: [NCH][NT] fragments, resident in registers
+  i32x4 af[NCH][NT];
+  {
+    const i32x4* wp = reinterpret_cast<const i32x4*>(a.c.wp) + (size_t)group * NCH * NT * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) af[c][t] = wp[(c * NT + t) * 64];
+  }
+  const int cb = group * 16 * NT + g * 4 * NT;
+  f32x4 bias[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    bias[t] = cb + t * 4 < a.c.Cout ? *reinterpret_cast<const f32x4*>(a.c.bias + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  // couts this lane may store: Cout is a multiple of 4, whole tiles beyond Cout are skipped
+  int nt_valid = 0;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) nt_valid += cb + t * 4 < a.c.Cout ? 1 : 0;
+
+  const T* x = reinterpret_cast<const T*>(a.c.x);
+  T* y = reinterpret_cast<T*>(a.c.y);
+  const i32x4 zero = {0, 0, 0, 0};
+  bool k_ok[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) k_ok[c] = c * KC + g * KG < a.c.Cin;
+
+  auto load_tile = [&](int tile, i32x4 (&bf)[MT][NCH]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int p = (tile * MT + m) * 16 + j;
+      const bool ok = p < a.c.P;
+      const T* src = x + (size_t)(ok ? p : 0) * a.c.Cin + g * KG;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) bf[m][c] = (ok && k_ok[c]) ? *reinterpret_cast<const i32x4*>(src + c * KC) : zero;
+    }
+  };
+
+  i32x4 bcur[MT][NCH], bnext[MT][NCH];
+  int tile = stream;
+  if (tile < a.ntiles) load_tile(tile, bcur);
+  for (; tile < a.ntiles; tile += a.nstreams) {
+    const int nxt = tile + a.nstreams;
+    if (nxt < a.ntiles) load_tile(nxt, bnext);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mma16<T>(acc[m][t], af[c][t], bcur[m][c]);
+
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int p = (tile * MT + m) * 16 + j;
+      if (p < a.c.P) {
+        f32x4 v[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          v[t] = acc[m][t] + bias[t];
+          if (a.c.relu) {
+            v[t][0] = fmaxf(v[t][0], 0.f); v[t][1] = fmaxf(v[t][1], 0.f);
+            v[t][2] = fmaxf(v[t][2], 0.f); v[t][3] = fmaxf(v[t][3], 0.f);
+          }
+        }
+        T* dst = y + (size_t)p * a.c.y_cstride + a.c.y_coffset + cb;
+        if (nt_valid == NT) {
+          if constexpr (sizeof(T) == 2) {
+            StoreRow16<NT>::run(reinterpret_cast<f16*>(dst), v);
+          } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) store4<T>(dst + t * 4, v[t]);
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            if (t < nt_valid) store4<T>(dst + t * 4, v[t]);
+        }
+      }
+    }
+    if (nxt < a.ntiles) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) bcur[m][c] = bnext[m][c];
+    }
+  }
+}
+
+template <typename T, int NCH, int NT, int MT>
+static void launch_c1(C1Args& a, hipStream_t st) {
+  a.ntiles = (a.c.P + 16 * MT - 1) / (16 * MT);
+  // persistent: ~8 waves per SIMD-slot budget -> 256 CUs x 16 waves, split over the cout groups
+  int streams = (256 * 16) / a.c.ngroups;
+  if (streams < 1) streams = 1;
+  if (streams > a.ntiles) streams = a.ntiles;
+  a.nstreams = streams;
+  const int waves = streams * a.c.ngroups;
+  hipLaunchKernelGGL((conv1x1_stream<T, NCH, NT, MT>), dim3((waves + 3) / 4), dim3(256), 0, st, a);
+}
+
+template <typename T, int NCH, int NT>
+static void dispatch_c1_mt(C1Args& a, int mt, hipStream_t st) {
+  if (mt == 4) launch_c1<T, NCH, NT, 4>(a, st);
+  else launch_c1<T, NCH, NT, 2>(a, st);
+}
+
+template <typename T, int NCH>
+static bool dispatch_c1_nt(C1Args& a, int nt, int mt, hipStream_t st) {
+  switch (nt) {
+    case 1: dispatch_c1_mt<T, NCH, 1>(a, mt, st); return true;
+    case 2: dispatch_c1_mt<T, NCH, 2>(a, mt, st); return true;
+    case 3: dispatch_c1_mt<T, NCH, 3>(a, mt, st); return true;
+    case 4: dispatch_c1_mt<T, NCH, 4>(a, mt, st); return true;
+    case 5: dispatch_c1_mt<T, NCH, 5>(a, mt, st); return true;
+    case 6: dispatch_c1_mt<T, NCH, 6>(a, mt, st); return true;
+    default: return false;
+  }
+}
+
+template <typename T>
+static bool dispatch_c1(C1Args& a, int nch, int nt, int mt, hipStream_t st) {
+  switch (nch) {
+    case 1: return dispatch_c1_nt<T, 1>(a, nt, mt, st);
+    case 2: return dispatch_c1_nt<T, 2>(a, nt, mt, st);
+    case 3: return dispatch_c1_nt<T, 3>(a, nt, mt, st);
+    case 4: return dispatch_c1_nt<T, 4>(a, nt, mt, st);
+    default: return false;
+  }
+}
+
+// *handled = false: not eligible (the generic kernel runs instead).
+int conv1x1_stream_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (conv_algo() != 0) return SQDET_OK;
+  if (c.k != 1 || c.stride != 1 || g.gather) return SQDET_OK;
+  if (g.nchunk > 4 || g.nchunk * g.nt > 18) return SQDET_OK;   // weights must fit in registers
+  C1Args a;
+  a.c = c;
+  // register budget: accumulators MT*NT*4 + double-buffered B 2*MT*NCH*4 + A NCH*NT*4
+  int mt = 4;
+  if (4 * g.nt * 4 + 2 * 4 * g.nchunk * 4 + g.nchunk * g.nt * 4 > 200) mt = 2;
+  if (c.P < 16 * 4 * 1024) mt = 2;
+  const bool ok = dtype == SQDET_F16 ? dispatch_c1<f16>(a, g.nchunk, g.nt, mt, st)
+                                     : dispatch_c1<float>(a, g.nchunk, g.nt, mt, st);
+  if (!ok) return SQDET_OK;
+  SQDET_CHECK_HIP(hipGetLastError());
+  *handled = true;
+  return SQDET_OK;
+}
+
+}  // namespace sqdet

@@ -42,17 +42,28 @@ __device__ __forceinline__ void stage_tile(const TileArgs& a, unsigned char* lds
   const int row_bytes = a.pieces * 16;  // bytes per pixel in global memory
   const int ppc = nload * 4;            // pieces per pixel in this stage
   const int total = HP * ppc;
-  for (int idx = threadIdx.x; idx < total; idx += 256) {
-    const int P = idx / ppc;
-    const int q = idx - P * ppc;          // piece within the staged range
-    const int gq = c0 * 4 + q;            // piece within the pixel
-    const int r = P / (TCOLS + 2), cc = P - r * (TCOLS + 2);
-    const int iy = oy0 - 1 + r, ix = ox0 - 1 + cc;
-    i32x4 v = {0, 0, 0, 0};
-    if (gq < a.pieces && iy >= 0 && iy < a.c.H && ix >= 0 && ix < a.c.W)
-      v = *reinterpret_cast<const i32x4*>(x + (((size_t)n * a.c.H + iy) * a.c.W + ix) * row_bytes + gq * 16);
-    const int c = q >> 2, g = q & 3;
-    *reinterpret_cast<i32x4*>(lds + c * CHUNK_BYTES + P * 64 + ((g ^ ((P >> 1) & 3)) << 4)) = v;
+  // batches of 4 loads in flight per thread before the LDS stores (a load->store loop would pay the
+  // global latency once per iteration)
+  for (int base = threadIdx.x; base < total; base += 256 * 4) {
+    i32x4 v[4];
+    int off[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * 256;
+      const int P = idx / ppc;
+      const int q = idx - P * ppc;          // piece within the staged range
+      const int gq = c0 * 4 + q;            // piece within the pixel
+      const int r = P / (TCOLS + 2), cc = P - r * (TCOLS + 2);
+      const int iy = oy0 - 1 + r, ix = ox0 - 1 + cc;
+      v[u] = i32x4{0, 0, 0, 0};
+      if (idx < total && gq < a.pieces && iy >= 0 && iy < a.c.H && ix >= 0 && ix < a.c.W)
+        v[u] = *reinterpret_cast<const i32x4*>(x + (((size_t)n * a.c.H + iy) * a.c.W + ix) * row_bytes + gq * 16);
+      const int c = q >> 2, g = q & 3;
+      off[u] = idx < total ? c * CHUNK_BYTES + P * 64 + ((g ^ ((P >> 1) & 3)) << 4) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (off[u] >= 0) *reinterpret_cast<i32x4*>(lds + off[u]) = v[u];
   }
 }
 

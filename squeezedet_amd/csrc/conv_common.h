@@ -53,5 +53,6 @@ __device__ __forceinline__ void store4<float>(float* dst, const f32x4& v) {
 int conv_algo();
 
 int conv3x3_tile_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);
+int conv1x1_stream_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);
 
 }  // namespace sqdet

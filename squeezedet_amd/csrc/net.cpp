@@ -15,6 +15,9 @@ int conv2d_launch(const void* x, const void* w_packed, const float* bias, void* 
                   hipStream_t st);
 int maxpool_launch(const void* x, void* y, int n, int h, int w, int c, int k, int stride, int pad_mode, int dtype,
                    hipStream_t st);
+int stem_launch(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cout, int k,
+                int conv_pad, int pool_pad, int dtype, int y_cstride, int y_coffset, hipStream_t st, bool* handled);
+int conv_algo();
 }  // namespace sqdet
 
 using namespace sqdet;
@@ -22,7 +25,7 @@ using namespace sqdet;
 namespace {
 
 enum { BUF_INPUT = -1, BUF_PREDS = -2, BUF_A = 0, BUF_B = 1, BUF_S = 2 };
-enum { L_CONV = 0, L_POOL = 1 };
+enum { L_CONV = 0, L_POOL = 1, L_STEM = 2 };  // L_STEM: conv(k, s2, Cin 3)+relu+maxpool(3, s2) in one launch
 
 struct Param {
   std::string name;
@@ -40,6 +43,7 @@ struct Layer {
   int ho, wo;
   int y_cstride, y_coffset;
   int kparam, bparam;  // indices into params (conv)
+  int pool_pad_mode;   // L_STEM: padding of the fused pool
   double flops, bytes;
 };
 
@@ -175,7 +179,39 @@ int run_layer(sqdet_net* net, const Layer& L, const void* input, void* preds, hi
     return conv2d_launch(x, wp, b, y, net->batch, L.h, L.w, L.cin, L.cout, L.k, L.stride, L.pad_mode, L.relu,
                          net->dtype, L.y_cstride, L.y_coffset, st);
   }
+  if (L.type == L_STEM) {
+    const void* wp = net->param_mem + net->params[L.kparam].offset;
+    const float* b = reinterpret_cast<const float*>(net->param_mem + net->params[L.bparam].offset);
+    bool handled = false;
+    const int rc = stem_launch(x, wp, b, y, net->batch, L.h, L.w, L.cout, L.k, L.pad_mode, L.pool_pad_mode, net->dtype,
+                               L.y_cstride, L.y_coffset, st, &handled);
+    if (rc != SQDET_OK) return rc;
+    if (!handled) { set_error("net: fused stem no longer eligible (conv_algo changed after net_create?)"); return SQDET_ESTATE; }
+    return SQDET_OK;
+  }
   return maxpool_launch(x, y, net->batch, L.h, L.w, L.cin, L.k, L.stride, L.pad_mode, net->dtype, st);
+}
+
+// conv1 + pool1 -> one L_STEM launch when the fused kernel applies (decided at plan creation).
+void fuse_stem(sqdet_net* net, size_t esz) {
+  if (conv_algo() != 0 || net->layers.size() < 2) return;
+  Layer& c = net->layers[0];
+  const Layer& p = net->layers[1];
+  if (c.type != L_CONV || p.type != L_POOL || c.cin != 3 || c.stride != 2 || !c.relu) return;
+  if (!((c.k == 3 && c.cout == 64) || (c.k == 7 && c.cout == 96))) return;
+  if (p.k != 3 || p.stride != 2 || p.in_buf != c.out_buf) return;
+  Layer f = c;
+  f.type = L_STEM;
+  f.name = c.name + "+" + p.name;
+  f.out_buf = p.out_buf;
+  f.pool_pad_mode = p.pad_mode;
+  f.ho = p.ho; f.wo = p.wo;
+  f.y_cstride = c.cout; f.y_coffset = 0;
+  // algorithmic bytes: input + POOLED output + weights (the conv activations never reach HBM)
+  f.bytes = ((double)net->batch * c.h * c.w * 3 + (double)net->batch * p.ho * p.wo * c.cout +
+             (double)c.k * c.k * 3 * c.cout) * (double)esz + c.cout * 4.0;
+  net->layers.erase(net->layers.begin() + 1);
+  net->layers[0] = f;
 }
 
 }  // namespace
@@ -214,6 +250,7 @@ extern "C" int sqdet_net_create(sqdet_net_t** out, int arch, int dtype, int batc
   // dropout11 is the identity at inference (keep_prob = 1.0, nn_skeleton.py:78)
   b.conv_layer("conv12", nout, 3, 1, SQDET_PAD_SAME, 0, true);
   net->gh = b.h; net->gw = b.w; net->out_ch = nout;
+  fuse_stem(net, b.esz);
   size_t off = 0;
   for (int i = 0; i < 3; ++i) {
     net->buf_off[i] = off;

@@ -60,62 +60,98 @@ __global__ __launch_bounds__(256) void stem_conv_pool(StemArgs a) {
   const int iy0 = 2 * cy0 - a.ptc, ix0 = 2 * cx0 - a.plc;   // first input pixel staged
 
   // ---- 1. stage the input patch (zero outside the image: conv zero padding) ----
+  // Thread t owns element column t of every staged row (TC*3 <= 256 elements per row): one address
+  // increment and one wave-uniform row test per load, all TR loads in flight before the LDS stores.
   const T* x = reinterpret_cast<const T*>(a.x);
-  for (int idx = threadIdx.x; idx < TR * TC * 3; idx += 256) {
-    const int r = idx / (TC * 3);
-    const int rem = idx - r * (TC * 3);
-    const int c = rem / 3, ch = rem - c * 3;
-    const int iy = iy0 + r, ix = ix0 + c;
-    T v = (T)0;
-    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = x[(((size_t)n * a.H + iy) * a.W + ix) * 3 + ch];
-    lin[idx] = v;
+  {
+    const int t = threadIdx.x;
+    const int c = t / 3;
+    const int ix = ix0 + c;
+    const bool col_ok = t < TC * 3 && ix >= 0 && ix < a.W;
+    const T* src = x + (((size_t)n * a.H) * a.W + (col_ok ? ix : 0)) * 3 + (t - c * 3);
+    T stg[TR];
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+      const int iy = iy0 + r;
+      stg[r] = (col_ok && iy >= 0 && iy < a.H) ? src[(size_t)iy * a.W * 3] : (T)0;
+    }
+    if (t < TC * 3) {
+#pragma unroll
+      for (int r = 0; r < TR; ++r) lin[r * (TC * 3) + t] = stg[r];
+    }
   }
   __syncthreads();
 
   // ---- 2. conv on MFMA, 16 flattened conv pixels per block ----
-  const i32x4* wp = reinterpret_cast<const i32x4*>(a.wp) + lane;
   constexpr int NBLK = (SNPIX + 15) / 16;
+  constexpr int NCHK = (KS * KS * 3 + KC - 1) / KC;     // K-chunks of the im2col patch
+  constexpr bool PRE = NCHK * KG <= 16;                 // gather offsets precomputed per lane
   f32x4 bias[NT];
   const int cb = g * 4 * NT;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
     bias[t] = cb + t * 4 < a.Cout ? *reinterpret_cast<const f32x4*>(a.bias + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  // element offset (within the staged patch) of k-slot e of chunk c for this lane group; -1 = padding slot
+  auto slot_off = [&](int c, int e) -> int {
+    const int kq = c * KC + g * KG + e;
+    const int tap = kq / 3, ch = kq - tap * 3;
+    const int dy = tap / KS, dx = tap - dy * KS;
+    return kq < KS * KS * 3 ? (dy * TC + dx) * 3 + ch : -1;
+  };
+  int offs[PRE ? NCHK * KG : 1];
+  i32x4 afr[PRE ? NCHK * NT : 1];   // weights resident in registers when the patch is small (3x3)
+  if constexpr (PRE) {
+#pragma unroll
+    for (int c = 0; c < NCHK; ++c)
+#pragma unroll
+      for (int e = 0; e < KG; ++e) offs[c * KG + e] = slot_off(c, e);
+    const i32x4* wp0 = reinterpret_cast<const i32x4*>(a.wp) + lane;
+#pragma unroll
+    for (int i = 0; i < NCHK * NT; ++i) afr[i] = wp0[i * 64];
+  }
+  const i32x4* wp = reinterpret_cast<const i32x4*>(a.wp) + lane;
+  typedef T TV __attribute__((ext_vector_type(KG)));
 
   for (int blk = wave; blk < NBLK; blk += 4) {
     int q = blk * 16 + j;
     const bool inb = q < SNPIX;
     if (!inb) q = SNPIX - 1;
     const int cr = q / SNC, cc = q - cr * SNC;
-    const int base = (2 * cr * TC + 2 * cc) * 3;   // element offset of the patch origin in lin
+    const T* patch = lin + (2 * cr * TC + 2 * cc) * 3;   // patch origin in the staged input
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < a.nchunk; ++c) {
-      typedef T TV __attribute__((ext_vector_type(KG)));
+#pragma unroll
+    for (int c = 0; c < NCHK; ++c) {
       TV bv;
 #pragma unroll
       for (int e = 0; e < KG; ++e) {
-        const int kq = c * KC + g * KG + e;
-        const int tap = kq / 3, ch = kq - tap * 3;
-        const int dy = tap / KS, dx = tap - dy * KS;
-        bv[e] = kq < a.kdim ? lin[base + (dy * TC + dx) * 3 + ch] : (T)0;
+        const int o = PRE ? offs[PRE ? c * KG + e : 0] : slot_off(c, e);
+        bv[e] = o >= 0 ? patch[o] : (T)0;
       }
       const i32x4 bfrag = __builtin_bit_cast(i32x4, bv);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) mma16<T>(acc[t], wp[(c * NT + t) * 64], bfrag);
+      for (int t = 0; t < NT; ++t) {
+        const i32x4 af = PRE ? afr[PRE ? c * NT + t : 0] : wp[(c * NT + t) * 64];
+        mma16<T>(acc[t], af, bfrag);
+      }
     }
     // bias + ReLU; conv pixels outside the conv output are -inf for the pool
     const int cy = cy0 + cr, cx = cx0 + cc;
     const bool valid = cy >= 0 && cy < a.Hc && cx >= 0 && cx < a.Wc;
     if (inb) {
       T* dst = reinterpret_cast<T*>(lconv + q * CPIX) + cb;
+      if (valid) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        f32x4 v = acc[t] + bias[t];
+        for (int t = 0; t < NT; ++t) {
+          f32x4 v = acc[t] + bias[t];
+          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+          store4<T>(dst + t * 4, v);
+        }
+      } else {
         const float ninf = -__builtin_huge_valf();
-        v[0] = valid ? fmaxf(v[0], 0.f) : ninf; v[1] = valid ? fmaxf(v[1], 0.f) : ninf;
-        v[2] = valid ? fmaxf(v[2], 0.f) : ninf; v[3] = valid ? fmaxf(v[3], 0.f) : ninf;
-        store4<T>(dst + t * 4, v);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) store4<T>(dst + t * 4, f32x4{ninf, ninf, ninf, ninf});
       }
     }
   }
@@ -131,18 +167,13 @@ __global__ __launch_bounds__(256) void stem_conv_pool(StemArgs a) {
     const int pr = pp / SPW, pc = pp - pr * SPW;
     const int py = py0 + pr, px = px0 + pc;
     if (py >= a.Hp || px >= a.Wp) continue;
-    PV m;
+    const unsigned char* w0 = lconv + ((2 * pr) * SNC + 2 * pc) * CPIX + cg * 16;
+    PV m = *reinterpret_cast<const PV*>(w0);
 #pragma unroll
-    for (int e = 0; e < KG; ++e) m[e] = (T)(-__builtin_huge_valf());
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int q = (2 * pr + dy) * SNC + 2 * pc + dx;
-        const PV v = *reinterpret_cast<const PV*>(lconv + q * CPIX + cg * 16);
-#pragma unroll
-        for (int e = 0; e < KG; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
-      }
+    for (int t9 = 1; t9 < 9; ++t9) {
+      const PV v = *reinterpret_cast<const PV*>(w0 + ((t9 / 3) * SNC + (t9 % 3)) * CPIX);
+      m = __builtin_elementwise_max(m, v);
+    }
     *reinterpret_cast<PV*>(y + (((size_t)n * a.Hp + py) * a.Wp + px) * a.y_cstride + a.y_coffset + cg * KG) = m;
   }
 }

@@ -296,3 +296,33 @@ def test_cpu_tensors_are_rejected():
         ops.maxpool_nhwc(torch.zeros(1, 8, 8, 8), 3, 2, "SAME")
     with pytest.raises(SqdetError):
         ops.maxpool_nhwc(torch.zeros(1, 8, 8, 6, device=DEV), 3, 2, "SAME")  # channels not a multiple of 4
+
+
+STEM_CASES = [(2, 37, 53, 3, 64, "SAME", "SAME"), (1, 375, 1242, 3, 64, "SAME", "SAME"), (1, 384, 1248, 3, 64, "SAME", "SAME"),
+              (1, 64, 80, 3, 64, "SAME", "SAME"), (1, 75, 131, 7, 96, "VALID", "VALID"), (1, 375, 1242, 7, 96, "VALID", "VALID")]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("case", STEM_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_fused_stem_conv_pool_parity(case, dtype):
+    """conv1+pool1 in one launch (nets/squeezeDet.py:40-44, nets/squeezeDetPlus.py:40-44) against the
+    oracle's conv_layer -> pooling_layer, and BITWISE against the unfused HIP conv -> pool."""
+    ops = _ops()
+    N, H, W, k, cout, cpad, ppad = case
+    rs = np.random.RandomState(H * 7 + W)
+    x = torch.from_numpy(rs.uniform(-2, 2, (N, H, W, 3)).astype(np.float32))
+    w = torch.from_numpy((rs.randn(k, k, 3, cout) * (2.0 / (k * k * 3)) ** 0.5).astype(np.float32))
+    b = torch.from_numpy(rs.uniform(-0.5, 0.5, cout).astype(np.float32))
+    tdt = torch.float16 if dtype == "fp16" else torch.float32
+    if dtype == "fp16":
+        x, w = x.half().float(), w.half().float()
+    ref = O.pooling_layer(O.conv_layer(x, w, b, 2, cpad, True, storage=dtype), 3, 2, ppad).numpy()
+    packed = ops.pack_conv_weights(w.to(DEV), tdt)
+    xd, bd = x.to(DEV, tdt).contiguous(), b.to(DEV)
+    y = ops.stem_conv_pool(xd, packed, bd, cpad, ppad)
+    y2 = ops.maxpool_nhwc(ops.conv2d_nhwc(xd, packed, bd, 2, cpad, True), 3, 2, ppad)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == ref.shape
+    assert torch.equal(y, y2), "fused stem differs from conv -> pool"
+    tol = dict(rtol=1e-3, atol=1e-4) if dtype == "fp32" else dict(rtol=2 ** -9, atol=1e-3)
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref, **tol)
