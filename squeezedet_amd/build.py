@@ -26,6 +26,7 @@ SOURCES = [
     ("stem.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("pool.hip", []),
     ("postproc.hip", ["-ffp-contract=off"]),
+    ("filter_fast.hip", ["-ffp-contract=off"]),
     ("probe.hip", []),
     ("net.cpp", []),
 ]

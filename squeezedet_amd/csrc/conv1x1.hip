@@ -14,22 +14,6 @@
 
 namespace sqdet {
 
-template <typename T, int NT>
-__device__ __forceinline__ void store_row(T* dst, const f32x4 (&v)[NT]);
-
-template <int NT>
-struct StoreRow16 {
-  static __device__ __forceinline__ void run(f16* dst, const f32x4 (&v)[NT]) {
-#pragma unroll
-    for (int t = 0; t + 1 < NT; t += 2) {
-      f16x8 h = {(f16)v[t][0], (f16)v[t][1], (f16)v[t][2], (f16)v[t][3],
-                 (f16)v[t + 1][0], (f16)v[t + 1][1], (f16)v[t + 1][2], (f16)v[t + 1][3]};
-      *reinterpret_cast<f16x8*>(dst + t * 4) = h;
-    }
-    if (NT & 1) store4<f16>(dst + (NT - 1) * 4, v[NT - 1]);
-  }
-};
-
 struct C1Args {
   ConvArgs c;
   int ntiles;      // pixel tiles of MT*16
@@ -117,18 +101,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream(C1Args a) {
           }
         }
         T* dst = y + (size_t)p * a.c.y_cstride + a.c.y_coffset + cb;
-        if (nt_valid == NT) {
-          if constexpr (sizeof(T) == 2) {
-            StoreRow16<NT>::run(reinterpret_cast<f16*>(dst), v);
-          } else {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) store4<T>(dst + t * 4, v[t]);
-          }
-        } else {
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-            if (t < nt_valid) store4<T>(dst + t * 4, v[t]);
-        }
+        store_couts<T, NT>(dst, v, nt_valid);
       }
     }
     if (nxt < a.ntiles) {

@@ -9,10 +9,10 @@
 //     (16 consecutive pixels of one row, 16 B each) is bank-conflict free for any alignment of the
 //     first pixel (checked exhaustively against the ds_read_b128 lane-group model of
 //     MI355X_MICROARCH.md section LDS).  All 9 taps then read LDS: no re-read of the input through L1/L2.
-//   * Weights stay the MFMA A operand, read as 1-KiB fragments straight from global (L1/L2);
-//     every wave computes ALL 8 pixel blocks of the tile (MT = 8), so one A fragment feeds 8
-//     MFMAs (128 B of L1 traffic per MFMA) and one B fragment feeds NTW.
-//   * COUT-split mode (expand3x3): the 4 waves own different cout tiles (NTW = 1..3 tiles each).
+//   * Weights stay the MFMA A operand, read as 1-KiB fragments straight from global (L1/L2).
+//   * COUT-split mode (expand3x3): a wave owns MT tile rows x one whole packed cout group
+//     (NTW = 4..6 tiles -> 32..48 contiguous output bytes per lane); the 4 waves are laid out
+//     WR = 8/MT along the rows x WC = 4/WR along the cout groups.
 //   * SPLIT-K mode (ConvDet, Cin = 768, 72 couts = 5 tiles): every wave owns all 5 cout tiles
 //     and a quarter of K -- the input is staged in stages of 4 K-chunks, wave w taking chunk w --
 //     and the 4 partial accumulators are summed through LDS at the end.
@@ -67,10 +67,12 @@ __device__ __forceinline__ void stage_tile(const TileArgs& a, unsigned char* lds
   }
 }
 
-template <typename T, int NTW, bool SPLITK>
+template <typename T, int MT, int NTW, bool SPLITK>
 __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  constexpr int MT = TROWS;
+  constexpr int WR = TROWS / MT;   // waves along the tile rows
+  constexpr int WC = 4 / WR;       // waves along the cout groups
+  static_assert(SPLITK ? MT == TROWS : (WR * MT == TROWS && WR * WC == 4), "bad wave layout");
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -81,8 +83,9 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
   const int n = b / a.tiles_y;
   const int oy0 = ty * TROWS, ox0 = tx * TCOLS;
 
-  // which cout tiles this wave owns
-  const int tile0 = SPLITK ? 0 : (blockIdx.y * 4 + wave) * NTW;
+  // rows and cout tiles this wave owns
+  const int m0 = SPLITK ? 0 : (wave % WR) * MT;
+  const int tile0 = SPLITK ? 0 : (blockIdx.y * WC + wave / WR) * NTW;
   const bool active = tile0 < a.total_tiles;
   const int group = tile0 / a.nt_pack;
   const int n0 = tile0 - group * a.nt_pack;
@@ -107,50 +110,70 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
     // chunks this wave walks in this stage
     const int cl_begin = SPLITK ? wave : 0;
     const int cl_end = SPLITK ? (wave < nload ? wave + 1 : wave) : nload;
-    for (int cl = cl_begin; cl < cl_end; ++cl) {
-      const int c = c0 + cl;                         // global chunk index
+    // Flattened (chunk, tap) steps with the NEXT step's weight fragments prefetched from global
+    // while the current step's MFMAs run (register double buffer): the L1/L2 latency of the A
+    // operand is off the critical path.
+    const int nsteps = (cl_end - cl_begin) * 9;
+    auto wptr = [&](int s) {
+      const int cl = cl_begin + s / 9, t9 = s - (s / 9) * 9;
+      return wbase + (size_t)(t9 * a.nchunk + c0 + cl) * a.nt_pack * 64;
+    };
+    i32x4 af[NTW], afn[NTW];
+    if (nsteps > 0) {
+      const i32x4* wp = wptr(0);
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) af[t] = wp[t * 64];
+    }
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+      if (s + 1 < nsteps) {
+        const i32x4* wp = wptr(s + 1);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) afn[t] = wp[t * 64];
+      }
+      const int cl = cl_begin + s / 9, t9 = s - (s / 9) * 9;
+      const int dy = t9 / 3, dx = t9 - dy * 3;
       // (16-byte pieces beyond Cin were zero-filled by stage_tile, so every read is unconditional)
       const unsigned char* lchunk = lds + cl * CHUNK_BYTES;
-#pragma unroll 1
-      for (int t9 = 0; t9 < 9; ++t9) {
-        const int dy = t9 / 3, dx = t9 - dy * 3;
-        const int P0 = dy * (TCOLS + 2) + j + dx;    // halo pixel of output (row 0, col j) at this tap
-        const int h0 = P0 >> 1;
-        i32x4 bf[MT];
+      const int P0 = (dy + m0) * (TCOLS + 2) + j + dx;   // halo pixel of this wave's first row at this tap
+      const int h0 = P0 >> 1;
+      i32x4 bf[MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          // pixel P = P0 + 18*m ; (P>>1)&3 == (h0 + 9m)&3 == (h0 + m)&3
-          const int slot = g ^ ((h0 + m) & 3);
-          bf[m] = *reinterpret_cast<const i32x4*>(lchunk + (P0 + (TCOLS + 2) * m) * 64 + (slot << 4));
-        }
-        const i32x4* wp = wbase + (size_t)(t9 * a.nchunk + c) * a.nt_pack * 64;
-        i32x4 af[NTW];
+      for (int m = 0; m < MT; ++m) {
+        // pixel P = P0 + 18*m ; (P>>1)&3 == (h0 + 9m)&3 == (h0 + m)&3
+        const int slot = g ^ ((h0 + m) & 3);
+        bf[m] = *reinterpret_cast<const i32x4*>(lchunk + (P0 + (TCOLS + 2) * m) * 64 + (slot << 4));
+      }
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) af[t] = wp[t * 64];
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], af[t], bf[m]);
+      if (s + 1 < nsteps) {
 #pragma unroll
-          for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], af[t], bf[m]);
+        for (int t = 0; t < NTW; ++t) af[t] = afn[t];
       }
     }
   }
 
-  // epilogue: lane = pixel (row m, col j); couts group*16*NTp + g*4*NTp + (n0+t)*4 .. +4 : 4*NTW consecutive
+  // epilogue: lane = pixel (row m0+m, col j); couts group*16*NTp + g*4*NTp + (n0+t)*4 .. +4 : 4*NTW consecutive
   T* y = reinterpret_cast<T*>(a.c.y);
   const int ox = ox0 + j;
   const int cb = group * 16 * a.nt_pack + g * 4 * a.nt_pack + n0 * 4;
   f32x4 bias[NTW];
+  int nt_valid = 0;   // Cout is a multiple of 4: whole 4-cout pieces beyond Cout are skipped
 #pragma unroll
-  for (int t = 0; t < NTW; ++t)
-    bias[t] = cb + t * 4 < a.c.Cout ? *reinterpret_cast<const f32x4*>(a.c.bias + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NTW; ++t) {
+    const bool ok = cb + t * 4 < a.c.Cout;
+    bias[t] = ok ? *reinterpret_cast<const f32x4*>(a.c.bias + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    nt_valid += ok ? 1 : 0;
+  }
 
   if (SPLITK) {
     // Deterministic sum of the 4 K-partial accumulators through LDS: wave 0 writes, waves 1..3 add in
-    // turn ((w0+w1)+w2)+w3; the accumulators are only ever READ here (they stay in AGPRs).  Then all
-    // four waves share the epilogue, two tile rows each.
+    // turn ((w0+w1)+w2)+w3; the accumulators are only ever READ here.  Then all four waves share the
+    // epilogue, two tile rows each.
     float* red = reinterpret_cast<float*>(lds);
-    // Every wave passes exactly 5 barriers: `wu` before its turn, 5-wu after it.  (A loop over rounds
-    // with `if (wave == round)` lets LICM hoist all 160 accumulator copies out of the loop.)
+    // Every wave passes exactly 5 barriers: 1 + `wu` before its turn, 4-wu after it.
     const int wu = __builtin_amdgcn_readfirstlane(wave);
     __syncthreads();  // all waves are done reading the input tile (the buffer is reused)
     for (int r = 0; r < wu; ++r) __syncthreads();
@@ -177,16 +200,16 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
         const int oy = oy0 + m;
         if (oy >= a.c.H) break;
         T* dst = y + (((size_t)n * a.c.H + oy) * a.c.W + ox) * a.c.y_cstride + a.c.y_coffset + cb;
+        f32x4 v[NTW];
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
-          if (cb + t * 4 < a.c.Cout) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(red + ((m * NTW + t) * 64 + lane) * 4) + bias[t];
-            if (a.c.relu) {
-              v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-            }
-            store4<T>(dst + t * 4, v);
+          v[t] = *reinterpret_cast<const f32x4*>(red + ((m * NTW + t) * 64 + lane) * 4) + bias[t];
+          if (a.c.relu) {
+            v[t][0] = fmaxf(v[t][0], 0.f); v[t][1] = fmaxf(v[t][1], 0.f);
+            v[t][2] = fmaxf(v[t][2], 0.f); v[t][3] = fmaxf(v[t][3], 0.f);
           }
         }
+        store_couts<T, NTW>(dst, v, nt_valid);
       }
     }
     return;
@@ -196,42 +219,57 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
   if (ox < a.c.W) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const int oy = oy0 + m;
+      const int oy = oy0 + m0 + m;
       if (oy >= a.c.H) break;
       T* dst = y + (((size_t)n * a.c.H + oy) * a.c.W + ox) * a.c.y_cstride + a.c.y_coffset + cb;
+      f32x4 v[NTW];
 #pragma unroll
       for (int t = 0; t < NTW; ++t) {
-        if (cb + t * 4 < a.c.Cout) {
-          f32x4 v = acc[m][t] + bias[t];
-          if (a.c.relu) {
-            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-          }
-          store4<T>(dst + t * 4, v);
+        v[t] = acc[m][t] + bias[t];
+        if (a.c.relu) {
+          v[t][0] = fmaxf(v[t][0], 0.f); v[t][1] = fmaxf(v[t][1], 0.f);
+          v[t][2] = fmaxf(v[t][2], 0.f); v[t][3] = fmaxf(v[t][3], 0.f);
         }
       }
-      asm volatile("" ::: "memory");
+      store_couts<T, NTW>(dst, v, nt_valid);
     }
   }
 }
 
-template <typename T, int NTW, bool SPLITK>
+template <typename T, int MT, int NTW, bool SPLITK>
 static void launch_tile(const TileArgs& a, int grid_y, size_t lds, hipStream_t st) {
   const dim3 grid((unsigned)(a.c.N * a.tiles_x * a.tiles_y), (unsigned)grid_y);
-  hipLaunchKernelGGL((conv3x3_tile<T, NTW, SPLITK>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_tile<T, MT, NTW, SPLITK>), grid, dim3(256), lds, st, a);
+}
+
+template <typename T, int MT>
+static bool dispatch_ntw(const TileArgs& a, int ntw, int grid_y, size_t lds, hipStream_t st) {
+  switch (ntw) {
+    case 1: launch_tile<T, MT, 1, false>(a, grid_y, lds, st); return true;
+    case 2: launch_tile<T, MT, 2, false>(a, grid_y, lds, st); return true;
+    case 3: launch_tile<T, MT, 3, false>(a, grid_y, lds, st); return true;
+    case 4: launch_tile<T, MT, 4, false>(a, grid_y, lds, st); return true;
+    case 5: launch_tile<T, MT, 5, false>(a, grid_y, lds, st); return true;
+    case 6: launch_tile<T, MT, 6, false>(a, grid_y, lds, st); return true;
+    default: return false;
+  }
 }
 
 template <typename T>
-static bool dispatch_tile(const TileArgs& a, int ntw, bool splitk, int grid_y, size_t lds, hipStream_t st) {
+static bool dispatch_tile(const TileArgs& a, int mt, int ntw, bool splitk, int grid_y, size_t lds, hipStream_t st) {
   if (splitk) {
-    if (ntw == 5) { launch_tile<T, 5, true>(a, 1, lds, st); return true; }
+    if (ntw == 5) { launch_tile<T, 8, 5, true>(a, 1, lds, st); return true; }
     return false;
   }
-  switch (ntw) {
-    case 1: launch_tile<T, 1, false>(a, grid_y, lds, st); return true;
-    case 2: launch_tile<T, 2, false>(a, grid_y, lds, st); return true;
-    case 3: launch_tile<T, 3, false>(a, grid_y, lds, st); return true;
-    default: return false;
+  if (mt == 8) {  // one wave = all 8 tile rows x a slice of a group (4 waves along the cout tiles)
+    switch (ntw) {
+      case 1: launch_tile<T, 8, 1, false>(a, grid_y, lds, st); return true;
+      case 2: launch_tile<T, 8, 2, false>(a, grid_y, lds, st); return true;
+      case 3: launch_tile<T, 8, 3, false>(a, grid_y, lds, st); return true;
+      default: return false;
+    }
   }
+  return mt == 4 ? dispatch_ntw<T, 4>(a, ntw, grid_y, lds, st) : dispatch_ntw<T, 2>(a, ntw, grid_y, lds, st);
 }
 
 // Eligibility + configuration.  *handled = false means "use the generic kernels".
@@ -252,28 +290,39 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
   a.pieces = c.Cin * esz / 16;
   if ((long)c.N * a.tiles_x * a.tiles_y > 0x7fffffffL) return SQDET_OK;
 
-  int ntw = 0;
+  int ntw = g.nt, mt = 2;
   bool splitk = false;
   size_t lds = 0;
   int grid_y = 1;
   if (g.nt == 5 && g.ngroups == 1 && g.nchunk >= 8) {
     // ConvDet-like: few couts, deep K -> split K over the 4 waves, 4 chunks per stage
-    ntw = 5; splitk = true;
+    splitk = true;
+    mt = 8;
     lds = 4 * (size_t)CHUNK_BYTES;                         // 46080 B
     const size_t red = (size_t)TROWS * 5 * 64 * 16;        // 40960 B reduction buffer
     if (red > lds) lds = red;
   } else if (g.nchunk <= 5) {
-    if (g.nt == 4) ntw = g.ngroups == 1 ? 1 : 2;
-    else if (g.nt == 6) ntw = 3;
-    else if (g.nt == 2) ntw = 1;
-    else return SQDET_OK;
+    // a wave owns one whole packed group; 2 groups per workgroup (waves 2 rows x 2 groups) when
+    // there are several, else the 4 waves split the 8 tile rows
+    // Measured on MI355X (tools/kbench.py, batch 32): MFMA-bound deep-K layers (fire10/11: 96 -> 384)
+    // want MT = 8 (one A fragment from L1 feeds 8 MFMAs); the mid layers want whole-group waves.
     lds = (size_t)g.nchunk * CHUNK_BYTES;                  // <= 57600 B
-    grid_y = (a.total_tiles + 4 * ntw - 1) / (4 * ntw);
+    if (g.nt == 6 && g.ngroups >= 2 && g.nchunk >= 3) {
+      mt = 8; ntw = 3;
+      grid_y = (a.total_tiles + 11) / 12;
+    } else if (g.nt == 4 && g.ngroups == 1) {
+      mt = 8; ntw = 1;
+      grid_y = 1;
+    } else {
+      mt = g.ngroups >= 2 ? 4 : 2;
+      const int wc = mt == 4 ? 2 : 1;
+      grid_y = (g.ngroups + wc - 1) / wc;
+    }
   } else {
     return SQDET_OK;
   }
-  const bool ok = dtype == SQDET_F16 ? dispatch_tile<f16>(a, ntw, splitk, grid_y, lds, st)
-                                     : dispatch_tile<float>(a, ntw, splitk, grid_y, lds, st);
+  const bool ok = dtype == SQDET_F16 ? dispatch_tile<f16>(a, mt, ntw, splitk, grid_y, lds, st)
+                                     : dispatch_tile<float>(a, mt, ntw, splitk, grid_y, lds, st);
   if (!ok) return SQDET_OK;
   SQDET_CHECK_HIP(hipGetLastError());
   *handled = true;

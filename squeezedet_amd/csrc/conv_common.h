@@ -47,6 +47,30 @@ __device__ __forceinline__ void store4<float>(float* dst, const f32x4& v) {
   *reinterpret_cast<f32x4*>(dst) = v;
 }
 
+// Stores 4*NT consecutive output channels held by one lane (nt_valid < NT: only the first nt_valid
+// 4-channel pieces exist).  fp16 rows go out as 16-byte vectors when the pieces pair up.
+template <typename T, int NT>
+__device__ __forceinline__ void store_couts(T* dst, const f32x4 (&v)[NT], int nt_valid) {
+  if (nt_valid == NT) {
+    // 16-byte stores need a 16-byte aligned row segment: even NT (8*NT bytes per lane) and a row
+    // stride / channel offset that are multiples of 8 halves -- checked on the address itself.
+    if (sizeof(T) == 2 && (NT & 1) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+#pragma unroll
+      for (int t = 0; t + 1 < NT; t += 2) {
+        f16x8 h = {(f16)v[t][0], (f16)v[t][1], (f16)v[t][2], (f16)v[t][3],
+                   (f16)v[t + 1][0], (f16)v[t + 1][1], (f16)v[t + 1][2], (f16)v[t + 1][3]};
+        *reinterpret_cast<f16x8*>(dst + t * 4) = h;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) store4<T>(dst + t * 4, v[t]);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (t < nt_valid) store4<T>(dst + t * 4, v[t]);
+  }
+}
 
 // Which kernel family conv2d_launch may pick: 0 = auto (fast paths when eligible),
 // 1 = generic only (conv_direct / conv_gather).  Set from SQDET_CONV_ALGO=generic (tests, A/B).

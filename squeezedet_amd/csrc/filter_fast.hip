@@ -1,0 +1,220 @@
+// filter_prediction, top-N branch (TOP_N_DETECTION <= 64 < A), fast path: one 1024-thread
+// workgroup per image.  Replaces ModelSkeleton.filter_prediction (reference
+// src/nn_skeleton.py:696-734) + util.nms / util.batch_iou (src/utils/util.py:32-76); results are
+// identical to the generic kernel in postproc.hip (same total order, same float32 IoU, same
+// float64 threshold compare) -- only the selection algorithm differs:
+//
+//   1. every thread keeps its <= 20 anchors' 32-bit order-preserving prob keys in registers and
+//      publishes its maximum;
+//   2. L = the TOP_N-th largest of the 1024 thread maxima, found by an all-pairs rank in LDS.
+//      At least TOP_N anchors have key >= L, so every top-N anchor has key >= L;
+//   3. the anchors with key >= L (typically ~TOP_N..4*TOP_N of 16848) are compacted into LDS as
+//      64-bit composite keys (prob key << 32 | anchor: all distinct);
+//   4. all-pairs rank among the candidates: rank r < TOP_N <=> selected, and r IS the position in
+//      the descending order -> no sort pass, no histogram atomics;
+//   5. wave 0 runs the non-greedy NMS on the <= 64 ranked boxes and emits them ordered by class,
+//      then descending prob.
+// If more than FCAP anchors tie at >= L (e.g. a constant score map) the call falls back to the
+// generic radix-select kernel for that launch (decided on the device, uniformly per image).
+#include "postproc.h"
+
+namespace sqdet {
+
+constexpr int FT = 1024;     // threads
+constexpr int FMAXE = 20;    // anchors per thread held in registers (A <= 20480)
+constexpr int FCAP = 2048;   // candidate capacity
+constexpr int FG = FT / 8;   // groups of 8 threads whose maxima bound the threshold (>= 64 needed)
+
+struct FastLds {
+  unsigned int wmax[FT];
+  unsigned long long cand[FCAP];
+  unsigned long long sel[64];
+  f32x4 box[64];
+  int cls[64];
+  int keep[64];
+  unsigned int L;
+  int count;
+  int fallback;
+};
+
+// Exact radix select of the top_n-th largest composite key over ALL anchors (the generic
+// algorithm, used only when the candidate list overflows).  Returns the key; all threads get it.
+__device__ unsigned long long slow_select(const float* probs, int A, int top_n, int* hist, int* scan, int* misc) {
+  const int tid = threadIdx.x;
+  unsigned long long prefix = 0;
+  int remaining = top_n;
+  for (int byte = 7; byte >= 0; --byte) {
+    if (byte < 4 && ((unsigned int)(A - 1) >> (8 * byte)) == 0) continue;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const int hs = 8 * (byte + 1);
+    for (int i = tid; i < A; i += FT) {
+      const unsigned long long key = make_key(probs[i], i);
+      const bool match = byte == 7 || (key >> hs) == (prefix >> hs);
+      if (match) atomicAdd(&hist[(int)((key >> (8 * byte)) & 255)], 1);
+    }
+    __syncthreads();
+    if (tid < 256) scan[tid] = hist[tid];
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      int v = 0;
+      if (tid < 256) v = tid + off < 256 ? scan[tid + off] : 0;
+      __syncthreads();
+      if (tid < 256) scan[tid] += v;
+      __syncthreads();
+    }
+    if (tid < 256) {
+      const int mine = scan[tid];
+      const int above = tid == 255 ? 0 : scan[tid + 1];
+      if (mine >= remaining && above < remaining) { misc[0] = tid; misc[1] = above; }
+    }
+    __syncthreads();
+    prefix |= (unsigned long long)misc[0] << (8 * byte);
+    remaining -= misc[1];
+    __syncthreads();
+  }
+  return prefix;
+}
+
+__global__ __launch_bounds__(FT) void filter_topn_fast(FilterArgs a) {
+  __shared__ FastLds s;
+  const int img = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float* probs = a.probs + (size_t)img * a.A;
+  const float* boxes = a.boxes + (size_t)img * a.A * 4;
+  const int64_t* cls = a.cls + (size_t)img * a.A;
+  float* ob = a.out_boxes + (size_t)img * a.max_out * 4;
+  float* op = a.out_probs + (size_t)img * a.max_out;
+  int32_t* oc = a.out_cls + (size_t)img * a.max_out;
+  int32_t* oi = a.out_index + (size_t)img * a.max_out;
+  const int M = a.top_n;  // 1 <= M <= 64, M < A
+
+  // ---- 1. keys in registers + per-thread maximum.  Slots beyond A hold key 0 and are never
+  //         selected (every selection below also tests the index).
+  unsigned int key[FMAXE];
+  unsigned int mx = 0;
+#pragma unroll
+  for (int e = 0; e < FMAXE; ++e) {
+    const int i = tid + e * FT;
+    key[e] = i < a.A ? order_key32(probs[i]) : 0u;
+    mx = key[e] > mx ? key[e] : mx;
+  }
+  // maximum of every group of 8 consecutive threads (128 disjoint groups of <= 160 anchors)
+  unsigned int gmx = mx;
+  {
+    unsigned int o = __shfl_xor(gmx, 1); gmx = o > gmx ? o : gmx;
+    o = __shfl_xor(gmx, 2); gmx = o > gmx ? o : gmx;
+    o = __shfl_xor(gmx, 4); gmx = o > gmx ? o : gmx;
+  }
+  if ((tid & 7) == 0) s.wmax[tid >> 3] = gmx;
+  if (tid == 0) { s.count = 0; s.fallback = 0; }
+  __syncthreads();
+
+  // ---- 2. L = M-th largest of the 128 group maxima (all-pairs rank; ties broken by group id).
+  //         Each group maximum is a distinct anchor, so >= M anchors have key >= L.
+  if (tid < FG) {
+    const unsigned int mine = s.wmax[tid];
+    int rank = 0;
+    for (int t = 0; t < FG; ++t) {
+      const unsigned int o = s.wmax[t];
+      rank += (o > mine || (o == mine && t < tid)) ? 1 : 0;
+    }
+    if (rank == M - 1) s.L = mine;
+  }
+  __syncthreads();
+  const unsigned int L = s.L;
+
+  // ---- 3. compaction of the candidates (key >= L) ----
+#pragma unroll
+  for (int e = 0; e < FMAXE; ++e) {
+    const int i = tid + e * FT;
+    if (i < a.A && key[e] >= L) {
+      const int slot = atomicAdd(&s.count, 1);
+      if (slot < FCAP) s.cand[slot] = ((unsigned long long)key[e] << 32) | (unsigned int)i;
+    }
+  }
+  __syncthreads();
+  int C = s.count;
+  if (C > FCAP) {
+    // too many ties at the boundary: exact radix select over all anchors, then re-compact
+    __shared__ int hist[256], scan[256], misc[4];
+    const unsigned long long T = slow_select(probs, a.A, M, hist, scan, misc);
+    if (tid == 0) s.count = 0;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < FMAXE; ++e) {
+      const int i = tid + e * FT;
+      const unsigned long long k64 = ((unsigned long long)key[e] << 32) | (unsigned int)i;
+      if (i < a.A && k64 >= T) {
+        const int slot = atomicAdd(&s.count, 1);
+        if (slot < FCAP) s.cand[slot] = k64;
+      }
+    }
+    __syncthreads();
+    C = s.count;  // == M
+  }
+
+  // ---- 4. all-pairs rank among the candidates: rank < M <=> in the top-N, rank = position ----
+  for (int q = tid; q < C; q += FT) {
+    const unsigned long long mine = s.cand[q];
+    int rank = 0;
+    for (int t = 0; t < C; ++t) rank += s.cand[t] > mine ? 1 : 0;
+    if (rank < M) s.sel[rank] = mine;
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+
+  // ---- 5. wave 0: NMS + ordered output ----
+  const int r = tid;
+  int idx = 0, c = -1;
+  f32x4 bj = {0.f, 0.f, 0.f, 0.f};
+  if (r < M) {
+    idx = (int)(s.sel[r] & 0xffffffffull);
+    bj = *reinterpret_cast<const f32x4*>(boxes + (size_t)idx * 4);
+    c = (int)cls[idx];
+    s.box[r] = bj;
+    s.cls[r] = c;
+  }
+  __syncthreads();  // only wave 0 is left (terminated waves do not take part in the barrier)
+  // the reference's non-greedy NMS (utils/util.py:56-76): r is dropped iff ANY higher-ranked
+  // same-class box has IoU > threshold (compared in float64, as under the reference's NumPy 1.12)
+  bool keep = r < M && c >= 0 && c < a.C;
+  for (int i = 0; i < r && keep; ++i) {
+    if (s.cls[i] != c) continue;
+    const float ov = iou_center(bj, s.box[i]);
+    if ((double)ov > a.nms_thresh) keep = false;
+  }
+  s.keep[r] = keep ? 1 : 0;
+  __syncthreads();
+  // output position: kept entries ordered by class, then rank (nn_skeleton.py:726-733)
+  int pos = 0, kept = 0;
+  for (int i = 0; i < M; ++i) {
+    const int ki = s.keep[i];
+    kept += ki;
+    if (ki && (s.cls[i] < c || (s.cls[i] == c && i < r))) ++pos;
+  }
+  if (keep) {
+    *reinterpret_cast<f32x4*>(ob + (size_t)pos * 4) = bj;
+    op[pos] = probs[idx];
+    oc[pos] = c;
+    oi[pos] = idx;
+  }
+  for (int o = kept + r; o < a.max_out; o += 64) {
+    *reinterpret_cast<f32x4*>(ob + (size_t)o * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    op[o] = 0.f;
+    oc[o] = -1;
+    oi[o] = -1;
+  }
+  if (r == 0) a.out_count[img] = kept;
+}
+
+int filter_topn_fast_launch(const FilterArgs& a, int n, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (!a.use_topn || a.top_n > 64 || a.A > FT * FMAXE) return SQDET_OK;
+  hipLaunchKernelGGL(filter_topn_fast, dim3(n), dim3(FT), 0, st, a);
+  SQDET_CHECK_HIP(hipGetLastError());
+  *handled = true;
+  return SQDET_OK;
+}
+
+}  // namespace sqdet

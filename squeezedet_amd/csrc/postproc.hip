@@ -9,7 +9,7 @@
 // This translation unit is compiled with -ffp-contract=off: the reference evaluates every
 // decode / IoU expression as separate rounded float32 operations (TF-CPU / NumPy), so no
 // mul+add may be fused here or clipped boxes and NMS decisions stop being bit-exact.
-#include "common.h"
+#include "postproc.h"
 
 namespace sqdet {
 
@@ -79,16 +79,6 @@ __global__ __launch_bounds__(256) void interpret_kernel(const T* __restrict__ pr
 }
 
 // ------------------------------------------------------------------ filter_prediction
-// Order-preserving map float -> uint32 (larger float <=> larger uint), then a 64-bit
-// composite key (key32 << 32 | anchor index): all keys are distinct, and a DESCENDING sort of
-// them is "descending prob, ties -> higher anchor index first" (the tie rule this repo
-// defines; the reference's unstable argsort leaves ties unspecified -- SURVEY.md 9.4).
-__device__ __forceinline__ unsigned long long make_key(float p, int idx) {
-  unsigned int b = __float_as_uint(p);
-  b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-  return ((unsigned long long)b << 32) | (unsigned int)idx;
-}
-
 // In-LDS bitonic sort of n (power of two) 64-bit keys by 256 threads.
 template <bool DESC>
 __device__ void bitonic_sort(unsigned long long* keys, int n) {
@@ -105,21 +95,6 @@ __device__ void bitonic_sort(unsigned long long* keys, int n) {
     }
   }
 }
-
-struct FilterArgs {
-  const float* boxes;
-  const float* probs;
-  const int64_t* cls;
-  float* out_boxes;
-  float* out_probs;
-  int32_t* out_cls;
-  int32_t* out_index;
-  int32_t* out_count;
-  int A, C, top_n, max_out, cap;  // cap: power-of-two LDS capacity (>= candidates)
-  int use_topn;
-  double nms_thresh;
-  float prob_thresh;
-};
 
 // One 256-thread workgroup per image.
 // LDS: keys[cap] u64 | boxes[cap] f32x4 | clsv[cap] i32 | keep[cap] i32 | hist[256] | scan[256] | misc[8]
@@ -229,14 +204,7 @@ __global__ __launch_bounds__(256) void filter_kernel(FilterArgs a) {
     for (int i = 0; i < r && keep; ++i) {
       if (scls[i] != cj) continue;
       const f32x4 bi = sbox[i];
-      // utils/util.py:32-54 batch_iou(boxes=lower-ranked j, box=higher-ranked i), float32 op for op
-      const float lr = fmaxf(fminf(bj[0] + 0.5f * bj[2], bi[0] + 0.5f * bi[2]) -
-                             fmaxf(bj[0] - 0.5f * bj[2], bi[0] - 0.5f * bi[2]), 0.0f);
-      const float tb = fmaxf(fminf(bj[1] + 0.5f * bj[3], bi[1] + 0.5f * bi[3]) -
-                             fmaxf(bj[1] - 0.5f * bj[3], bi[1] - 0.5f * bi[3]), 0.0f);
-      const float inter = lr * tb;
-      const float uni = bj[2] * bj[3] + bi[2] * bi[3] - inter;
-      const float ov = inter / uni;
+      const float ov = iou_center(bj, bi);
       if ((double)ov > a.nms_thresh) keep = false;
     }
     skeep[r] = keep ? 1 : 0;
@@ -335,6 +303,9 @@ extern "C" int sqdet_filter_prediction(const float* boxes, const float* probs, c
   while (cap < need) cap <<= 1;
   SQDET_UNSUPPORTED(cap > 1024, "filter_prediction: more than 1024 NMS candidates per image (%d) not supported", need);
   a.cap = cap;
+  bool handled = false;
+  const int rc = filter_topn_fast_launch(a, n, as_stream(stream), &handled);
+  if (rc != SQDET_OK || handled) return rc;
   const size_t lds = (size_t)cap * 32 + 4096 + (size_t)cap * 8;
   hipLaunchKernelGGL(filter_kernel, dim3(n), dim3(256), lds, as_stream(stream), a);
   SQDET_CHECK_HIP(hipGetLastError());

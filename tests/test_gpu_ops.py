@@ -74,6 +74,13 @@ CONV_CASES = [
     ("e3_multitile_96_384", 1, 17, 30, 96, 384, 3, 1, "SAME", True),
     ("convdet_full_24x78", 1, 24, 78, 768, 72, 3, 1, "SAME", False),
     ("plus_convdet_22x76", 1, 22, 76, 512, 72, 3, 1, "SAME", False),
+    # odd tile counts per group (8-byte-aligned rows only) and shallow-K 72-cout 3x3
+    ("c1_k64_n48", 1, 12, 20, 64, 48, 1, 1, "SAME", True),
+    ("c1_k32_n80", 2, 9, 21, 32, 80, 1, 1, "SAME", False),
+    ("c1_k128_n32", 1, 33, 45, 128, 32, 1, 1, "SAME", True),
+    ("e3_cin32_cout72", 1, 11, 19, 32, 72, 3, 1, "SAME", True),
+    ("e3_cin16_cout32", 1, 10, 33, 16, 32, 3, 1, "SAME", True),
+    ("e3_cin64_cout48", 1, 9, 17, 64, 48, 3, 1, "SAME", True),
 ]
 
 
@@ -263,6 +270,29 @@ def test_filter_prediction_tie_rule_and_small_inputs():
         ob, op, oc, oi, n = _gpu_filter(boxes[:A], probs[:A], cls[:A], mc, max_out=64)
         fb, fp, fc, fi = O.filter_prediction(mc, boxes[:A], probs[:A], cls[:A], return_index=True)
         np.testing.assert_array_equal(oi, np.array(fi, np.int32))
+
+
+@pytest.mark.parametrize("kind", ["constant", "two_levels", "few_distinct"])
+def test_filter_prediction_massive_ties_full_size(kind):
+    """Score maps with thousands of equal values (a saturated or constant head): the fast top-N
+    kernel's candidate list overflows and it must fall back to the exact radix select; the result
+    still follows the repo's total order (descending prob, ties -> higher anchor index first)."""
+    mc = O.kitti_squeezeDet_config()
+    rs = np.random.RandomState(31)
+    A = 16848
+    boxes = np.stack([rs.uniform(0, 1247, A), rs.uniform(0, 383, A), rs.uniform(1, 60, A), rs.uniform(1, 60, A)], 1).astype(np.float32)
+    if kind == "constant":
+        probs = np.full(A, 0.5, np.float32)
+    elif kind == "two_levels":
+        probs = np.where(rs.uniform(0, 1, A) < 0.002, 0.9, 0.25).astype(np.float32)   # ~34 high, the rest tied
+    else:
+        probs = rs.choice(np.array([0.1, 0.2, 0.7], np.float32), A)
+    cls = rs.randint(0, 3, A).astype(np.int64)
+    ob, op, oc, oi, n = _gpu_filter(boxes, probs, cls, mc)
+    fb, fp, fc, fi = O.filter_prediction(mc, boxes, probs, cls, return_index=True)
+    np.testing.assert_array_equal(oi, np.array(fi, np.int32))
+    np.testing.assert_array_equal(op, np.array(fp, np.float32))
+    np.testing.assert_array_equal(oc, np.array(fc, np.int32))
 
 
 def test_filter_prediction_threshold_overflow_reports_count():
