@@ -42,7 +42,9 @@ enum { SQDET_ARCH_SQUEEZEDET = 0, SQDET_ARCH_SQUEEZEDET_PLUS = 1 };
 const char* sqdet_version(void);
 const char* sqdet_last_error(void);
 /* Tuning knobs (process-wide).  "conv_algo": 0 = auto (specialised kernels when eligible,
- * default), 1 = generic implicit-GEMM kernels only (also env SQDET_CONV_ALGO=generic). */
+ * default), 1 = generic implicit-GEMM kernels only (also env SQDET_CONV_ALGO=generic).
+ * "fire_overlap": 1 (default 0: measured slower on MI355X) = sqdet_net_forward runs expand1x1 on an internal side stream
+ * concurrently with expand3x3 (they read the same squeeze tensor and write disjoint channels). */
 int sqdet_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------ conv --

@@ -18,6 +18,7 @@ int maxpool_launch(const void* x, void* y, int n, int h, int w, int c, int k, in
 int stem_launch(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cout, int k,
                 int conv_pad, int pool_pad, int dtype, int y_cstride, int y_coffset, hipStream_t st, bool* handled);
 int conv_algo();
+int fire_overlap();
 }  // namespace sqdet
 
 using namespace sqdet;
@@ -67,6 +68,10 @@ struct sqdet_net {
   int probe_layer = -1;
   int probe_count = 0;
   std::vector<hipEvent_t> probe_events;  // 2 per record
+  // expand1x1 || expand3x3 overlap: the two expand convs of a fire module read the same squeeze
+  // tensor and write disjoint channel ranges, so expand1x1 runs on a side stream
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> fork_events, join_events;
 };
 
 namespace {
@@ -265,6 +270,9 @@ extern "C" void sqdet_net_destroy(sqdet_net_t* net) {
   if (!net) return;
   for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
   for (hipEvent_t e : net->probe_events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : net->fork_events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : net->join_events) (void)hipEventDestroy(e);
+  if (net->side) (void)hipStreamDestroy(net->side);
   delete net;
 }
 
@@ -324,14 +332,44 @@ extern "C" int sqdet_net_forward(sqdet_net_t* net, const void* image_input, void
   if (!net->param_mem || !net->workspace) { set_error("net_forward: call sqdet_net_bind first"); return SQDET_ESTATE; }
   hipStream_t st = as_stream(stream);
   const int nl = (int)net->layers.size();
+  const bool overlap = fire_overlap() != 0;
+  if (overlap && !net->side) SQDET_CHECK_HIP(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking));
+  size_t fires = 0;
   for (int i = 0; i < nl; ++i) {
+    const Layer& L = net->layers[i];
+    // expand1x1 (layer i) and expand3x3 (layer i+1) of one fire module: same input buffer, same
+    // output buffer, disjoint channel ranges -> i runs on the side stream while i+1 runs on `st`
+    const bool pair = overlap && i + 1 < nl && L.type == L_CONV && net->layers[i + 1].type == L_CONV &&
+                      L.in_buf == BUF_S && net->layers[i + 1].in_buf == BUF_S && L.out_buf == net->layers[i + 1].out_buf &&
+                      L.y_coffset + L.cout <= net->layers[i + 1].y_coffset;
+    hipStream_t ls = st;
+    if (pair) {
+      if (fires >= net->fork_events.size()) {
+        hipEvent_t e1, e2;
+        SQDET_CHECK_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        SQDET_CHECK_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+        net->fork_events.push_back(e1);
+        net->join_events.push_back(e2);
+      }
+      SQDET_CHECK_HIP(hipEventRecord(net->fork_events[fires], st));
+      SQDET_CHECK_HIP(hipStreamWaitEvent(net->side, net->fork_events[fires], 0));
+      ls = net->side;
+    }
     const bool probe = i == net->probe_layer && 2 * (net->probe_count + 1) <= (int)net->probe_events.size();
-    if (probe) SQDET_CHECK_HIP(hipEventRecord(net->probe_events[2 * net->probe_count], st));
-    const int rc = run_layer(net, net->layers[i], image_input, preds, st);
+    if (probe) SQDET_CHECK_HIP(hipEventRecord(net->probe_events[2 * net->probe_count], ls));
+    const int rc = run_layer(net, L, image_input, preds, ls);
     if (rc != SQDET_OK) return rc;
     if (probe) {
-      SQDET_CHECK_HIP(hipEventRecord(net->probe_events[2 * net->probe_count + 1], st));
+      SQDET_CHECK_HIP(hipEventRecord(net->probe_events[2 * net->probe_count + 1], ls));
       ++net->probe_count;
+    }
+    if (pair) {
+      SQDET_CHECK_HIP(hipEventRecord(net->join_events[fires], net->side));
+      const int rc2 = run_layer(net, net->layers[i + 1], image_input, preds, st);
+      if (rc2 != SQDET_OK) return rc2;
+      SQDET_CHECK_HIP(hipStreamWaitEvent(st, net->join_events[fires], 0));
+      ++fires;
+      ++i;
     }
   }
   return SQDET_OK;
