@@ -293,6 +293,12 @@ void set_conv_algo(int v) { g_conv_algo = v; }
 static int g_fire_overlap = 0;  // measured on MI355X: the cross-stream fork/join costs more than the overlap wins (24.9k vs 26.3k img/s)
 int fire_overlap() { return g_fire_overlap; }
 
+// Experiment knobs (0 = built-in heuristic): see tune() call sites.
+static const char* const kTuneNames[] = {"c1_waves", "c1_mt", "c1_min_tiles", "fire_fuse"};
+constexpr int kNumTune = 4;
+static int g_tune[kNumTune] = {0, 0, 0, 0};
+int tune(int which) { return g_tune[which]; }
+
 }  // namespace sqdet
 
 using namespace sqdet;
@@ -307,6 +313,12 @@ extern "C" int sqdet_set_option(const char* name, int value) {
   if (!strcmp(name, "fire_overlap")) {
     g_fire_overlap = value ? 1 : 0;
     return SQDET_OK;
+  }
+  for (int i = 0; i < kNumTune; ++i) {
+    if (!strcmp(name, kTuneNames[i])) {
+      g_tune[i] = value;
+      return SQDET_OK;
+    }
   }
   set_error("set_option: unknown option '%s'", name);
   return SQDET_EINVAL;

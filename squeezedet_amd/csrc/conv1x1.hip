@@ -117,9 +117,14 @@ template <typename T, int NCH, int NT, int MT>
 static void launch_c1(C1Args& a, hipStream_t st) {
   a.ntiles = (a.c.P + 16 * MT - 1) / (16 * MT);
   // persistent: ~8 waves per SIMD-slot budget -> 256 CUs x 16 waves, split over the cout groups
-  int streams = (256 * 16) / a.c.ngroups;
+  const int budget = tune(TUNE_C1_WAVES) > 0 ? tune(TUNE_C1_WAVES) : 256 * 16;
+  int streams = budget / a.c.ngroups;
   if (streams < 1) streams = 1;
+  // a wave re-loads its weight fragments once: give it at least `min_tiles` pixel tiles to amortise them
+  const int min_tiles = tune(TUNE_C1_MIN_TILES) > 0 ? tune(TUNE_C1_MIN_TILES) : 1;
+  if (streams * min_tiles > a.ntiles) streams = (a.ntiles + min_tiles - 1) / min_tiles;
   if (streams > a.ntiles) streams = a.ntiles;
+  if (streams < 1) streams = 1;
   a.nstreams = streams;
   const int waves = streams * a.c.ngroups;
   hipLaunchKernelGGL((conv1x1_stream<T, NCH, NT, MT>), dim3((waves + 3) / 4), dim3(256), 0, st, a);
@@ -167,6 +172,7 @@ int conv1x1_stream_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipSt
   int mt = 4;
   if (4 * g.nt * 4 + 2 * 4 * g.nchunk * 4 + g.nchunk * g.nt * 4 > 200) mt = 2;
   if (c.P < 16 * 4 * 1024) mt = 2;
+  if (tune(TUNE_C1_MT) == 2 || tune(TUNE_C1_MT) == 4) mt = tune(TUNE_C1_MT);
   const bool ok = dtype == SQDET_F16 ? dispatch_c1<f16>(a, g.nchunk, g.nt, mt, st)
                                      : dispatch_c1<float>(a, g.nchunk, g.nt, mt, st);
   if (!ok) return SQDET_OK;

@@ -75,6 +75,9 @@ __device__ __forceinline__ void store_couts(T* dst, const f32x4 (&v)[NT], int nt
 // Which kernel family conv2d_launch may pick: 0 = auto (fast paths when eligible),
 // 1 = generic only (conv_direct / conv_gather).  Set from SQDET_CONV_ALGO=generic (tests, A/B).
 int conv_algo();
+// experiment knobs set through sqdet_set_option (0 = built-in heuristic)
+enum { TUNE_C1_WAVES = 0, TUNE_C1_MT = 1, TUNE_C1_MIN_TILES = 2, TUNE_FIRE_FUSE = 3 };  // fire_fuse: 0 heuristic, 1 always, 2 never
+int tune(int which);
 
 int conv3x3_tile_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);
 int conv1x1_stream_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);

@@ -1,0 +1,289 @@
+// Fused fire module for gfx950: squeeze1x1 -> (expand1x1 || expand3x3) -> concat in ONE launch
+// (reference src/nets/squeezeDet.py:81-106).  The squeeze tensor never touches HBM: HBM traffic is
+// the fire input + the concat output + the three weight sets (SURVEY.md 8d "fused fire kernel").
+//
+// One 256-thread workgroup owns an 8 x 16 tile of output pixels of one image.
+//   Phase A (squeeze): the 10 x 18 halo of squeeze outputs the 3x3 expand needs is computed on
+//     MFMA straight from the NHWC input (B fragments are 16-byte global loads, weights the A
+//     operand; K-loop register double-buffered), bias + ReLU, rounded to the storage type and
+//     written to LDS in the bank-conflict-free [K-chunk][pixel][4 x 16 B, slot g ^ ((pixel>>1)&3)]
+//     layout of conv3x3.hip.  Halo pixels outside the image are ZERO (the expand convs' SAME
+//     padding pads the squeeze tensor, not the input).  The halo recompute costs 180/128 of the
+//     squeeze FLOPs -- the squeeze is 15-20 % of a module.
+//   Phase B (expand): each wave computes all 8 tile rows x NTW cout tiles per work item, items
+//     alternate over the expand3x3 tiles (9 taps) and the expand1x1 tiles (centre tap), weights
+//     prefetched one step ahead; results go to their channel range of the concat tensor.
+// Numerics are identical to the unfused kernels (same chunk order, same MFMA, same roundings).
+#include "conv_common.h"
+
+namespace sqdet {
+
+constexpr int FROWS = 8, FCOLS = 16;
+constexpr int FHP = (FROWS + 2) * (FCOLS + 2);   // 180 halo pixels
+constexpr int FCHUNK = FHP * 64;                 // bytes per 64-byte K-chunk of the squeeze tile
+constexpr int FBLK = (FHP + 15) / 16;            // 12 pixel blocks in phase A (3 per wave)
+
+struct FireArgs {
+  const void* x;
+  void* y;
+  const void *ws, *w1, *w3;
+  const float *bs, *b1, *b3;
+  int N, H, W, Cin, S, E1, E3;
+  int tiles_x, tiles_y;
+  int nch_x;       // 64-byte chunks of the input channels
+  int x_pieces;    // Cin*sizeof(T)/16
+  int nch_s;       // 64-byte chunks of the squeeze channels
+  int e_nt;        // tiles per packed group of the expand convs (same for both)
+  int e1_tiles, e3_tiles;   // cout tiles (all groups) of expand1x1 / expand3x3
+};
+
+template <typename T, int NTS, int NTW>
+__global__ __launch_bounds__(256) void fire_fused(FireArgs a) {
+  constexpr int KG = Tr<T>::KG;
+  constexpr int KC = 4 * KG;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  int b = blockIdx.x;
+  const int tx = b % a.tiles_x; b /= a.tiles_x;
+  const int ty = b % a.tiles_y;
+  const int n = b / a.tiles_y;
+  const int oy0 = ty * FROWS, ox0 = tx * FCOLS;
+
+  // ---------------------------------------------------------------- phase A: squeeze on the halo
+  {
+    // zero the channel padding of the last squeeze chunk (S not a multiple of 64 bytes)
+    const int s_pieces = a.S * (int)sizeof(T) / 16;
+    const int pad = a.nch_s * 4 - s_pieces;
+    for (int idx = threadIdx.x; idx < FHP * pad; idx += 256) {
+      const int P = idx / pad, q = s_pieces + (idx - P * pad);
+      *reinterpret_cast<i32x4*>(lds + (q >> 2) * FCHUNK + P * 64 + (((q & 3) ^ ((P >> 1) & 3)) << 4)) = i32x4{0, 0, 0, 0};
+    }
+    constexpr int MB = FBLK / 4;   // 3 pixel blocks per wave
+    int P[MB];
+    bool inimg[MB];
+    const T* src[MB];
+    const T* x = reinterpret_cast<const T*>(a.x);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      P[mb] = (wave * MB + mb) * 16 + j;
+      const int r = P[mb] / (FCOLS + 2), c = P[mb] - r * (FCOLS + 2);
+      const int iy = oy0 - 1 + r, ix = ox0 - 1 + c;
+      inimg[mb] = P[mb] < FHP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      src[mb] = x + (((size_t)n * a.H + (inimg[mb] ? iy : 0)) * a.W + (inimg[mb] ? ix : 0)) * a.Cin + g * KG;
+    }
+    f32x4 acc[MB][NTS];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int t = 0; t < NTS; ++t) acc[mb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const i32x4* wsp = reinterpret_cast<const i32x4*>(a.ws) + lane;
+    const i32x4 zero = {0, 0, 0, 0};
+    auto load_step = [&](int c, i32x4 (&bf)[MB], i32x4 (&af)[NTS]) {
+      const bool k_ok = c * 4 + g < a.x_pieces;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) bf[mb] = (inimg[mb] && k_ok) ? *reinterpret_cast<const i32x4*>(src[mb] + c * KC) : zero;
+#pragma unroll
+      for (int t = 0; t < NTS; ++t) af[t] = wsp[(c * NTS + t) * 64];
+    };
+    i32x4 bc[MB], bn[MB], ac[NTS], an[NTS];
+    load_step(0, bc, ac);
+#pragma unroll 1
+    for (int c = 0; c < a.nch_x; ++c) {
+      if (c + 1 < a.nch_x) load_step(c + 1, bn, an);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int t = 0; t < NTS; ++t) mma16<T>(acc[mb][t], ac[t], bc[mb]);
+      if (c + 1 < a.nch_x) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) bc[mb] = bn[mb];
+#pragma unroll
+        for (int t = 0; t < NTS; ++t) ac[t] = an[t];
+      }
+    }
+    // bias + ReLU -> storage type -> LDS squeeze tile; lane = pixel P, channels g*4*NTS + 4t .. +4
+#pragma unroll
+    for (int t = 0; t < NTS; ++t) {
+      const int ch0 = g * 4 * NTS + 4 * t;
+      if (ch0 < a.S) {
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bs + ch0);
+        const int q = ch0 / KG;                         // 16-byte piece of the pixel's channel vector
+        const int sub = (ch0 - q * KG) * (int)sizeof(T);  // byte offset inside the piece (0 or 8 for f16, 0 for f32)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          if (P[mb] < FHP) {
+            f32x4 v = acc[mb][t] + bias;
+            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            if (!inimg[mb]) v = f32x4{0.f, 0.f, 0.f, 0.f};   // SAME padding of the squeeze tensor
+            unsigned char* dst = lds + (q >> 2) * FCHUNK + P[mb] * 64 + (((q & 3) ^ ((P[mb] >> 1) & 3)) << 4) + sub;
+            store4<T>(reinterpret_cast<T*>(dst), v);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- phase B: expand3x3 + expand1x1
+  constexpr int MT = FROWS;
+  T* y = reinterpret_cast<T*>(a.y);
+  const int ox = ox0 + j;
+  const int ctot = a.E1 + a.E3;
+  const int n3 = a.e3_tiles / NTW, n1 = a.e1_tiles / NTW;
+  for (int item = wave; item < n3 + n1; item += 4) {
+    const bool is3 = item < n3;
+    const int tile0 = (is3 ? item : item - n3) * NTW;
+    const int group = tile0 / a.e_nt, n0 = tile0 - group * a.e_nt;
+    const int taps = is3 ? 9 : 1;
+    const int steps = taps * a.nch_s;
+    const i32x4* wbase = reinterpret_cast<const i32x4*>(is3 ? a.w3 : a.w1) + ((size_t)group * steps * a.e_nt + n0) * 64 + lane;
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Steps walk chunk-major, tap-minor -- the accumulation order of conv3x3_tile, so the result is
+    // bitwise the unfused one; the packed fragment of (tap, chunk) sits at step tap*nch_s + chunk.
+    // expand1x1 = the centre tap only.
+    auto frag = [&](int s) {
+      const int c = is3 ? s / 9 : s;
+      const int tap = is3 ? s - c * 9 : 0;
+      return wbase + (size_t)(tap * a.nch_s + c) * a.e_nt * 64;
+    };
+    i32x4 af[NTW], afn[NTW];
+    {
+      const i32x4* wp = frag(0);
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) af[t] = wp[t * 64];
+    }
+#pragma unroll 1
+    for (int s = 0; s < steps; ++s) {
+      if (s + 1 < steps) {
+        const i32x4* wp = frag(s + 1);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) afn[t] = wp[t * 64];
+      }
+      const int c = is3 ? s / 9 : s;
+      const int tap = is3 ? s - c * 9 : 4;
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const unsigned char* lchunk = lds + c * FCHUNK;
+      const int P0 = dy * (FCOLS + 2) + j + dx;
+      const int h0 = P0 >> 1;
+      i32x4 bf[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int slot = g ^ ((h0 + m) & 3);
+        bf[m] = *reinterpret_cast<const i32x4*>(lchunk + (P0 + (FCOLS + 2) * m) * 64 + (slot << 4));
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], af[t], bf[m]);
+      if (s + 1 < steps) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) af[t] = afn[t];
+      }
+    }
+    // epilogue: bias + ReLU, 4*NTW consecutive channels per lane into the concat tensor
+    const int cout = is3 ? a.E3 : a.E1;
+    const int coff = is3 ? a.E1 : 0;
+    const float* bias_p = is3 ? a.b3 : a.b1;
+    const int cb = group * 16 * a.e_nt + g * 4 * a.e_nt + n0 * 4;
+    f32x4 bias[NTW];
+    int nt_valid = 0;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const bool ok = cb + t * 4 < cout;
+      bias[t] = ok ? *reinterpret_cast<const f32x4*>(bias_p + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      nt_valid += ok ? 1 : 0;
+    }
+    if (ox < a.W) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int oy = oy0 + m;
+        if (oy >= a.H) break;
+        T* dst = y + (((size_t)n * a.H + oy) * a.W + ox) * ctot + coff + cb;
+        f32x4 v[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          v[t] = acc[m][t] + bias[t];
+          v[t][0] = fmaxf(v[t][0], 0.f); v[t][1] = fmaxf(v[t][1], 0.f);
+          v[t][2] = fmaxf(v[t][2], 0.f); v[t][3] = fmaxf(v[t][3], 0.f);
+        }
+        store_couts<T, NTW>(dst, v, nt_valid);
+      }
+    }
+  }
+}
+
+template <typename T, int NTS>
+static bool dispatch_fire_ntw(const FireArgs& a, int ntw, size_t lds, hipStream_t st) {
+  const dim3 grid((unsigned)(a.N * a.tiles_x * a.tiles_y));
+  switch (ntw) {
+    case 2: hipLaunchKernelGGL((fire_fused<T, NTS, 2>), grid, dim3(256), lds, st, a); return true;
+    case 3: hipLaunchKernelGGL((fire_fused<T, NTS, 3>), grid, dim3(256), lds, st, a); return true;
+    case 4: hipLaunchKernelGGL((fire_fused<T, NTS, 4>), grid, dim3(256), lds, st, a); return true;
+    default: return false;
+  }
+}
+
+template <typename T>
+static bool dispatch_fire(const FireArgs& a, int nts, int ntw, size_t lds, hipStream_t st) {
+  switch (nts) {
+    case 1: return dispatch_fire_ntw<T, 1>(a, ntw, lds, st);
+    case 2: return dispatch_fire_ntw<T, 2>(a, ntw, lds, st);
+    case 3: return dispatch_fire_ntw<T, 3>(a, ntw, lds, st);
+    case 4: return dispatch_fire_ntw<T, 4>(a, ntw, lds, st);
+    case 6: return dispatch_fire_ntw<T, 6>(a, ntw, lds, st);
+    default: return false;
+  }
+}
+
+// Same checks as fire_fused_launch, for the executor's plan-time decision.
+bool fire_fused_eligible(int cin, int s, int e1, int e3, int dtype) {
+  if (conv_algo() != 0) return false;
+  const int esz = dtype == SQDET_F16 ? 2 : 4;
+  const ConvGeom gs = conv_geom(1, cin, s, dtype), g1 = conv_geom(1, s, e1, dtype), g3 = conv_geom(3, s, e3, dtype);
+  if (gs.gather || g1.gather || g3.gather || gs.ngroups != 1) return false;
+  if (!(gs.nt == 1 || gs.nt == 2 || gs.nt == 3 || gs.nt == 4 || gs.nt == 6)) return false;
+  if (g1.nt != g3.nt || g1.nchunk != g3.nchunk) return false;
+  if ((cin * esz) % 16 != 0 || (s * esz) % 16 != 0 || s % 4 != 0 || e1 % 8 != 0 || e3 % 8 != 0) return false;
+  const int ntw = g1.nt == 6 ? 3 : (g1.nt == 4 ? 4 : (g1.nt == 2 ? 2 : 0));
+  if (!ntw) return false;
+  if ((g1.nt * g1.ngroups) % ntw || (g3.nt * g3.ngroups) % ntw) return false;
+  return (size_t)g1.nchunk * FCHUNK <= 60000;
+}
+
+// *handled = false: not eligible, run the three convs separately.
+int fire_fused_launch(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
+                      const float* b3, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
+                      hipStream_t st, bool* handled) {
+  *handled = false;
+  if (conv_algo() != 0) return SQDET_OK;
+  const int esz = dtype == SQDET_F16 ? 2 : 4;
+  const ConvGeom gs = conv_geom(1, cin, s, dtype), g1 = conv_geom(1, s, e1, dtype), g3 = conv_geom(3, s, e3, dtype);
+  if (gs.gather || g1.gather || g3.gather || gs.ngroups != 1) return SQDET_OK;
+  if (g1.nt != g3.nt || g1.nchunk != g3.nchunk) return SQDET_OK;
+  if ((cin * esz) % 16 != 0 || (s * esz) % 16 != 0 || s % 4 != 0 || e1 % 8 != 0 || e3 % 8 != 0) return SQDET_OK;
+  int ntw = g1.nt == 6 ? 3 : (g1.nt == 4 ? 4 : (g1.nt == 2 ? 2 : 0));
+  if (!ntw) return SQDET_OK;
+  const int e1_tiles = g1.nt * g1.ngroups, e3_tiles = g3.nt * g3.ngroups;
+  if (e1_tiles % ntw || e3_tiles % ntw) return SQDET_OK;
+  const size_t lds = (size_t)g1.nchunk * FCHUNK;
+  if (lds > 60000) return SQDET_OK;
+  FireArgs a;
+  a.x = x; a.y = y; a.ws = ws; a.w1 = w1; a.w3 = w3; a.bs = bs; a.b1 = b1; a.b3 = b3;
+  a.N = n; a.H = h; a.W = w; a.Cin = cin; a.S = s; a.E1 = e1; a.E3 = e3;
+  a.tiles_x = (w + FCOLS - 1) / FCOLS; a.tiles_y = (h + FROWS - 1) / FROWS;
+  a.nch_x = gs.nchunk; a.x_pieces = cin * esz / 16; a.nch_s = g1.nchunk;
+  a.e_nt = g1.nt; a.e1_tiles = e1_tiles; a.e3_tiles = e3_tiles;
+  if ((long)n * a.tiles_x * a.tiles_y > 0x7fffffffL) return SQDET_OK;
+  const bool ok = dtype == SQDET_F16 ? dispatch_fire<f16>(a, gs.nt, ntw, lds, st) : dispatch_fire<float>(a, gs.nt, ntw, lds, st);
+  if (!ok) return SQDET_OK;
+  SQDET_CHECK_HIP(hipGetLastError());
+  *handled = true;
+  return SQDET_OK;
+}
+
+}  // namespace sqdet

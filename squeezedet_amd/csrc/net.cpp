@@ -17,8 +17,13 @@ int maxpool_launch(const void* x, void* y, int n, int h, int w, int c, int k, in
                    hipStream_t st);
 int stem_launch(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cout, int k,
                 int conv_pad, int pool_pad, int dtype, int y_cstride, int y_coffset, hipStream_t st, bool* handled);
+int fire_fused_launch(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
+                      const float* b3, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
+                      hipStream_t st, bool* handled);
+bool fire_fused_eligible(int cin, int s, int e1, int e3, int dtype);
 int conv_algo();
 int fire_overlap();
+int tune(int which);
 }  // namespace sqdet
 
 using namespace sqdet;
@@ -26,7 +31,8 @@ using namespace sqdet;
 namespace {
 
 enum { BUF_INPUT = -1, BUF_PREDS = -2, BUF_A = 0, BUF_B = 1, BUF_S = 2 };
-enum { L_CONV = 0, L_POOL = 1, L_STEM = 2 };  // L_STEM: conv(k, s2, Cin 3)+relu+maxpool(3, s2) in one launch
+// L_STEM: conv(k, s2, Cin 3)+relu+maxpool(3, s2) in one launch; L_FIRE: squeeze + both expands in one launch
+enum { L_CONV = 0, L_POOL = 1, L_STEM = 2, L_FIRE = 3 };
 
 struct Param {
   std::string name;
@@ -45,6 +51,9 @@ struct Layer {
   int y_cstride, y_coffset;
   int kparam, bparam;  // indices into params (conv)
   int pool_pad_mode;   // L_STEM: padding of the fused pool
+  // L_FIRE: cin = fire input channels, cout = e1 + e3; the three convs' parameters
+  int fs, fe1, fe3;
+  int kp_s, bp_s, kp_1, bp_1, kp_3, bp_3;
   double flops, bytes;
 };
 
@@ -194,7 +203,54 @@ int run_layer(sqdet_net* net, const Layer& L, const void* input, void* preds, hi
     if (!handled) { set_error("net: fused stem no longer eligible (conv_algo changed after net_create?)"); return SQDET_ESTATE; }
     return SQDET_OK;
   }
+  if (L.type == L_FIRE) {
+    auto pk = [&](int i) { return (const void*)(net->param_mem + net->params[i].offset); };
+    auto pb = [&](int i) { return reinterpret_cast<const float*>(net->param_mem + net->params[i].offset); };
+    bool handled = false;
+    const int rc = fire_fused_launch(x, pk(L.kp_s), pb(L.bp_s), pk(L.kp_1), pb(L.bp_1), pk(L.kp_3), pb(L.bp_3), y,
+                                     net->batch, L.h, L.w, L.cin, L.fs, L.fe1, L.fe3, net->dtype, st, &handled);
+    if (rc != SQDET_OK) return rc;
+    if (!handled) { set_error("net: fused fire no longer eligible (options changed after net_create?)"); return SQDET_ESTATE; }
+    return SQDET_OK;
+  }
   return maxpool_launch(x, y, net->batch, L.h, L.w, L.cin, L.k, L.stride, L.pad_mode, net->dtype, st);
+}
+
+// squeeze1x1 + expand1x1 + expand3x3 -> one L_FIRE launch (decided at plan creation).  Heuristic
+// (tools/kbench.py on MI355X): fusion pays on the small late feature maps, where the three
+// launches are latency-bound; "fire_fuse" = 1 forces it everywhere, 2 disables it.
+void fuse_fires(sqdet_net* net, size_t esz) {
+  if (conv_algo() != 0 || tune(3) == 2) return;
+  std::vector<Layer> out;
+  const std::vector<Layer>& in = net->layers;
+  for (size_t i = 0; i < in.size(); ++i) {
+    const bool trio = i + 2 < in.size() && in[i].type == L_CONV && in[i + 1].type == L_CONV && in[i + 2].type == L_CONV &&
+                      in[i].out_buf == BUF_S && in[i + 1].in_buf == BUF_S && in[i + 2].in_buf == BUF_S && in[i].k == 1 &&
+                      in[i + 1].k == 1 && in[i + 2].k == 3 && in[i + 1].out_buf == in[i + 2].out_buf;
+    const long pixels = (long)net->batch * in[i].h * in[i].w;
+    if (!trio || !(tune(3) == 1 || pixels <= 100000) ||
+        !fire_fused_eligible(in[i].cin, in[i].cout, in[i + 1].cout, in[i + 2].cout, net->dtype)) {
+      out.push_back(in[i]);
+      continue;
+    }
+    const Layer &s = in[i], &e1 = in[i + 1], &e3 = in[i + 2];
+    Layer f = s;
+    f.type = L_FIRE;
+    f.name = s.name.substr(0, s.name.find('/'));
+    f.out_buf = e1.out_buf;
+    f.cout = e1.cout + e3.cout;
+    f.fs = s.cout; f.fe1 = e1.cout; f.fe3 = e3.cout;
+    f.kp_s = s.kparam; f.bp_s = s.bparam; f.kp_1 = e1.kparam; f.bp_1 = e1.bparam; f.kp_3 = e3.kparam; f.bp_3 = e3.bparam;
+    f.y_cstride = f.cout; f.y_coffset = 0;
+    f.flops = s.flops + e1.flops + e3.flops;
+    // algorithmic bytes: fire input + concat output + the three weight sets (squeeze tensor not counted)
+    const double npix = (double)net->batch * s.h * s.w;
+    f.bytes = (npix * s.cin + npix * f.cout + (double)s.cin * s.cout + (double)s.cout * e1.cout + 9.0 * s.cout * e3.cout) *
+                  (double)esz + 4.0 * (s.cout + e1.cout + e3.cout);
+    out.push_back(f);
+    i += 2;
+  }
+  net->layers.swap(out);
 }
 
 // conv1 + pool1 -> one L_STEM launch when the fused kernel applies (decided at plan creation).
@@ -256,6 +312,7 @@ extern "C" int sqdet_net_create(sqdet_net_t** out, int arch, int dtype, int batc
   b.conv_layer("conv12", nout, 3, 1, SQDET_PAD_SAME, 0, true);
   net->gh = b.h; net->gw = b.w; net->out_ch = nout;
   fuse_stem(net, b.esz);
+  fuse_fires(net, b.esz);
   size_t off = 0;
   for (int i = 0; i < 3; ++i) {
     net->buf_off[i] = off;
@@ -442,7 +499,13 @@ extern "C" int sqdet_fire_fwd(const void* x, const void* w_s, const float* b_s, 
                               int cin, int s1x1, int e1x1, int e3x3, int dtype, sqdet_stream_t stream) {
   SQDET_REQUIRE(sq_scratch, "fire_fwd: null scratch");
   hipStream_t st = as_stream(stream);
-  int rc = conv2d_launch(x, w_s, b_s, sq_scratch, n, h, w, cin, s1x1, 1, 1, SQDET_PAD_SAME, 1, dtype, s1x1, 0, st);
+  bool handled = false;
+  int rc = SQDET_OK;
+  if (tune(3) != 2) {  // one fused launch when eligible (the squeeze scratch is then untouched)
+    rc = fire_fused_launch(x, w_s, b_s, w_e1, b_e1, w_e3, b_e3, y, n, h, w, cin, s1x1, e1x1, e3x3, dtype, st, &handled);
+    if (rc != SQDET_OK || handled) return rc;
+  }
+  rc = conv2d_launch(x, w_s, b_s, sq_scratch, n, h, w, cin, s1x1, 1, 1, SQDET_PAD_SAME, 1, dtype, s1x1, 0, st);
   if (rc != SQDET_OK) return rc;
   rc = conv2d_launch(sq_scratch, w_e1, b_e1, y, n, h, w, s1x1, e1x1, 1, 1, SQDET_PAD_SAME, 1, dtype, e1x1 + e3x3, 0, st);
   if (rc != SQDET_OK) return rc;

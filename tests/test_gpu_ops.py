@@ -144,6 +144,45 @@ def test_conv2d_concat_offset_and_fire(dtype):
     np.testing.assert_allclose(got, ref, **tol)
 
 
+FIRE_CASES = [("fire2", 64, 16, 64, 19, 37), ("fire3", 128, 16, 64, 9, 33), ("fire4", 128, 32, 128, 17, 20),
+              ("fire5", 256, 32, 128, 8, 16), ("fire6", 256, 48, 192, 24, 78), ("fire7", 384, 48, 192, 11, 19),
+              ("fire8", 384, 64, 256, 10, 17), ("fire9", 512, 64, 256, 9, 31), ("fire10", 512, 96, 384, 24, 78),
+              ("fire11", 768, 96, 384, 13, 21)]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("case", FIRE_CASES, ids=[c[0] for c in FIRE_CASES])
+def test_fused_fire_module_parity(case, dtype):
+    """sqdet_fire_fwd as ONE launch (squeeze halo in LDS -> expand1x1 || expand3x3 -> concat,
+    nets/squeezeDet.py:81-106) against the oracle, and BITWISE against the three separate convs."""
+    ops = _ops()
+    name, cin, s, e, H, W = case
+    tdt = torch.float16 if dtype == "fp16" else torch.float32
+    rs = np.random.RandomState(zlib.crc32(name.encode()) % (2 ** 31))
+    p = {}
+    for sub, (k, ci, co) in (("squeeze1x1", (1, cin, s)), ("expand1x1", (1, s, e)), ("expand3x3", (3, s, e))):
+        w = torch.from_numpy((rs.randn(k, k, ci, co) * (2.0 / (k * k * ci)) ** 0.5).astype(np.float32))
+        p["%s/%s/kernels" % (name, sub)] = w.half().float() if dtype == "fp16" else w
+        p["%s/%s/biases" % (name, sub)] = torch.from_numpy(rs.uniform(-0.3, 0.3, co).astype(np.float32))
+    x = torch.from_numpy(np.maximum(rs.randn(2, H, W, cin), 0).astype(np.float32))
+    if dtype == "fp16":
+        x = x.half().float()
+    ref = O.fire_layer(p, name, x, storage=dtype).numpy()
+    pk = {n: ops.pack_conv_weights(p["%s/%s/kernels" % (name, n)].to(DEV), tdt) for n in ("squeeze1x1", "expand1x1", "expand3x3")}
+    bs = {n: p["%s/%s/biases" % (name, n)].to(DEV) for n in pk}
+    xd = x.to(DEV, tdt).contiguous()
+    args = (xd, pk["squeeze1x1"], bs["squeeze1x1"], pk["expand1x1"], bs["expand1x1"], pk["expand3x3"], bs["expand3x3"])
+    ops.set_option("fire_fuse", 1)
+    y_fused = ops.fire(*args)
+    ops.set_option("fire_fuse", 2)
+    y_sep = ops.fire(*args)
+    ops.set_option("fire_fuse", 0)
+    torch.cuda.synchronize()
+    assert torch.equal(y_fused, y_sep), "fused fire differs from squeeze -> expand1x1 / expand3x3"
+    tol = dict(rtol=1e-3, atol=1e-4) if dtype == "fp32" else dict(rtol=2 ** -8, atol=2e-3)
+    np.testing.assert_allclose(y_fused.float().cpu().numpy(), ref, **tol)
+
+
 POOL_CASES = [(2, 37, 53, 64, 3, 2, "SAME"), (1, 188, 621, 8, 3, 2, "SAME"), (1, 47, 156, 16, 3, 2, "SAME"),
               (1, 94, 311, 8, 3, 2, "SAME"), (1, 41, 57, 96, 3, 2, "VALID"), (1, 12, 14, 8, 2, 2, "SAME"), (1, 3, 3, 8, 3, 2, "SAME")]
 

@@ -62,7 +62,13 @@ def main():
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--opt", action="append", default=[], help="tuning knob name=value (sqdet_set_option), repeatable")
     args = ap.parse_args()
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ops.set_option(k, int(v))
+    if args.opt:
+        print("options:", " ".join(args.opt))
     dt = torch.float16 if args.dtype == "fp16" else torch.float32
     esz = 2 if args.dtype == "fp16" else 4
     dev = "cuda:0"
@@ -107,6 +113,32 @@ def main():
         nbytes = (x.numel() + args.batch * hp * wp * 64) * esz
         print("%-22s %9.4f %9.1f   (fused conv1+pool1)" % ("stem", ms, nbytes / ms / 1e6))
     print("sum auto %.4f ms   sum generic %.4f ms" % tuple(tot))
+    # whole fire modules: one fused launch vs squeeze -> expand1x1 / expand3x3
+    if not args.only or "fire" in args.only:
+        print("%-10s %10s %10s   (fused vs three launches, ms)" % ("module", "fused", "separate"))
+        o = lambda n: -(-n // 2)
+        h, w = o(o(args.height)), o(o(args.width))
+        c = 64
+        ft = st = 0.0
+        for name, s, e1, e3 in FIRES:
+            x = torch.randn((args.batch, h, w, c), generator=g).clamp_(min=0).to(dev, dt)
+            mk = lambda k, ci, co: ops.pack_conv_weights((torch.randn((k, k, ci, co), generator=g) * (2.0 / (k * k * ci)) ** 0.5).to(dev), dt)
+            ps, p1, p3 = mk(1, c, s), mk(1, s, e1), mk(3, s, e3)
+            bz = [torch.zeros(n_, device=dev) for n_ in (s, e1, e3)]
+            fn = lambda: ops.fire(x, ps, bz[0], p1, bz[1], p3, bz[2])
+            ops.set_option("fire_fuse", 1)
+            t1 = timeit(fn, args.iters)
+            ops.set_option("fire_fuse", 2)
+            t2 = timeit(fn, args.iters)
+            ops.set_option("fire_fuse", 0)
+            ft += t1
+            st += t2
+            print("%-10s %10.4f %10.4f" % (name, t1, t2))
+            c = e1 + e3
+            if name in ("fire3", "fire5"):
+                h, w = o(h), o(w)
+            del x
+        print("%-10s %10.4f %10.4f" % ("sum", ft, st))
 
 
 if __name__ == "__main__":
