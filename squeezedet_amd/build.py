@@ -24,6 +24,7 @@ SOURCES = [
     ("conv3x3.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("conv1x1.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("stem.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    ("stem2.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("fire.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("pool.hip", []),
     ("postproc.hip", ["-ffp-contract=off"]),

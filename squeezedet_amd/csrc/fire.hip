@@ -38,7 +38,7 @@ struct FireArgs {
 };
 
 template <typename T, int NTS, int NTW>
-__global__ __launch_bounds__(256) void fire_fused(FireArgs a) {
+__global__ __launch_bounds__(256, (NTW <= 3 ? 3 : 2)) void fire_fused(FireArgs a) {  // 3 waves/SIMD when 96 accumulators fit in 168 VGPRs
   constexpr int KG = Tr<T>::KG;
   constexpr int KC = 4 * KG;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];

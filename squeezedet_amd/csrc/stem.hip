@@ -14,28 +14,14 @@
 //      tile (row stride Cout*sizeof(T)+16 B: the +16 makes the 8-lane ds_write_b128 groups conflict
 //      free); conv pixels outside the conv output get -inf so the pool ignores them (TF SAME max-pool);
 //   3. each thread max-reduces 3x3 conv pixels x 16 B of channels from LDS and stores 16 B.
-#include "conv_common.h"
+#include "stem.h"
 
 namespace sqdet {
 
-constexpr int SPH = 4, SPW = 16;               // pooled tile
+constexpr int SPH = 4, SPW = 16;              // pooled tile
 constexpr int SNR = 2 * SPH + 1, SNC = 2 * SPW + 1;  // conv pixels under the tile: 9 x 33
 constexpr int SNPIX = SNR * SNC;               // 297
 
-struct StemArgs {
-  const void* x;
-  const void* wp;
-  const float* bias;
-  void* y;
-  int N, H, W;          // input
-  int Hc, Wc;           // conv output
-  int Hp, Wp;           // pooled output
-  int ptc, plc;         // conv pad before (top, left)
-  int ptp, plp;         // pool pad before
-  int Cout, nchunk, kdim;
-  int tiles_x, tiles_y;
-  int y_cstride, y_coffset;
-};
 
 template <typename T, int KS, int NT>
 __global__ __launch_bounds__(256) void stem_conv_pool(StemArgs a) {
@@ -214,6 +200,10 @@ int stem_launch(const void* x, const void* w_packed, const float* bias, void* y,
   a.tiles_x = (a.Wp + SPW - 1) / SPW; a.tiles_y = (a.Hp + SPH - 1) / SPH;
   a.y_cstride = y_cstride; a.y_coffset = y_coffset;
   if (a.Hp <= 0 || a.Wp <= 0) return SQDET_OK;
+  if (tune(TUNE_STEM_ALGO) != 1) {  // default: the in-register-pool strip kernel (stem2.hip)
+    const int rc2 = stem_strip_launch(a, k, dtype, st, handled);
+    if (rc2 != SQDET_OK || *handled) return rc2;
+  }
   int rc;
   if (dtype == SQDET_F16)
     rc = k == 3 ? launch_stem<f16, 3, 4>(a, st) : launch_stem<f16, 7, 6>(a, st);
