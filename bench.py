@@ -173,7 +173,17 @@ def main(argv=None):
         else:
             roof = {"bound": "hbm", "achieved": round(nbytes / (avg_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+        # HBM bytes per launch from the PMC counters: not measurable inside this process; taken from the
+        # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+        # (profiles/r01_d_hbm_traffic_pmc.json: 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), else null
         roof["traffic"] = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_d_hbm_traffic_pmc.json")) as fh:
+                pmc = json.load(fh)["by_layer"]
+            if args.dtype == "fp16" and (args.batch, args.height, args.width) == (32, 375, 1242):
+                roof["traffic"] = pmc.get(name)
+        except (OSError, KeyError, ValueError):
+            pass
         roof["kernel"] = name
         roof["avg_launch_ms"] = round(avg_ms, 5)
         roof["algorithmic_bytes_per_launch"] = nbytes
