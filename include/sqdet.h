@@ -122,6 +122,68 @@ int sqdet_filter_prediction(const float* boxes, const float* probs, const int64_
                             int32_t* out_count, int n, int num_anchors, int classes, int top_n, int max_out,
                             double nms_thresh, float prob_thresh, sqdet_stream_t stream);
 
+/* ------------------------------------------------------------ training --
+ * Replaces the gradient half of the reference's TF graph for the trainable convs (stride 1,
+ * SAME: every conv but the frozen conv1, nets/squeezeDet.py:40-42), the loss graph
+ * (ModelSkeleton._add_loss_graph, nn_skeleton.py:285-327, on top of _add_interpretation_graph
+ * :142-283) and the train graph (ModelSkeleton._add_train_graph, nn_skeleton.py:329-361).
+ * float32 storage (SQDET_F32), the reference's training dtype.
+ */
+
+/* Backward-data: dx = conv(dy, rot180(W)^T).  pack: float32 HWIO [k,k,cin,cout] -> fragment order
+ * of the [k,k,cout,cin] kernel (same size as sqdet_conv_packed_bytes(k, cout, cin, dtype)).
+ * dy is channels [dy_coffset, +cout) of rows dy_cstride wide (a fire module's concat gradient);
+ * accumulate != 0: dx += result (the squeeze tensor receives expand1x1's and expand3x3's dgrad). */
+int sqdet_conv_pack_weights_bwd_data(const float* w_hwio_f32, void* packed, int k, int cin, int cout, int dtype,
+                                     sqdet_stream_t stream);
+int sqdet_conv2d_nhwc_bwd_data(const void* dy, const void* w_packed_bwd, void* dx, int n, int h, int w, int cin,
+                               int cout, int k, int dtype, int dy_cstride, int dy_coffset, int accumulate,
+                               sqdet_stream_t stream);
+
+/* Backward-filter (+ bias): dW[kh,kw,ci,co] = sum_pixels x@tap[ci]*dy[co] (+ weight_decay*W when
+ * w_hwio_for_decay != NULL: the gradient of wd*l2_loss(W), nn_skeleton.py:66-69), dbias[co] =
+ * sum dy (dbias may be NULL).  x / dy may be channel slices.  workspace: device scratch of
+ * sqdet_conv2d_bwd_filter_workspace_bytes(...).  Deterministic (two-pass slab reduction). */
+size_t sqdet_conv2d_bwd_filter_workspace_bytes(int n, int h, int w, int cin, int cout, int k);
+int sqdet_conv2d_nhwc_bwd_filter(const float* x, const float* dy, float* dw_hwio, float* dbias,
+                                 const float* w_hwio_for_decay, float weight_decay, float* workspace, int n, int h,
+                                 int w, int cin, int cout, int k, int x_cstride, int x_coffset, int dy_cstride,
+                                 int dy_coffset, sqdet_stream_t stream);
+
+/* dy *= (y > 0)  (tf.nn.relu gradient; count floats, multiple of 4). */
+int sqdet_relu_bwd(const float* y, float* dy_inout, size_t count, sqdet_stream_t stream);
+/* y = x * mask * scale: tf.nn.dropout forward (mask = floor(keep_prob + U) in {0,1}, scale =
+ * 1/keep_prob; nets/squeezeDet.py:74) and its backward. */
+int sqdet_scale_mask(const float* x, const float* mask, float* y, float scale, size_t count, sqdet_stream_t stream);
+/* tf.nn.max_pool gradient: dx[cell] = sum of dy over the windows whose first maximum the cell is. */
+int sqdet_maxpool_nhwc_bwd(const float* x, const float* dy, float* dx, int n, int h, int w, int c, int k, int stride,
+                           int pad_mode, sqdet_stream_t stream);
+
+/* Loss forward + backward.  Inputs as the reference's placeholders (nn_skeleton.py:86-97):
+ * input_mask [B,A], box_delta_input [B,A,4], box_input [B,A,4] (cx,cy,w,h), labels [B,A,C];
+ * num_objects = sum(input_mask) over the batch.  Outputs: dpreds = d(class+conf+bbox loss)/dpreds
+ * [B,gh,gw,K*(C+5)], ious [B,A] (the assign'ed IoU target, no gradient), losses3 = {class_loss,
+ * conf_loss, bbox_loss}.  workspace: sqdet_loss_workspace_bytes() of device scratch. */
+size_t sqdet_loss_workspace_bytes(void);
+int sqdet_loss_fwd_bwd(const float* preds, const float* anchors, const float* input_mask, const float* box_delta_input,
+                       const float* box_input, const float* labels, float* dpreds, float* ious, float* losses3,
+                       float* workspace, int batch, int gh, int gw, int apg, int classes, float img_w, float img_h,
+                       float exp_thresh, float epsilon, float coef_class, float coef_conf_pos, float coef_conf_neg,
+                       float coef_bbox, float num_objects, sqdet_stream_t stream);
+
+/* Momentum + per-variable clip_by_norm over flat parameter / gradient / momentum buffers.
+ * Variable v = elements [offsets[v], +counts[v]); decays[v] = weight decay added to its gradient
+ * BEFORE clipping (0 for biases).  step: g += decay*w; g *= max_norm/max(||g||,max_norm);
+ * accum = momentum*accum + g; w -= lr*accum.  Deterministic (fixed-order norm reduction), so
+ * data-parallel replicas stay bit-identical. */
+typedef struct sqdet_optimizer sqdet_optimizer_t;
+int sqdet_optimizer_create(sqdet_optimizer_t** out, const long* offsets, const long* counts, const float* decays,
+                           int nvars);
+void sqdet_optimizer_destroy(sqdet_optimizer_t* opt);
+size_t sqdet_optimizer_workspace_bytes(const sqdet_optimizer_t* opt);
+int sqdet_optimizer_step(sqdet_optimizer_t* opt, float* params, float* grads, float* accum, void* workspace, float lr,
+                         float momentum, float max_grad_norm, sqdet_stream_t stream);
+
 /* ------------------------------------------------------------- network --
  * Replaces SqueezeDet.__init__/_add_forward_graph (nets/squeezeDet.py:19-79,
  * nets/squeezeDetPlus.py:19-79) + the sess.run([det_boxes,det_probs,det_class])

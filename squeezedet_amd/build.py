@@ -29,6 +29,7 @@ SOURCES = [
     ("pool.hip", []),
     ("postproc.hip", ["-ffp-contract=off"]),
     ("filter_fast.hip", ["-ffp-contract=off"]),
+    ("train.hip", ["-ffp-contract=off"]),
     ("probe.hip", []),
     ("net.cpp", []),
 ]

@@ -33,15 +33,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
   for (int n = 0; n < NT; ++n) {
     const int c = cbase + n * 4;
     if (c < a.Cout) {  // Cout % 4 == 0 (checked on the host)
-      const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + c);
+      const f32x4 b = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         if (valid[m]) {
           f32x4 v = acc[m][n] + b;
+          T* dst = y + (size_t)pix[m] * a.y_cstride + a.y_coffset + c;
+          if (a.accum) {
+            v[0] += (float)dst[0]; v[1] += (float)dst[1]; v[2] += (float)dst[2]; v[3] += (float)dst[3];
+          }
           if (a.relu) {
             v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
           }
-          store4<T>(y + (size_t)pix[m] * a.y_cstride + a.y_coffset + c, v);
+          store4<T>(dst, v);
         }
       }
     }
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256) void conv_direct(ConvArgs a) {
       for (int m = 0; m < MT; ++m) {
         const int iy = iy0[m] + ty, ix = ix0[m] + tx;
         inb[m] = valid[m] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        src[m] = x + ((size_t)(nb[m] + iy) * a.W + ix) * a.Cin + g * KG;
+        src[m] = x + ((size_t)(nb[m] + iy) * a.W + ix) * a.x_cstride + a.x_coffset + g * KG;
       }
       for (int c = 0; c < a.nchunk; ++c) {
         const bool cin_ok = c * KC + g * KG < a.Cin;
@@ -244,10 +248,27 @@ static int dispatch_mt(ConvArgs& a, int nt, bool gather, hipStream_t st) {
   }
 }
 
+int conv2d_launch_ex(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
+                     int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
+                     int x_cstride, int x_coffset, int accum, hipStream_t st);
+
 int conv2d_launch(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
                   int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
                   hipStream_t st) {
-  SQDET_REQUIRE(x && w_packed && bias && y, "conv2d: null pointer");
+  return conv2d_launch_ex(x, w_packed, bias, y, n, h, w, cin, cout, k, stride, pad_mode, relu, dtype, y_cstride,
+                          y_coffset, cin, 0, 0, st);
+}
+
+// x_cstride / x_coffset: the input is channels [x_coffset, x_coffset+cin) of rows x_cstride wide;
+// accum: y += conv(x) instead of y = conv(x).  Both are served by the generic kernel only.
+int conv2d_launch_ex(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
+                     int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
+                     int x_cstride, int x_coffset, int accum, hipStream_t st) {
+  SQDET_REQUIRE(x && w_packed && y, "conv2d: null pointer");  // bias == NULL means no bias (generic kernel)
+  const int kg_ = dtype == SQDET_F16 ? 8 : 4;
+  SQDET_UNSUPPORTED(x_cstride % kg_ != 0 || x_coffset % kg_ != 0 || x_coffset < 0 || x_coffset + cin > x_cstride,
+                    "conv2d: x_cstride %d / x_coffset %d must be multiples of %d with coffset+cin <= cstride",
+                    x_cstride, x_coffset, kg_);
   SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "conv2d: bad dtype %d", dtype);
   SQDET_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && k > 0 && stride > 0, "conv2d: bad dims");
   SQDET_REQUIRE(pad_mode == SQDET_PAD_SAME || pad_mode == SQDET_PAD_VALID, "conv2d: bad pad_mode %d", pad_mode);
@@ -270,11 +291,17 @@ int conv2d_launch(const void* x, const void* w_packed, const float* bias, void* 
   a.ntiles = 0;
   a.nchunk = g.nchunk; a.steps = g.steps; a.ngroups = g.ngroups;
   a.y_cstride = y_cstride; a.y_coffset = y_coffset; a.relu = relu;
+  a.x_cstride = x_cstride; a.x_coffset = x_coffset; a.accum = accum;
+  const bool plain = x_cstride == cin && x_coffset == 0 && !accum && bias != nullptr;
+  SQDET_UNSUPPORTED(!plain && g.gather, "conv2d: channel-sliced / accumulating convs need Cin %% %d == 0", kg_);
   bool handled = false;
-  int rc = conv3x3_tile_launch(a, g, dtype, st, &handled);
-  if (rc != SQDET_OK || handled) return rc;
-  rc = conv1x1_stream_launch(a, g, dtype, st, &handled);
-  if (rc != SQDET_OK || handled) return rc;
+  int rc = SQDET_OK;
+  if (plain) {
+    rc = conv3x3_tile_launch(a, g, dtype, st, &handled);
+    if (rc != SQDET_OK || handled) return rc;
+    rc = conv1x1_stream_launch(a, g, dtype, st, &handled);
+    if (rc != SQDET_OK || handled) return rc;
+  }
   rc = dtype == SQDET_F16 ? dispatch_mt<f16>(a, g.nt, g.gather, st) : dispatch_mt<float>(a, g.nt, g.gather, st);
   if (rc != SQDET_OK) return rc;
   SQDET_CHECK_HIP(hipGetLastError());

@@ -33,6 +33,10 @@ struct ConvArgs {
   int ntiles;   // ceil(P / (16*MT))
   int nchunk, steps, ngroups;
   int y_cstride, y_coffset, relu;
+  // generic kernel only: the input may be a channel slice [x_coffset, x_coffset+Cin) of rows
+  // x_cstride channels wide, and the result may be ADDED to y (backward-data of a fire module:
+  // d(squeeze) = dgrad_1x1(dY[:, :e1]) + dgrad_3x3(dY[:, e1:])).
+  int x_cstride, x_coffset, accum;
 };
 
 template <typename T>

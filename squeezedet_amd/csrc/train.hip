@@ -1,0 +1,604 @@
+// Training-path kernels for gfx950 (float32 storage, the reference's training dtype):
+//   conv backward-data   -- the forward conv kernel run on the 180-degree-rotated, in/out-swapped
+//                           kernel (stride-1 SAME convs: every trainable conv of SqueezeDet);
+//   conv backward-filter -- split-K GEMM over pixels on the exact-f32 MFMA, deterministic two-pass
+//                           reduction (no atomics), + bias gradient;
+//   ReLU / max-pool / dropout backward;
+//   loss forward+backward (reference src/nn_skeleton.py:142-327: _add_interpretation_graph +
+//                           _add_loss_graph) writing dL/dpreds;
+//   Momentum update with per-variable clip_by_norm and weight decay (nn_skeleton.py:329-361).
+// Compiled with -ffp-contract=off (the loss decode must match interpret_output op for op).
+#include <math.h>
+
+#include <vector>
+
+#include "conv_common.h"
+
+namespace sqdet {
+
+int conv2d_launch_ex(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
+                     int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
+                     int x_cstride, int x_coffset, int accum, hipStream_t st);
+
+// ------------------------------------------------------------------ backward-data weight packing
+// dgrad(dy)[ci] = sum_{tap,co} W[k-1-ty][k-1-tx][ci][co] * dy@tap[co]: a forward conv with
+// kernel W'[ty][tx][co][ci].  Packed in the forward fragment order for a [k,k,cout,cin] kernel.
+template <typename T>
+__global__ void pack_bwd_data_kernel(const float* __restrict__ w, T* __restrict__ out, int k, int cin, int cout,
+                                     int nchunk, int nt, size_t total) {
+  constexpr int KG = Tr<T>::KG;
+  constexpr int KC = 4 * KG;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    size_t t = idx;
+    const int e = t % KG; t /= KG;
+    const int lane = t % 64; t /= 64;
+    const int n = t % nt; t /= nt;
+    const int step = t % (k * k * nchunk); t /= (k * k * nchunk);
+    const int group = (int)t;
+    const int tap = step / nchunk, chunk = step - tap * nchunk;
+    const int i = lane & 15, g = lane >> 4;
+    const int o = group * 16 * nt + (i >> 2) * 4 * nt + n * 4 + (i & 3);   // output channel of the dgrad = original cin
+    const int c = chunk * KC + g * KG + e;                                  // input channel of the dgrad = original cout
+    const int ty = tap / k, tx = tap - ty * k;
+    float v = 0.f;
+    if (o < cin && c < cout) v = w[(((size_t)(k - 1 - ty) * k + (k - 1 - tx)) * cin + o) * cout + c];
+    out[idx] = (T)v;
+  }
+}
+
+// ------------------------------------------------------------------ backward-filter (wgrad)
+// dW[tap][ci][co] = sum_p X[p@tap][ci] * dY[p][co]; GEMM M = ci, N = co, K = pixels.
+// Workgroup: one tap x (MW*16 ci) x (NW*16 co) tile; 4 waves 2x2, each (MW/2 x NW/2) MFMA tiles;
+// K walked in 32-pixel stages staged through LDS (coalesced 16-byte loads, TF zero padding by
+// bounds predication); blockIdx.z owns every ksplit-th stage and writes a partial [tap][ci][co]
+// slab; wgrad_reduce sums the slabs in a fixed order (deterministic).
+struct WgArgs {
+  const float* x;
+  const float* dy;
+  float* partial;
+  int N, H, W, Cin, Cout, k, pad;
+  int x_cstride, x_coffset, dy_cstride, dy_coffset;
+  int P, nstages, ksplit, ci_tiles;
+};
+
+template <int MW, int NW>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
+  constexpr int PS = 32;                 // pixels per stage
+  constexpr int XS = MW * 16 + 16;       // LDS row strides (floats): == 16 mod 32 -> the two k rows a
+  constexpr int DS = NW * 16 + 16;       //   ds_read_b32 half-wave touches hit disjoint bank halves
+  __shared__ float xs[PS * XS];
+  __shared__ float dsm[PS * DS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int i = lane & 15, kk = lane >> 4;
+  const int tap = blockIdx.x / a.ci_tiles;
+  const int ci0 = (blockIdx.x - tap * a.ci_tiles) * (MW * 16);
+  const int co0 = blockIdx.y * (NW * 16);
+  const int ty = tap / a.k, tx = tap - ty * a.k;
+
+  f32x4 acc[MW / 2][NW / 2];
+#pragma unroll
+  for (int mi = 0; mi < MW / 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NW / 2; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int st = blockIdx.z; st < a.nstages; st += a.ksplit) {
+    const int p0 = st * PS;
+    // ---- stage X (shifted by the tap) and dY ----
+    for (int idx = threadIdx.x; idx < PS * (MW * 4); idx += 256) {
+      const int pp = idx / (MW * 4), c4 = idx - pp * (MW * 4);
+      const int p = p0 + pp;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int ci = ci0 + c4 * 4;
+      if (p < a.P && ci < a.Cin) {
+        const int n = p / (a.H * a.W);
+        const int r = p - n * (a.H * a.W);
+        const int y = r / a.W, xx = r - y * a.W;
+        const int iy = y + ty - a.pad, ix = xx + tx - a.pad;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+          v = *reinterpret_cast<const f32x4*>(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.x_cstride + a.x_coffset + ci);
+      }
+      *reinterpret_cast<f32x4*>(&xs[pp * XS + c4 * 4]) = v;
+    }
+    for (int idx = threadIdx.x; idx < PS * (NW * 4); idx += 256) {
+      const int pp = idx / (NW * 4), c4 = idx - pp * (NW * 4);
+      const int p = p0 + pp;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int co = co0 + c4 * 4;
+      if (p < a.P && co < a.Cout) v = *reinterpret_cast<const f32x4*>(a.dy + (size_t)p * a.dy_cstride + a.dy_coffset + co);
+      *reinterpret_cast<f32x4*>(&dsm[pp * DS + c4 * 4]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < PS / 4; ++ks) {
+      float af[MW / 2], bf[NW / 2];
+#pragma unroll
+      for (int mi = 0; mi < MW / 2; ++mi) af[mi] = xs[(ks * 4 + kk) * XS + (wm * (MW / 2) + mi) * 16 + i];
+#pragma unroll
+      for (int ni = 0; ni < NW / 2; ++ni) bf[ni] = dsm[(ks * 4 + kk) * DS + (wn * (NW / 2) + ni) * 16 + i];
+#pragma unroll
+      for (int mi = 0; mi < MW / 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NW / 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D layout: col (co) = lane&15, row (ci) = 4*(lane>>4) + reg
+  float* out = a.partial + (size_t)blockIdx.z * a.k * a.k * a.Cin * a.Cout;
+#pragma unroll
+  for (int mi = 0; mi < MW / 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NW / 2; ++ni) {
+      const int co = co0 + (wn * (NW / 2) + ni) * 16 + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = ci0 + (wm * (MW / 2) + mi) * 16 + kk * 4 + r;
+        if (ci < a.Cin && co < a.Cout) out[((size_t)tap * a.Cin + ci) * a.Cout + co] = acc[mi][ni][r];
+      }
+    }
+}
+
+// out[e] = sum_z partial[z][e]  (+ decay * w[e] when w != NULL), z ascending: deterministic.
+__global__ void slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, const float* __restrict__ w,
+                                   float decay, size_t count, int nslabs) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < nslabs; ++z) s += partial[(size_t)z * count + e];
+    if (w) s += decay * w[e];
+    out[e] = s;
+  }
+}
+
+// bias gradient partials: partial[blockIdx.x][co] = sum over this block's pixels of dy[p][co]
+__global__ void bias_grad_partial_kernel(const float* __restrict__ dy, float* __restrict__ partial, int P, int cout,
+                                         int cstride, int coffset) {
+  const int co = blockIdx.y * blockDim.x + threadIdx.x;
+  if (co >= cout) return;
+  float s = 0.f;
+  for (int p = blockIdx.x; p < P; p += gridDim.x) s += dy[(size_t)p * cstride + coffset + co];
+  partial[(size_t)blockIdx.x * cout + co] = s;
+}
+
+// ------------------------------------------------------------------ elementwise backward ops
+__global__ void relu_bwd_kernel(const float* __restrict__ y, float* __restrict__ dy, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+    f32x4 g = reinterpret_cast<f32x4*>(dy)[i];
+    g[0] = v[0] > 0.f ? g[0] : 0.f; g[1] = v[1] > 0.f ? g[1] : 0.f;
+    g[2] = v[2] > 0.f ? g[2] : 0.f; g[3] = v[3] > 0.f ? g[3] : 0.f;
+    reinterpret_cast<f32x4*>(dy)[i] = g;
+  }
+}
+
+// y = x * mask * scale  (tf.nn.dropout forward with mask = floor(keep_prob + U), scale = 1/keep_prob; and its backward)
+__global__ void scale_mask_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ y,
+                                  float scale, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    const f32x4 m = reinterpret_cast<const f32x4*>(mask)[i];
+    f32x4 o;
+    o[0] = v[0] * m[0] * scale; o[1] = v[1] * m[1] * scale; o[2] = v[2] * m[2] * scale; o[3] = v[3] * m[3] * scale;
+    reinterpret_cast<f32x4*>(y)[i] = o;
+  }
+}
+
+// max-pool backward, gather form (deterministic): an input cell receives dy of every window whose
+// FIRST maximum (row-major scan, as tf.nn.max_pool's argmax) it is.
+__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                   int N, int H, int W, int C, int k, int stride, int pt, int pl, int Ho, int Wo) {
+  const int c4n = C / 4;
+  const size_t total = (size_t)N * H * W * c4n;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % c4n);
+    size_t p = idx / c4n;
+    const int ix = (int)(p % W); p /= W;
+    const int iy = (int)(p % H);
+    const int n = (int)(p / H);
+    const f32x4 me = *reinterpret_cast<const f32x4*>(x + idx * 4);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    // windows (oy, ox) containing (iy, ix): oy*stride - pt <= iy <= oy*stride - pt + k - 1
+    const int oy_hi = (iy + pt) / stride, ox_hi = (ix + pl) / stride;
+    for (int oy = oy_hi; oy >= 0 && oy * stride - pt + k - 1 >= iy; --oy) {
+      if (oy >= Ho) continue;
+      for (int ox = ox_hi; ox >= 0 && ox * stride - pl + k - 1 >= ix; --ox) {
+        if (ox >= Wo) continue;
+        // first argmax of the window, per channel
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int by[4] = {-1, -1, -1, -1}, bx[4] = {-1, -1, -1, -1};
+        for (int dy_ = 0; dy_ < k; ++dy_) {
+          const int yy = oy * stride - pt + dy_;
+          if (yy < 0 || yy >= H) continue;
+          for (int dx_ = 0; dx_ < k; ++dx_) {
+            const int xx = ox * stride - pl + dx_;
+            if (xx < 0 || xx >= W) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((((size_t)n * H + yy) * W + xx) * C + c4 * 4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (v[e] > best[e]) { best[e] = v[e]; by[e] = yy; bx[e] = xx; }
+          }
+        }
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + ((((size_t)n * Ho + oy) * Wo + ox) * C + c4 * 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (by[e] == iy && bx[e] == ix) g[e] += d[e];
+      }
+    }
+    (void)me;
+    *reinterpret_cast<f32x4*>(dx + idx * 4) = g;
+  }
+}
+
+// ------------------------------------------------------------------ loss forward + backward
+struct LossArgs {
+  const float* preds;      // [B, cells, K*(C+5)]
+  const float* anchors;    // [A,4] float32
+  const float* mask;       // [B,A]
+  const float* delta_in;   // [B,A,4]
+  const float* box_in;     // [B,A,4] (cx,cy,w,h)
+  const float* labels;     // [B,A,C]
+  float* dpreds;           // [B, cells, K*(C+5)]
+  float* ious;             // [B,A]
+  float* partial;          // [blocks][4]: class, conf, bbox loss partial sums (+ unused)
+  int B, cells, K, C;
+  float w1, h1, thr, slope, eps;
+  float coef_class, coef_pos, coef_neg, coef_bbox;
+  float num_obj;           // sum(mask) over the whole batch (host computed from the label tensors)
+};
+
+__global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
+  __shared__ float red[3][256];
+  const int A = a.cells * a.K;
+  const int ch = a.K * (a.C + 5);
+  const long total = (long)a.B * A;
+  float l_class = 0.f, l_conf = 0.f, l_bbox = 0.f;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(idx / A);
+    const int an = (int)(idx - (long)b * A);
+    const int cell = an / a.K, k = an - cell * a.K;
+    const float* p = a.preds + ((size_t)b * a.cells + cell) * ch;
+    float* dp = a.dpreds + ((size_t)b * a.cells + cell) * ch;
+    const float m = a.mask[idx];
+    // class probabilities (softmax) and their loss (nn_skeleton.py:150-160, 292-299)
+    const float* lg = p + k * a.C;
+    float mx = lg[0];
+    for (int c = 1; c < a.C; ++c) mx = fmaxf(mx, lg[c]);
+    float sum = expf(lg[0] - mx);
+    for (int c = 1; c < a.C; ++c) sum = sum + expf(lg[c] - mx);
+    const float inv = 1.0f / sum;
+    float gdotp = 0.f;
+    for (int c = 0; c < a.C; ++c) {
+      const float pc = expf(lg[c] - mx) * inv;
+      const float lab = a.labels[idx * a.C + c];
+      l_class += (lab * (-logf(pc + a.eps)) + (1.0f - lab) * (-logf(1.0f - pc + a.eps))) * m * a.coef_class;
+      const float gc = m * a.coef_class / a.num_obj * (-lab / (pc + a.eps) + (1.0f - lab) / (1.0f - pc + a.eps));
+      gdotp += gc * pc;
+    }
+    for (int c = 0; c < a.C; ++c) {
+      const float pc = expf(lg[c] - mx) * inv;
+      const float lab = a.labels[idx * a.C + c];
+      const float gc = m * a.coef_class / a.num_obj * (-lab / (pc + a.eps) + (1.0f - lab) / (1.0f - pc + a.eps));
+      dp[k * a.C + c] = pc * (gc - gdotp);
+    }
+    // decode (as interpret_output) -> IoU with the ground-truth box (nn_skeleton.py:240-269)
+    const float zc = p[a.K * a.C + k];
+    const float conf = 1.0f / (1.0f + expf(-zc));
+    const float* dl = p + a.K * (a.C + 1) + 4 * k;
+    const f32x4 anc = *reinterpret_cast<const f32x4*>(a.anchors + (size_t)an * 4);
+    const float cx = anc[0] + dl[0] * anc[2];
+    const float cy = anc[1] + dl[1] * anc[3];
+    const float ew = dl[2] > a.thr ? a.slope * ((dl[2] - a.thr) + 1.0f) : expf(dl[2]);
+    const float eh = dl[3] > a.thr ? a.slope * ((dl[3] - a.thr) + 1.0f) : expf(dl[3]);
+    const float bw = anc[2] * ew, bh = anc[3] * eh;
+    float xmin = fminf(fmaxf(0.0f, cx - bw / 2.0f), a.w1), ymin = fminf(fmaxf(0.0f, cy - bh / 2.0f), a.h1);
+    float xmax = fmaxf(fminf(a.w1, cx + bw / 2.0f), 0.0f), ymax = fmaxf(fminf(a.h1, cy + bh / 2.0f), 0.0f);
+    const float w2 = xmax - xmin + 1.0f, h2 = ymax - ymin + 1.0f;
+    const float dcx = xmin + 0.5f * w2, dcy = ymin + 0.5f * h2;
+    // bbox_transform of det box and of the GT box (utils/util.py:167-179), _tensor_iou (:241-262)
+    const float ax0 = dcx - w2 / 2.0f, ay0 = dcy - h2 / 2.0f, ax1 = dcx + w2 / 2.0f, ay1 = dcy + h2 / 2.0f;
+    const f32x4 gb = *reinterpret_cast<const f32x4*>(a.box_in + idx * 4);
+    const float bx0 = gb[0] - gb[2] / 2.0f, by0 = gb[1] - gb[3] / 2.0f, bx1 = gb[0] + gb[2] / 2.0f, by1 = gb[1] + gb[3] / 2.0f;
+    const float iw = fmaxf(0.0f, fminf(ax1, bx1) - fmaxf(ax0, bx0));
+    const float ih = fmaxf(0.0f, fminf(ay1, by1) - fmaxf(ay0, by0));
+    const float inter = iw * ih;
+    const float uni = (ax1 - ax0) * (ay1 - ay0) + (bx1 - bx0) * (by1 - by0) - inter;
+    const float iou = inter / (uni + a.eps) * m;
+    a.ious[idx] = iou;
+    // confidence loss (:304-312): mean over the batch of sum_a (iou-conf)^2 * w_a
+    const float wgt = m * a.coef_pos / a.num_obj + (1.0f - m) * a.coef_neg / ((float)A - a.num_obj);
+    const float dc = iou - conf;
+    l_conf += dc * dc * wgt / (float)a.B;
+    dp[a.K * a.C + k] = 2.0f * (conf - iou) * wgt / (float)a.B * conf * (1.0f - conf);
+    // bbox loss (:317-323)
+    for (int d = 0; d < 4; ++d) {
+      const float df = m * (dl[d] - a.delta_in[idx * 4 + d]);
+      l_bbox += a.coef_bbox * df * df / a.num_obj;
+      dp[a.K * (a.C + 1) + 4 * k + d] = 2.0f * a.coef_bbox * m * df / a.num_obj;
+    }
+  }
+  l_class = l_class / a.num_obj;
+  red[0][threadIdx.x] = l_class; red[1][threadIdx.x] = l_conf; red[2][threadIdx.x] = l_bbox;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + off];
+      red[1][threadIdx.x] += red[1][threadIdx.x + off];
+      red[2][threadIdx.x] += red[2][threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) a.partial[blockIdx.x * 4 + threadIdx.x] = threadIdx.x < 3 ? red[threadIdx.x][0] : 0.f;
+}
+
+// ------------------------------------------------------------------ optimizer
+// Segment table: variable v occupies [seg[v].off, +count) of the flat parameter / gradient / momentum
+// buffers.  Pass 1 adds the weight-decay gradient and writes per-block partial sums of squares; pass 2
+// (one block) finishes the norms in a fixed order; pass 3 clips per variable and applies Momentum.
+struct OptSeg { long off; long count; float decay; int first_block; int nblocks; };
+
+__global__ __launch_bounds__(256) void opt_sumsq_kernel(const OptSeg* __restrict__ segs, const int* __restrict__ block_seg,
+                                                        const float* __restrict__ w, float* __restrict__ g,
+                                                        double* __restrict__ partial) {
+  __shared__ double red[256];
+  const int v = block_seg[blockIdx.x];
+  const OptSeg s = segs[v];
+  const int lb = blockIdx.x - s.first_block;
+  double acc = 0.0;
+  for (long i = (long)lb * 256 + threadIdx.x; i < s.count; i += (long)s.nblocks * 256) {
+    float gi = g[s.off + i];
+    if (s.decay != 0.f) { gi = gi + s.decay * w[s.off + i]; g[s.off + i] = gi; }
+    acc += (double)gi * (double)gi;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void opt_norm_kernel(const OptSeg* __restrict__ segs, const double* __restrict__ partial, float* __restrict__ scale,
+                                int nvars, float max_norm) {
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nvars; v += gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int b = 0; b < segs[v].nblocks; ++b) s += partial[segs[v].first_block + b];
+    const float nrm = (float)sqrt(s);
+    scale[v] = max_norm / fmaxf(nrm, max_norm);   // tf.clip_by_norm: g * clip / max(||g||, clip)
+  }
+}
+
+__global__ __launch_bounds__(256) void opt_apply_kernel(const OptSeg* __restrict__ segs, const int* __restrict__ block_seg,
+                                                        float* __restrict__ w, const float* __restrict__ g,
+                                                        float* __restrict__ accum, const float* __restrict__ scale,
+                                                        float lr, float momentum) {
+  const int v = block_seg[blockIdx.x];
+  const OptSeg s = segs[v];
+  const int lb = blockIdx.x - s.first_block;
+  const float sc = scale[v];
+  for (long i = (long)lb * 256 + threadIdx.x; i < s.count; i += (long)s.nblocks * 256) {
+    const float gc = g[s.off + i] * sc;
+    const float ac = momentum * accum[s.off + i] + gc;   // MomentumOptimizer: accum = m*accum + g ; var -= lr*accum
+    accum[s.off + i] = ac;
+    w[s.off + i] = w[s.off + i] - lr * ac;
+  }
+}
+
+static int grid_for(size_t n, int cap = 4096) {
+  size_t b = (n + 255) / 256;
+  if (b > (size_t)cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace sqdet
+
+using namespace sqdet;
+
+extern "C" int sqdet_conv_pack_weights_bwd_data(const float* w_hwio_f32, void* packed, int k, int cin, int cout,
+                                                int dtype, sqdet_stream_t stream) {
+  SQDET_REQUIRE(w_hwio_f32 && packed && k > 0 && cin > 0 && cout > 0, "pack_weights_bwd_data: bad arguments");
+  SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "pack_weights_bwd_data: bad dtype");
+  const ConvGeom g = conv_geom(k, cout, cin, dtype);   // the dgrad conv: cout -> cin channels
+  SQDET_UNSUPPORTED(g.gather, "pack_weights_bwd_data: cout %d must be a multiple of %d", cout, g.kg);
+  const size_t total = (size_t)g.ngroups * g.steps * g.nt * 64 * g.kg;
+  if (dtype == SQDET_F16)
+    hipLaunchKernelGGL(pack_bwd_data_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w_hwio_f32,
+                       (f16*)packed, k, cin, cout, g.nchunk, g.nt, total);
+  else
+    hipLaunchKernelGGL(pack_bwd_data_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w_hwio_f32,
+                       (float*)packed, k, cin, cout, g.nchunk, g.nt, total);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_conv2d_nhwc_bwd_data(const void* dy, const void* w_packed_bwd, void* dx, int n, int h, int w, int cin,
+                                          int cout, int k, int dtype, int dy_cstride, int dy_coffset, int accumulate,
+                                          sqdet_stream_t stream) {
+  // stride-1 SAME convs only (every trainable conv of the reference's nets on this path)
+  SQDET_REQUIRE(k == 1 || k == 3, "conv2d_bwd_data: k must be 1 or 3 (stride 1, SAME)");
+  return conv2d_launch_ex(dy, w_packed_bwd, nullptr, dx, n, h, w, cout, cin, k, 1, SQDET_PAD_SAME, 0, dtype, cin, 0,
+                          dy_cstride, dy_coffset, accumulate, as_stream(stream));
+}
+
+extern "C" size_t sqdet_conv2d_bwd_filter_workspace_bytes(int n, int h, int w, int cin, int cout, int k) {
+  // ksplit slabs of the filter + 256 rows of bias partials
+  const long P = (long)n * h * w;
+  long nst = (P + 31) / 32;
+  long ks = nst < 64 ? nst : 64;
+  return (size_t)(ks * (long)k * k * cin * cout + 256L * cout) * sizeof(float);
+}
+
+extern "C" int sqdet_conv2d_nhwc_bwd_filter(const float* x, const float* dy, float* dw_hwio, float* dbias,
+                                            const float* w_hwio_for_decay, float weight_decay, float* workspace, int n,
+                                            int h, int w, int cin, int cout, int k, int x_cstride, int x_coffset,
+                                            int dy_cstride, int dy_coffset, sqdet_stream_t stream) {
+  SQDET_REQUIRE(x && dy && dw_hwio && workspace, "conv2d_bwd_filter: null pointer");
+  SQDET_REQUIRE((k == 1 || k == 3) && n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "conv2d_bwd_filter: bad dims");
+  SQDET_UNSUPPORTED(cin % 4 || cout % 4 || x_cstride % 4 || x_coffset % 4 || dy_cstride % 4 || dy_coffset % 4,
+                    "conv2d_bwd_filter: channel counts / strides must be multiples of 4");
+  hipStream_t st = as_stream(stream);
+  WgArgs a;
+  a.x = x; a.dy = dy; a.partial = workspace;
+  a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout; a.k = k; a.pad = k == 3 ? 1 : 0;
+  a.x_cstride = x_cstride; a.x_coffset = x_coffset; a.dy_cstride = dy_cstride; a.dy_coffset = dy_coffset;
+  const long P = (long)n * h * w;
+  SQDET_UNSUPPORTED(P > (1L << 30), "conv2d_bwd_filter: too many pixels");
+  a.P = (int)P;
+  a.nstages = (int)((P + 31) / 32);
+  const bool big_m = cin > 32, big_n = cout > 32;
+  const int mw = big_m ? 4 : 2, nw = big_n ? 4 : 2;
+  a.ci_tiles = (cin + mw * 16 - 1) / (mw * 16);
+  const int gx = k * k * a.ci_tiles, gy = (cout + nw * 16 - 1) / (nw * 16);
+  // enough workgroups to fill the chip, at most 64 slabs
+  int ks = (2048 + gx * gy - 1) / (gx * gy);
+  if (ks > 64) ks = 64;
+  if (ks > a.nstages) ks = a.nstages;
+  if (ks < 1) ks = 1;
+  a.ksplit = ks;
+  const dim3 grid(gx, gy, ks);
+  if (big_m && big_n) hipLaunchKernelGGL((wgrad_kernel<4, 4>), grid, dim3(256), 0, st, a);
+  else if (big_m) hipLaunchKernelGGL((wgrad_kernel<4, 2>), grid, dim3(256), 0, st, a);
+  else if (big_n) hipLaunchKernelGGL((wgrad_kernel<2, 4>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wgrad_kernel<2, 2>), grid, dim3(256), 0, st, a);
+  SQDET_CHECK_HIP(hipGetLastError());
+  const size_t count = (size_t)k * k * cin * cout;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(count)), dim3(256), 0, st, workspace, dw_hwio, w_hwio_for_decay,
+                     weight_decay, count, ks);
+  SQDET_CHECK_HIP(hipGetLastError());
+  if (dbias) {
+    float* bpart = workspace + (size_t)ks * count;
+    int rows = (int)(P < 256 ? P : 256);
+    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(rows, (cout + 255) / 256), dim3(256), 0, st, dy, bpart, (int)P, cout,
+                       dy_cstride, dy_coffset);
+    SQDET_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(cout)), dim3(256), 0, st, bpart, dbias, (const float*)nullptr, 0.f,
+                       (size_t)cout, rows);
+    SQDET_CHECK_HIP(hipGetLastError());
+  }
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_relu_bwd(const float* y, float* dy_inout, size_t count, sqdet_stream_t stream) {
+  SQDET_REQUIRE(y && dy_inout && count % 4 == 0, "relu_bwd: bad arguments (count must be a multiple of 4)");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(count / 4, 8192)), dim3(256), 0, as_stream(stream), y, dy_inout, count / 4);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_scale_mask(const float* x, const float* mask, float* y, float scale, size_t count,
+                                sqdet_stream_t stream) {
+  SQDET_REQUIRE(x && mask && y && count % 4 == 0, "scale_mask: bad arguments (count must be a multiple of 4)");
+  hipLaunchKernelGGL(scale_mask_kernel, dim3(grid_for(count / 4, 8192)), dim3(256), 0, as_stream(stream), x, mask, y, scale,
+                     count / 4);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_maxpool_nhwc_bwd(const float* x, const float* dy, float* dx, int n, int h, int w, int c, int k,
+                                      int stride, int pad_mode, sqdet_stream_t stream) {
+  SQDET_REQUIRE(x && dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && k > 0 && stride > 0,
+                "maxpool_bwd: bad arguments");
+  const int Ho = out_size(h, k, stride, pad_mode), Wo = out_size(w, k, stride, pad_mode);
+  const int pt = pad_before(h, k, stride, pad_mode), pl = pad_before(w, k, stride, pad_mode);
+  const size_t total = (size_t)n * h * w * (c / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, as_stream(stream), x, dy, dx, n, h, w, c,
+                     k, stride, pt, pl, Ho, Wo);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_loss_fwd_bwd(const float* preds, const float* anchors, const float* input_mask,
+                                  const float* box_delta_input, const float* box_input, const float* labels,
+                                  float* dpreds, float* ious, float* losses3, float* workspace, int batch, int gh, int gw,
+                                  int apg, int classes, float img_w, float img_h, float exp_thresh, float epsilon,
+                                  float coef_class, float coef_conf_pos, float coef_conf_neg, float coef_bbox,
+                                  float num_objects, sqdet_stream_t stream) {
+  SQDET_REQUIRE(preds && anchors && input_mask && box_delta_input && box_input && labels && dpreds && ious && losses3 &&
+                    workspace, "loss_fwd_bwd: null pointer");
+  SQDET_REQUIRE(batch > 0 && gh > 0 && gw > 0 && apg > 0 && classes > 0 && num_objects > 0.f, "loss_fwd_bwd: bad arguments");
+  LossArgs a;
+  a.preds = preds; a.anchors = anchors; a.mask = input_mask; a.delta_in = box_delta_input; a.box_in = box_input;
+  a.labels = labels; a.dpreds = dpreds; a.ious = ious; a.partial = workspace;
+  a.B = batch; a.cells = gh * gw; a.K = apg; a.C = classes;
+  a.w1 = img_w - 1.0f; a.h1 = img_h - 1.0f; a.thr = exp_thresh; a.slope = (float)exp((double)exp_thresh); a.eps = epsilon;
+  a.coef_class = coef_class; a.coef_pos = coef_conf_pos; a.coef_neg = coef_conf_neg; a.coef_bbox = coef_bbox;
+  a.num_obj = num_objects;
+  const long total = (long)batch * gh * gw * apg;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 512) blocks = 512;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(loss_kernel, dim3(blocks), dim3(256), 0, st, a);
+  SQDET_CHECK_HIP(hipGetLastError());
+  // losses3[j] = sum over blocks of partial[b][j], fixed order; partial is [blocks][4] -> treat as 4 x strided slabs
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, st, workspace, workspace + 4 * 512, (const float*)nullptr, 0.f,
+                     (size_t)4, blocks);
+  SQDET_CHECK_HIP(hipGetLastError());
+  SQDET_CHECK_HIP(hipMemcpyAsync(losses3, workspace + 4 * 512, 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return SQDET_OK;
+}
+
+extern "C" size_t sqdet_loss_workspace_bytes(void) { return (4 * 512 + 4) * sizeof(float); }
+
+// ---- optimizer: host-side segment table lives in a small opaque object ----
+struct sqdet_optimizer {
+  std::vector<OptSeg> segs;
+  std::vector<int> block_seg;
+  int nblocks = 0;
+};
+
+extern "C" int sqdet_optimizer_create(sqdet_optimizer** out, const long* offsets, const long* counts, const float* decays,
+                                      int nvars) {
+  SQDET_REQUIRE(out && offsets && counts && decays && nvars > 0, "optimizer_create: bad arguments");
+  sqdet_optimizer* o = new sqdet_optimizer();
+  for (int v = 0; v < nvars; ++v) {
+    OptSeg s;
+    s.off = offsets[v]; s.count = counts[v]; s.decay = decays[v];
+    long nb = (counts[v] + 256 * 8 - 1) / (256 * 8);
+    if (nb < 1) nb = 1;
+    if (nb > 64) nb = 64;
+    s.first_block = o->nblocks; s.nblocks = (int)nb;
+    o->nblocks += (int)nb;
+    for (long b = 0; b < nb; ++b) o->block_seg.push_back(v);
+    o->segs.push_back(s);
+  }
+  *out = o;
+  return SQDET_OK;
+}
+
+extern "C" void sqdet_optimizer_destroy(sqdet_optimizer* o) { delete o; }
+
+extern "C" size_t sqdet_optimizer_workspace_bytes(const sqdet_optimizer* o) {
+  if (!o) return 0;
+  // segs | block_seg | partial (double) | scale
+  size_t b = o->segs.size() * sizeof(OptSeg);
+  b = (b + 255) / 256 * 256 + o->block_seg.size() * sizeof(int);
+  b = (b + 255) / 256 * 256 + (size_t)o->nblocks * sizeof(double);
+  b = (b + 255) / 256 * 256 + o->segs.size() * sizeof(float);
+  return b + 256;
+}
+
+extern "C" int sqdet_optimizer_step(sqdet_optimizer* o, float* params, float* grads, float* accum, void* workspace,
+                                    float lr, float momentum, float max_grad_norm, sqdet_stream_t stream) {
+  SQDET_REQUIRE(o && params && grads && accum && workspace, "optimizer_step: null pointer");
+  hipStream_t st = as_stream(stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  size_t off = 0;
+  OptSeg* d_segs = reinterpret_cast<OptSeg*>(ws + off);
+  off = (off + o->segs.size() * sizeof(OptSeg) + 255) / 256 * 256;
+  int* d_bs = reinterpret_cast<int*>(ws + off);
+  off = (off + o->block_seg.size() * sizeof(int) + 255) / 256 * 256;
+  double* d_part = reinterpret_cast<double*>(ws + off);
+  off = (off + (size_t)o->nblocks * sizeof(double) + 255) / 256 * 256;
+  float* d_scale = reinterpret_cast<float*>(ws + off);
+  SQDET_CHECK_HIP(hipMemcpyAsync(d_segs, o->segs.data(), o->segs.size() * sizeof(OptSeg), hipMemcpyHostToDevice, st));
+  SQDET_CHECK_HIP(hipMemcpyAsync(d_bs, o->block_seg.data(), o->block_seg.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(opt_sumsq_kernel, dim3(o->nblocks), dim3(256), 0, st, d_segs, d_bs, params, grads, d_part);
+  SQDET_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(opt_norm_kernel, dim3(1), dim3(256), 0, st, d_segs, d_part, d_scale, (int)o->segs.size(), max_grad_norm);
+  SQDET_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(opt_apply_kernel, dim3(o->nblocks), dim3(256), 0, st, d_segs, d_bs, params, grads, accum, d_scale, lr,
+                     momentum);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}

@@ -159,6 +159,121 @@ def filter_prediction(boxes, probs, cls, classes, top_n, nms_thresh, prob_thresh
     return ob, op, oc, oi, cnt
 
 
+# ---------------------------------------------------------------- training (float32)
+class PackedConvBwd:
+    """rot180(W)^T in fragment order: the kernel of the backward-data conv (sqdet_conv_pack_weights_bwd_data)."""
+
+    def __init__(self, w_hwio, dtype=torch.float32):
+        w = w_hwio.detach().to(torch.float32).contiguous()
+        self.k, _, self.cin, self.cout = [int(v) for v in w.shape]
+        self.dtype = dtype
+        code = dtype_code(dtype)
+        nbytes = lib().sqdet_conv_packed_bytes(self.k, self.cout, self.cin, code)
+        self.data = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        check(lib().sqdet_conv_pack_weights_bwd_data(_dev(w, "w_hwio"), _dev(self.data, "packed"), self.k, self.cin,
+                                                     self.cout, code, stream_ptr()), "sqdet_conv_pack_weights_bwd_data")
+
+
+def conv2d_bwd_data(dy, packed_bwd, dx=None, dy_coffset=0, accumulate=False):
+    """dx = conv(dy[..., dy_coffset:dy_coffset+cout], rot180(W)^T) (stride-1 SAME convs).  dy [N,H,W,Ctot]."""
+    n, h, w, ctot = [int(v) for v in dy.shape]
+    if dx is None:
+        dx = torch.empty((n, h, w, packed_bwd.cin), dtype=dy.dtype, device=dy.device)
+        accumulate = False
+    check(lib().sqdet_conv2d_nhwc_bwd_data(_dev(dy, "dy"), _dev(packed_bwd.data, "packed"), _dev(dx, "dx"), n, h, w,
+                                           packed_bwd.cin, packed_bwd.cout, packed_bwd.k, dtype_code(dy.dtype), ctot,
+                                           int(dy_coffset), int(bool(accumulate)), stream_ptr()), "sqdet_conv2d_nhwc_bwd_data")
+    return dx
+
+
+def conv2d_bwd_filter(x, dy, k, cin, cout, w_for_decay=None, weight_decay=0.0, x_coffset=0, dy_coffset=0, want_bias=True,
+                      dw=None, db=None):
+    """dW [k,k,cin,cout] float32 HWIO (+ weight_decay*W), dbias [cout].  x [N,H,W,Cx], dy [N,H,W,Cy] float32;
+    the conv's input / output are the channel slices [x_coffset,+cin) / [dy_coffset,+cout)."""
+    n, h, w, cx = [int(v) for v in x.shape]
+    cy = int(dy.shape[3])
+    dev = x.device
+    if dw is None:
+        dw = torch.empty((k, k, cin, cout), dtype=torch.float32, device=dev)
+    if db is None and want_bias:
+        db = torch.empty((cout,), dtype=torch.float32, device=dev)
+    ws = torch.empty(int(lib().sqdet_conv2d_bwd_filter_workspace_bytes(n, h, w, cin, cout, k)) // 4 + 64, dtype=torch.float32, device=dev)
+    check(lib().sqdet_conv2d_nhwc_bwd_filter(_dev(x, "x", torch.float32), _dev(dy, "dy", torch.float32), _dev(dw, "dw"),
+                                             _dev(db, "db") if db is not None else None,
+                                             _dev(w_for_decay, "w", torch.float32) if w_for_decay is not None else None,
+                                             float(weight_decay), _dev(ws, "ws"), n, h, w, int(cin), int(cout), int(k), cx,
+                                             int(x_coffset), cy, int(dy_coffset), stream_ptr()), "sqdet_conv2d_nhwc_bwd_filter")
+    return dw, db
+
+
+def relu_bwd(y, dy):
+    """In place: dy *= (y > 0)."""
+    check(lib().sqdet_relu_bwd(_dev(y, "y", torch.float32), _dev(dy, "dy", torch.float32), y.numel(), stream_ptr()), "sqdet_relu_bwd")
+    return dy
+
+
+def scale_mask(x, mask, scale):
+    y = torch.empty_like(x)
+    check(lib().sqdet_scale_mask(_dev(x, "x", torch.float32), _dev(mask, "mask", torch.float32), _dev(y, "y"), float(scale),
+                                 x.numel(), stream_ptr()), "sqdet_scale_mask")
+    return y
+
+
+def maxpool_bwd(x, dy, size, stride, padding="SAME"):
+    n, h, w, c = [int(v) for v in x.shape]
+    dx = torch.empty_like(x)
+    check(lib().sqdet_maxpool_nhwc_bwd(_dev(x, "x", torch.float32), _dev(dy, "dy", torch.float32), _dev(dx, "dx"), n, h, w, c,
+                                       int(size), int(stride), pad_code(padding), stream_ptr()), "sqdet_maxpool_nhwc_bwd")
+    return dx
+
+
+def loss_fwd_bwd(preds, anchors_f32, input_mask, box_delta_input, box_input, labels, mc, num_objects):
+    """ModelSkeleton._add_loss_graph forward + backward (nn_skeleton.py:285-327).  All tensors float32 on
+    the device.  Returns (dpreds, ious [B,A], losses [3] = class, conf, bbox)."""
+    n, gh, gw, ch = [int(v) for v in preds.shape]
+    A = gh * gw * mc.ANCHOR_PER_GRID
+    dev = preds.device
+    dpreds = torch.empty_like(preds)
+    ious = torch.empty((n, A), dtype=torch.float32, device=dev)
+    losses = torch.empty((3,), dtype=torch.float32, device=dev)
+    ws = torch.empty(int(lib().sqdet_loss_workspace_bytes()) // 4 + 16, dtype=torch.float32, device=dev)
+    check(lib().sqdet_loss_fwd_bwd(_dev(preds, "preds", torch.float32), _dev(anchors_f32, "anchors", torch.float32),
+                                   _dev(input_mask, "mask", torch.float32), _dev(box_delta_input, "delta", torch.float32),
+                                   _dev(box_input, "box", torch.float32), _dev(labels, "labels", torch.float32),
+                                   _dev(dpreds, "dpreds"), _dev(ious, "ious"), _dev(losses, "losses"), _dev(ws, "ws"),
+                                   n, gh, gw, int(mc.ANCHOR_PER_GRID), int(mc.CLASSES), float(mc.IMAGE_WIDTH),
+                                   float(mc.IMAGE_HEIGHT), float(mc.EXP_THRESH), float(mc.EPSILON), float(mc.LOSS_COEF_CLASS),
+                                   float(mc.LOSS_COEF_CONF_POS), float(mc.LOSS_COEF_CONF_NEG), float(mc.LOSS_COEF_BBOX),
+                                   float(num_objects), stream_ptr()), "sqdet_loss_fwd_bwd")
+    return dpreds, ious, losses
+
+
+class MomentumOptimizer:
+    """sqdet_optimizer_*: Momentum + per-variable clip_by_norm (+ weight decay) over flat buffers."""
+
+    def __init__(self, offsets, counts, decays, device):
+        nv = len(offsets)
+        self._h = C.c_void_p()
+        off = (C.c_long * nv)(*[int(v) for v in offsets])
+        cnt = (C.c_long * nv)(*[int(v) for v in counts])
+        dec = (C.c_float * nv)(*[float(v) for v in decays])
+        check(lib().sqdet_optimizer_create(C.byref(self._h), off, cnt, dec, nv), "sqdet_optimizer_create")
+        self.ws = torch.empty(int(lib().sqdet_optimizer_workspace_bytes(self._h)) + 256, dtype=torch.uint8, device=device)
+
+    def step(self, params, grads, accum, lr, momentum, max_grad_norm):
+        check(lib().sqdet_optimizer_step(self._h, _dev(params, "params", torch.float32), _dev(grads, "grads", torch.float32),
+                                         _dev(accum, "accum", torch.float32), _dev(self.ws, "ws"), float(lr), float(momentum),
+                                         float(max_grad_norm), stream_ptr()), "sqdet_optimizer_step")
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().sqdet_optimizer_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 def set_option(name, value):
     """Process-wide tuning knob (sqdet_set_option), e.g. set_option("conv_algo", 1) = generic kernels only."""
     check(lib().sqdet_set_option(name.encode(), int(value)), "sqdet_set_option")

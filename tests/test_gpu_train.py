@@ -1,0 +1,151 @@
+"""GPU parity tests of the TRAINING path (float32): every backward / loss / optimizer kernel against
+PyTorch-CPU autograd on the restated graph (oracle/train_oracle.py; parity unpinned against TF --
+see that module's header), then one whole training step.
+
+Tolerances: gradients are sums of up to ~1e5 float32 products evaluated in a different order than
+the CPU's, so they are compared at 2e-4 relative to the tensor's max (north_star: 1e-3 rel)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sqdet_oracle as O
+from oracle import train_oracle as TO
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ops():
+    from squeezedet_amd import ops
+    return ops
+
+
+def _close(got, ref, rel=2e-4, what=""):
+    got = got.detach().float().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    ref = ref.detach().float().cpu().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
+    assert got.shape == ref.shape, what
+    scale = max(np.abs(ref).max(), 1e-12)
+    err = np.abs(got - ref).max()
+    assert err <= rel * scale + 1e-7, "%s: max err %g vs scale %g" % (what, err, scale)
+
+
+def _conv_ref(x, w, stride=1):
+    k = w.shape[0]
+    pad = (k - 1) // 2
+    return F.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), None, stride=stride, padding=pad).permute(0, 2, 3, 1)
+
+
+BWD_CASES = [("e1_16_64", 2, 23, 31, 16, 64, 1), ("e3_16_64", 2, 23, 31, 16, 64, 3), ("sq_128_32", 1, 12, 39, 128, 32, 1),
+             ("e3_48_192", 1, 12, 20, 48, 192, 3), ("sq_768_96", 1, 9, 14, 768, 96, 1), ("e3_96_384", 1, 9, 14, 96, 384, 3),
+             ("convdet_768_72", 2, 7, 13, 768, 72, 3), ("e1_32_128_large", 2, 47, 63, 32, 128, 1)]
+
+
+@pytest.mark.parametrize("case", BWD_CASES, ids=[c[0] for c in BWD_CASES])
+def test_conv_backward_data_and_filter(case):
+    ops = _ops()
+    name, N, H, W, cin, cout, k = case
+    rs = np.random.RandomState(len(name) * 7 + cin)
+    x = torch.from_numpy(rs.randn(N, H, W, cin).astype(np.float32)).requires_grad_(True)
+    w = torch.from_numpy((rs.randn(k, k, cin, cout) * (2.0 / (k * k * cin)) ** 0.5).astype(np.float32)).requires_grad_(True)
+    b = torch.zeros(cout, requires_grad=True)
+    dy = torch.from_numpy(rs.randn(N, H, W, cout).astype(np.float32))
+    y = _conv_ref(x, w) + b
+    y.backward(dy)
+    dxg = ops.conv2d_bwd_data(dy.to(DEV), ops.PackedConvBwd(w.detach().to(DEV)))
+    wd = 1e-4
+    dwg, dbg = ops.conv2d_bwd_filter(x.detach().to(DEV), dy.to(DEV), k, cin, cout, w_for_decay=w.detach().to(DEV), weight_decay=wd)
+    torch.cuda.synchronize()
+    _close(dxg, x.grad, what=name + " dx")
+    _close(dwg, w.grad + wd * w.detach(), what=name + " dW")
+    _close(dbg, b.grad, what=name + " dbias")
+
+
+def test_fire_backward_channel_slices_and_accumulate():
+    """A fire module's backward: dY is the concat gradient; expand1x1 / expand3x3 read its two channel
+    ranges, and the squeeze tensor's gradient is the SUM of their backward-data results."""
+    ops = _ops()
+    rs = np.random.RandomState(2)
+    N, H, W, s, e = 2, 13, 21, 32, 128
+    S = torch.from_numpy(np.maximum(rs.randn(N, H, W, s), 0).astype(np.float32)).requires_grad_(True)
+    w1 = torch.from_numpy((rs.randn(1, 1, s, e) * 0.2).astype(np.float32)).requires_grad_(True)
+    w3 = torch.from_numpy((rs.randn(3, 3, s, e) * 0.08).astype(np.float32)).requires_grad_(True)
+    dY = torch.from_numpy(rs.randn(N, H, W, 2 * e).astype(np.float32))
+    Y = torch.cat([_conv_ref(S, w1), _conv_ref(S, w3)], dim=3)
+    Y.backward(dY)
+    dYd, Sd = dY.to(DEV), S.detach().to(DEV)
+    dS = ops.conv2d_bwd_data(dYd, ops.PackedConvBwd(w1.detach().to(DEV)), dy_coffset=0)
+    ops.conv2d_bwd_data(dYd, ops.PackedConvBwd(w3.detach().to(DEV)), dx=dS, dy_coffset=e, accumulate=True)
+    dw1, _ = ops.conv2d_bwd_filter(Sd, dYd, 1, s, e, dy_coffset=0)
+    dw3, _ = ops.conv2d_bwd_filter(Sd, dYd, 3, s, e, dy_coffset=e)
+    torch.cuda.synchronize()
+    _close(dS, S.grad, what="dS")
+    _close(dw1, w1.grad, what="dW1")
+    _close(dw3, w3.grad, what="dW3")
+
+
+def test_relu_dropout_maxpool_backward():
+    ops = _ops()
+    rs = np.random.RandomState(3)
+    y = torch.from_numpy(np.maximum(rs.randn(2, 9, 11, 16), 0).astype(np.float32))
+    dy = torch.from_numpy(rs.randn(2, 9, 11, 16).astype(np.float32))
+    got = ops.relu_bwd(y.to(DEV), dy.to(DEV).clone())
+    np.testing.assert_array_equal(got.cpu().numpy(), (dy * (y > 0)).numpy())
+    m = torch.from_numpy((rs.uniform(size=(2, 9, 11, 16)) < 0.5).astype(np.float32))
+    np.testing.assert_array_equal(ops.scale_mask(dy.to(DEV), m.to(DEV), 2.0).cpu().numpy(), (dy * m * 2.0).numpy())
+    for (H, W, pad) in ((47, 156, "SAME"), (94, 311, "SAME"), (20, 31, "VALID")):
+        x = torch.from_numpy(rs.randn(1, H, W, 8).astype(np.float32)).requires_grad_(True)   # distinct values: unique argmax
+        yp = O.pooling_layer(x, 3, 2, pad)
+        g = torch.from_numpy(rs.randn(*yp.shape).astype(np.float32))
+        yp.backward(g)
+        dx = ops.maxpool_bwd(x.detach().to(DEV), g.to(DEV), 3, 2, pad)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(dx.cpu().numpy(), x.grad.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_loss_forward_backward_vs_oracle():
+    ops = _ops()
+    mc = O.squeezeDet_config_for_input(128, 256)
+    B = 3
+    rs = np.random.RandomState(5)
+    gh, gw = O.squeezedet_grid(128, 256)
+    preds = torch.from_numpy((rs.randn(B, gh, gw, 72) * 1.2).astype(np.float32)).requires_grad_(True)
+    mask, delta, box, labels = TO.synthetic_labels(mc, B, seed=6)
+    parts = TO.loss_graph(mc, preds, mask, delta, box, labels)
+    total = parts["class_loss"] + parts["conf_loss"] + parts["bbox_loss"]
+    (dref,) = torch.autograd.grad(total, preds)
+    anchors = torch.from_numpy(mc.ANCHOR_BOX.astype(np.float32)).to(DEV)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    dp, ious, losses = ops.loss_fwd_bwd(preds.detach().to(DEV), anchors, t(mask.reshape(B, -1)), t(delta), t(box), t(labels), mc,
+                                        float(mask.sum()))
+    torch.cuda.synchronize()
+    ls = losses.cpu().numpy()
+    np.testing.assert_allclose(ls, [float(parts["class_loss"]), float(parts["conf_loss"]), float(parts["bbox_loss"])], rtol=2e-5)
+    np.testing.assert_allclose(ious.cpu().numpy(), parts["ious"].numpy(), rtol=1e-5, atol=1e-6)
+    _close(dp, dref, rel=5e-5, what="dpreds")
+
+
+def test_momentum_clip_optimizer_vs_oracle():
+    ops = _ops()
+    mc = O.kitti_squeezeDet_config()
+    rs = np.random.RandomState(8)
+    shapes = {"a/kernels": (3, 3, 16, 64), "a/biases": (64,), "b/kernels": (1, 1, 64, 16), "b/biases": (16,), "c/kernels": (3, 3, 96, 384)}
+    params = {k: torch.from_numpy(rs.randn(*s).astype(np.float32) * 0.1) for k, s in shapes.items()}
+    grads = {k: torch.from_numpy(rs.randn(*s).astype(np.float32) * (5.0 if "a/" in k else 0.01)) for k, s in shapes.items()}
+    mom = {k: torch.from_numpy(rs.randn(*s).astype(np.float32) * 0.01) for k, s in shapes.items()}
+    # oracle: weight decay is part of the gradient (TF differentiates the total loss), then clip, then momentum
+    g_ref = {k: g + (mc.WEIGHT_DECAY * params[k] if k.endswith("kernels") else 0) for k, g in grads.items()}
+    p_ref, m_ref = TO.apply_gradients(mc, params, mom, g_ref, step=20000)
+    offs, cnts, decs, o = [], [], [], 0
+    for k, s in shapes.items():
+        offs.append(o); cnts.append(int(np.prod(s))); decs.append(mc.WEIGHT_DECAY if k.endswith("kernels") else 0.0)
+        o += (cnts[-1] + 63) // 64 * 64
+    flat = lambda d: torch.cat([F.pad(d[k].reshape(-1), (0, (c + 63) // 64 * 64 - c)) for k, c in zip(shapes, cnts)]).to(DEV)
+    P, G, M = flat(params), flat(grads), flat(mom)
+    opt = ops.MomentumOptimizer(offs, cnts, decs, DEV)
+    opt.step(P, G, M, TO.learning_rate(mc, 20000), mc.MOMENTUM, mc.MAX_GRAD_NORM)
+    torch.cuda.synchronize()
+    assert TO.learning_rate(mc, 20000) == 0.01 * 0.25
+    for k, off, c in zip(shapes, offs, cnts):
+        _close(P[off:off + c].reshape(shapes[k]), p_ref[k], rel=1e-6, what=k + " param")
+        _close(M[off:off + c].reshape(shapes[k]), m_ref[k], rel=1e-6, what=k + " momentum")
