@@ -173,7 +173,7 @@ int sqdet_loss_fwd_bwd(const float* preds, const float* anchors, const float* in
 
 /* Momentum + per-variable clip_by_norm over flat parameter / gradient / momentum buffers.
  * Variable v = elements [offsets[v], +counts[v]); decays[v] = weight decay added to its gradient
- * BEFORE clipping (0 for biases).  step: g += decay*w; g *= max_norm/max(||g||,max_norm);
+ * BEFORE clipping (0 for biases).  step: g = g*grad_scale (1/world_size after a SUM all-reduce) + decay*w; g *= max_norm/max(||g||,max_norm);
  * accum = momentum*accum + g; w -= lr*accum.  Deterministic (fixed-order norm reduction), so
  * data-parallel replicas stay bit-identical. */
 typedef struct sqdet_optimizer sqdet_optimizer_t;
@@ -182,7 +182,7 @@ int sqdet_optimizer_create(sqdet_optimizer_t** out, const long* offsets, const l
 void sqdet_optimizer_destroy(sqdet_optimizer_t* opt);
 size_t sqdet_optimizer_workspace_bytes(const sqdet_optimizer_t* opt);
 int sqdet_optimizer_step(sqdet_optimizer_t* opt, float* params, float* grads, float* accum, void* workspace, float lr,
-                         float momentum, float max_grad_norm, sqdet_stream_t stream);
+                         float momentum, float max_grad_norm, float grad_scale, sqdet_stream_t stream);
 
 /* ------------------------------------------------------------- network --
  * Replaces SqueezeDet.__init__/_add_forward_graph (nets/squeezeDet.py:19-79,

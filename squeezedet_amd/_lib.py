@@ -41,7 +41,7 @@ SIGNATURES = {
     "sqdet_optimizer_create": (ci, [C.POINTER(vp), C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(cf), ci]),
     "sqdet_optimizer_destroy": (None, [vp]),
     "sqdet_optimizer_workspace_bytes": (sz, [vp]),
-    "sqdet_optimizer_step": (ci, [vp, vp, vp, vp, vp, cf, cf, cf, vp]),
+    "sqdet_optimizer_step": (ci, [vp, vp, vp, vp, vp, cf, cf, cf, cf, vp]),
     "sqdet_net_create": (ci, [C.POINTER(vp), ci, ci, ci, ci, ci, ci, ci]),
     "sqdet_net_destroy": (None, [vp]),
     "sqdet_net_num_params": (ci, [vp]),

@@ -266,7 +266,8 @@ int conv2d_launch_ex(const void* x, const void* w_packed, const float* bias, voi
                      int x_cstride, int x_coffset, int accum, hipStream_t st) {
   SQDET_REQUIRE(x && w_packed && y, "conv2d: null pointer");  // bias == NULL means no bias (generic kernel)
   const int kg_ = dtype == SQDET_F16 ? 8 : 4;
-  SQDET_UNSUPPORTED(x_cstride % kg_ != 0 || x_coffset % kg_ != 0 || x_coffset < 0 || x_coffset + cin > x_cstride,
+  SQDET_UNSUPPORTED((x_cstride != cin || x_coffset != 0) &&
+                        (x_cstride % kg_ != 0 || x_coffset % kg_ != 0 || x_coffset < 0 || x_coffset + cin > x_cstride),
                     "conv2d: x_cstride %d / x_coffset %d must be multiples of %d with coffset+cin <= cstride",
                     x_cstride, x_coffset, kg_);
   SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "conv2d: bad dtype %d", dtype);

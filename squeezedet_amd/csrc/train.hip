@@ -338,15 +338,16 @@ struct OptSeg { long off; long count; float decay; int first_block; int nblocks;
 
 __global__ __launch_bounds__(256) void opt_sumsq_kernel(const OptSeg* __restrict__ segs, const int* __restrict__ block_seg,
                                                         const float* __restrict__ w, float* __restrict__ g,
-                                                        double* __restrict__ partial) {
+                                                        double* __restrict__ partial, float grad_scale) {
   __shared__ double red[256];
   const int v = block_seg[blockIdx.x];
   const OptSeg s = segs[v];
   const int lb = blockIdx.x - s.first_block;
   double acc = 0.0;
   for (long i = (long)lb * 256 + threadIdx.x; i < s.count; i += (long)s.nblocks * 256) {
-    float gi = g[s.off + i];
-    if (s.decay != 0.f) { gi = gi + s.decay * w[s.off + i]; g[s.off + i] = gi; }
+    float gi = g[s.off + i] * grad_scale;   // grad_scale = 1/world_size after a SUM all-reduce
+    if (s.decay != 0.f) gi = gi + s.decay * w[s.off + i];
+    g[s.off + i] = gi;
     acc += (double)gi * (double)gi;
   }
   red[threadIdx.x] = acc;
@@ -579,7 +580,8 @@ extern "C" size_t sqdet_optimizer_workspace_bytes(const sqdet_optimizer* o) {
 }
 
 extern "C" int sqdet_optimizer_step(sqdet_optimizer* o, float* params, float* grads, float* accum, void* workspace,
-                                    float lr, float momentum, float max_grad_norm, sqdet_stream_t stream) {
+                                    float lr, float momentum, float max_grad_norm, float grad_scale,
+                                    sqdet_stream_t stream) {
   SQDET_REQUIRE(o && params && grads && accum && workspace, "optimizer_step: null pointer");
   hipStream_t st = as_stream(stream);
   char* ws = reinterpret_cast<char*>(workspace);
@@ -593,7 +595,7 @@ extern "C" int sqdet_optimizer_step(sqdet_optimizer* o, float* params, float* gr
   float* d_scale = reinterpret_cast<float*>(ws + off);
   SQDET_CHECK_HIP(hipMemcpyAsync(d_segs, o->segs.data(), o->segs.size() * sizeof(OptSeg), hipMemcpyHostToDevice, st));
   SQDET_CHECK_HIP(hipMemcpyAsync(d_bs, o->block_seg.data(), o->block_seg.size() * sizeof(int), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(opt_sumsq_kernel, dim3(o->nblocks), dim3(256), 0, st, d_segs, d_bs, params, grads, d_part);
+  hipLaunchKernelGGL(opt_sumsq_kernel, dim3(o->nblocks), dim3(256), 0, st, d_segs, d_bs, params, grads, d_part, grad_scale);
   SQDET_CHECK_HIP(hipGetLastError());
   hipLaunchKernelGGL(opt_norm_kernel, dim3(1), dim3(256), 0, st, d_segs, d_part, d_scale, (int)o->segs.size(), max_grad_norm);
   SQDET_CHECK_HIP(hipGetLastError());

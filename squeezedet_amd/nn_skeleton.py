@@ -164,9 +164,10 @@ class ModelSkeleton:
 
     def _dropout(self, inputs, keep_prob, name=None):
         """tf.nn.dropout (nets/squeezeDet.py:74); identity at inference (keep_prob == 1.0)."""
-        if keep_prob != 1.0:
-            raise SqdetError("training-mode dropout is not part of the inference hot path")
-        return inputs
+        if keep_prob == 1.0:
+            return inputs
+        # training graph (mc.IS_TRAINING): x * floor(keep_prob + U) / keep_prob, float32 only
+        return Node(self, "dropout", [inputs], inputs.get_shape(), name, keep_prob=keep_prob)
 
     # ------------------------------------------------------------------ interpretation
     def _add_interpretation_graph(self):
@@ -240,7 +241,7 @@ class ModelSkeleton:
         mc = self.mc
         if node.op == "placeholder":
             raise SqdetError("placeholder %s was not fed" % node.name)
-        if use_plan and node is self.preds and self.NATIVE_ARCH is not None:
+        if use_plan and node is self.preds and self.NATIVE_ARCH is not None and self.keep_prob == 1.0:
             x = self._eval(self.image_input, env, use_plan)
             v = self._native_plan(int(x.shape[0])).forward(x)
         elif node.op == "conv":
@@ -263,6 +264,11 @@ class ModelSkeleton:
                     off += i.shape[3]
             else:
                 v = torch.cat([self._eval(i, env, use_plan) for i in node.inputs], dim=3).contiguous()
+        elif node.op == "dropout":
+            x = self._eval(node.inputs[0], env, use_plan)
+            kp = node.attrs["keep_prob"]
+            dmask = torch.floor(kp + torch.rand(x.shape, device=x.device))
+            v = ops.scale_mask(x.float().contiguous(), dmask, 1.0 / kp).to(x.dtype)
         elif node.op == "interpret":
             preds = self._eval(node.inputs[0], env, use_plan)
             v = ops.interpret_output(preds, self.anchors_f32(), mc.CLASSES, mc.ANCHOR_PER_GRID, mc.IMAGE_WIDTH,

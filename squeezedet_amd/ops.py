@@ -260,10 +260,10 @@ class MomentumOptimizer:
         check(lib().sqdet_optimizer_create(C.byref(self._h), off, cnt, dec, nv), "sqdet_optimizer_create")
         self.ws = torch.empty(int(lib().sqdet_optimizer_workspace_bytes(self._h)) + 256, dtype=torch.uint8, device=device)
 
-    def step(self, params, grads, accum, lr, momentum, max_grad_norm):
+    def step(self, params, grads, accum, lr, momentum, max_grad_norm, grad_scale=1.0):
         check(lib().sqdet_optimizer_step(self._h, _dev(params, "params", torch.float32), _dev(grads, "grads", torch.float32),
                                          _dev(accum, "accum", torch.float32), _dev(self.ws, "ws"), float(lr), float(momentum),
-                                         float(max_grad_norm), stream_ptr()), "sqdet_optimizer_step")
+                                         float(max_grad_norm), float(grad_scale), stream_ptr()), "sqdet_optimizer_step")
 
     def __del__(self):
         try:

@@ -1,0 +1,195 @@
+"""Training step of SqueezeDet on MI355X: forward (training mode) -> loss -> backward -> gradient
+all-reduce -> clipped Momentum update, every arithmetic step a HIP kernel of libsqdet_hip.so.
+Mirrors the reference's train graph (src/nn_skeleton.py:285-361: _add_loss_graph,
+_add_train_graph) and the training loop body of src/train.py:302-304
+(`sess.run([train_op, loss, conf_loss, bbox_loss, class_loss])`).
+
+Data parallelism: one process per GPU, replicas hold full weights, ONE flat float32
+gradient bucket all-reduced (SUM) per step over RCCL (torch.distributed backend "nccl"), divided by
+the world size inside the optimizer kernel, then per-variable clip_by_norm and Momentum -- applied
+identically (and deterministically) on every rank, so replicas stay bit-identical.  Loss
+normalisation is "replica-mean": each replica normalises by its own num_objects (the reference at
+its own batch size), gradients are averaged.
+"""
+import collections
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import SqdetError
+
+
+class SqueezeDetTrainer:
+    """model: a squeezedet_amd.nets.SqueezeDet built with mc.IS_TRAINING = True and dtype float32."""
+
+    def __init__(self, model, process_group=None):
+        if model.dtype != torch.float32:
+            raise SqdetError("training runs in float32 (the reference's training dtype)")
+        if not model.has_device:
+            raise SqdetError("squeezedet_amd needs a HIP device: there is no CPU path")
+        self.model, self.mc, self.dev = model, model.mc, model.device
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self.global_step = 0
+        # trainable variables (conv1 is frozen: nets/squeezeDet.py:40-42) packed into flat buffers
+        self.names = [n for n in model.params if model.trainable[n]]
+        offs, cnts, decs, o = [], [], [], 0
+        for n in self.names:
+            c = model.params[n].numel()
+            offs.append(o)
+            cnts.append(c)
+            decs.append(self.mc.WEIGHT_DECAY if n.endswith("/kernels") else 0.0)   # nn_skeleton.py:66-69
+            o += (c + 63) // 64 * 64
+        self.total = o
+        self.flat_params = torch.zeros(o, dtype=torch.float32, device=self.dev)
+        self.flat_grads = torch.zeros(o, dtype=torch.float32, device=self.dev)
+        self.flat_accum = torch.zeros(o, dtype=torch.float32, device=self.dev)
+        self.view, self.gview = {}, {}
+        for n, off, c in zip(self.names, offs, cnts):
+            shp = tuple(model.params[n].shape)
+            self.view[n] = self.flat_params[off:off + c].view(shp)
+            self.view[n].copy_(model.params[n])
+            model.params[n] = self.view[n]           # the model now reads the flat buffer
+            self.gview[n] = self.flat_grads[off:off + c].view(shp)
+        model._packed.clear()
+        model._plan_stale = True
+        self.opt = ops.MomentumOptimizer(offs, cnts, decs, self.dev)
+        self.layers = self._layer_list()
+
+    # ---- the forward graph as a list (nets/squeezeDet.py:30-79) ----
+    def _layer_list(self):
+        m = self.model
+        seq, node = [], m.preds
+        chain = []
+        # walk back from preds through the graph
+        def walk(n):
+            if n.op == "placeholder":
+                return
+            walk(n.inputs[0] if n.op != "concat" else n.inputs[0].inputs[0].inputs[0])
+            chain.append(n)
+        walk(node)
+        for n in chain:
+            if n.op == "concat":
+                e1, e3 = n.inputs
+                seq.append(("fire", n.name.split("/")[0], e1.inputs[0], e1, e3))
+            elif n.op == "conv":
+                seq.append(("conv", n.name, n))
+            elif n.op == "pool":
+                seq.append(("pool", n.name, n))
+        return seq
+
+    def _pack(self, name):
+        return ops.pack_conv_weights(self.model.params[name + "/kernels"], torch.float32)
+
+    def learning_rate(self):
+        mc = self.mc
+        return mc.LEARNING_RATE * mc.LR_DECAY_FACTOR ** (self.global_step // mc.DECAY_STEPS)   # staircase decay
+
+    def step(self, images, input_mask, box_delta_input, box_input, labels, dropout_mask=None, apply_update=True):
+        """One training step.  images [B,H,W,3]; input_mask [B,A] or [B,A,1]; box_delta_input / box_input
+        [B,A,4]; labels [B,A,C] (the reference's placeholders, nn_skeleton.py:81-97).  Returns a dict
+        with loss, class_loss, conf_loss, bbox_loss (device scalars)."""
+        m, mc, P = self.model, self.mc, self.model.params
+        x = m._to_input(images)
+        B = int(x.shape[0])
+        t = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))).to(self.dev, torch.float32).contiguous()
+        mask = t(input_mask).reshape(B, -1)
+        delta, box, lab = t(box_delta_input), t(box_input), t(labels)
+        num_objects = float(mask.sum().item())
+        keep = m.keep_prob
+        # ---------------- forward, keeping what the backward needs ----------------
+        saved = []
+        cur = x
+        drop_in = None
+        for item in self.layers:
+            if item[0] == "conv":
+                node = item[2]
+                if node.name == "conv12":
+                    drop_in = cur
+                    if dropout_mask is None:
+                        dropout_mask = torch.floor(keep + torch.rand(cur.shape, device=self.dev))   # tf.nn.dropout's mask
+                    dm = t(dropout_mask)
+                    cur = ops.scale_mask(cur, dm, 1.0 / keep) if keep != 1.0 else cur
+                y = ops.conv2d_nhwc(cur, self._pack(node.name), P[node.name + "/biases"], node.attrs["stride"],
+                                    node.attrs["padding"], node.attrs["relu"])
+                saved.append(("conv", node, cur, y))
+                cur = y
+            elif item[0] == "pool":
+                node = item[2]
+                y = ops.maxpool_nhwc(cur, node.attrs["size"], node.attrs["stride"], node.attrs["padding"])
+                saved.append(("pool", node, cur, y))
+                cur = y
+            else:
+                _, fname, sq, e1, e3 = item
+                s = ops.conv2d_nhwc(cur, self._pack(sq.name), P[sq.name + "/biases"], 1, "SAME", True)
+                y = torch.empty((B, int(s.shape[1]), int(s.shape[2]), e1.shape[3] + e3.shape[3]), dtype=torch.float32, device=self.dev)
+                ops.conv2d_nhwc(s, self._pack(e1.name), P[e1.name + "/biases"], 1, "SAME", True, out=y, out_coffset=0)
+                ops.conv2d_nhwc(s, self._pack(e3.name), P[e3.name + "/biases"], 1, "SAME", True, out=y, out_coffset=e1.shape[3])
+                saved.append(("fire", (sq, e1, e3), cur, s, y))
+                cur = y
+        preds = cur
+        # ---------------- loss ----------------
+        dpreds, ious, losses = ops.loss_fwd_bwd(preds, m.anchors_f32(), mask, delta, box, lab, mc, num_objects)
+        # ---------------- backward ----------------
+        wd = mc.WEIGHT_DECAY
+        self.flat_grads.zero_()
+        g = dpreds                      # gradient w.r.t. the current layer's OUTPUT (pre-activation mask applied below)
+
+        def has_trainable(rec):
+            if rec[0] == "conv":
+                return m.trainable[rec[1].name + "/kernels"]
+            return rec[0] == "fire"
+        first_tr = min(i for i, r in enumerate(saved) if has_trainable(r))
+        for ri in range(len(saved) - 1, first_tr - 1, -1):
+            rec = saved[ri]
+            need_dx = ri > first_tr     # nothing trainable (and no image gradient) below the first trainable layer
+            if rec[0] == "conv":
+                _, node, xin, y = rec
+                name = node.name
+                if node.attrs["relu"]:
+                    ops.relu_bwd(y, g)
+                k = node.attrs["size"]
+                cin, cout = int(xin.shape[3]), int(y.shape[3])
+                ops.conv2d_bwd_filter(xin, g, k, cin, cout, dw=self.gview[name + "/kernels"], db=self.gview[name + "/biases"])
+                if need_dx:
+                    g = ops.conv2d_bwd_data(g, ops.PackedConvBwd(P[name + "/kernels"]))
+                    if name == "conv12" and keep != 1.0:
+                        g = ops.scale_mask(g, t(dropout_mask), 1.0 / keep)
+            elif rec[0] == "pool":
+                _, node, xin, y = rec
+                g = ops.maxpool_bwd(xin, g, node.attrs["size"], node.attrs["stride"], node.attrs["padding"])
+            else:
+                _, (sq, e1, e3), xin, s, y = rec
+                ne1, ne3, ns = e1.shape[3], e3.shape[3], sq.shape[3]
+                ops.relu_bwd(y, g)      # both expand convs end in ReLU
+                ops.conv2d_bwd_filter(s, g, 1, ns, ne1, dy_coffset=0, dw=self.gview[e1.name + "/kernels"], db=self.gview[e1.name + "/biases"])
+                ops.conv2d_bwd_filter(s, g, 3, ns, ne3, dy_coffset=ne1, dw=self.gview[e3.name + "/kernels"], db=self.gview[e3.name + "/biases"])
+                ds = ops.conv2d_bwd_data(g, ops.PackedConvBwd(P[e1.name + "/kernels"]), dy_coffset=0)
+                ops.conv2d_bwd_data(g, ops.PackedConvBwd(P[e3.name + "/kernels"]), dx=ds, dy_coffset=ne1, accumulate=True)
+                ops.relu_bwd(s, ds)
+                ops.conv2d_bwd_filter(xin, ds, 1, int(xin.shape[3]), ns, dw=self.gview[sq.name + "/kernels"], db=self.gview[sq.name + "/biases"])
+                if need_dx:
+                    g = ops.conv2d_bwd_data(ds, ops.PackedConvBwd(P[sq.name + "/kernels"]))
+        # ---------------- gradient all-reduce + update ----------------
+        if self.world > 1:
+            torch.distributed.all_reduce(self.flat_grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        if apply_update:
+            self.opt.step(self.flat_params, self.flat_grads, self.flat_accum, self.learning_rate(), mc.MOMENTUM,
+                          mc.MAX_GRAD_NORM, 1.0 / self.world)
+            self.global_step += 1
+            m._packed.clear()
+            m._plan_stale = True
+        out = collections.OrderedDict(class_loss=losses[0], conf_loss=losses[1], bbox_loss=losses[2], ious=ious, preds=preds,
+                                      dpreds=dpreds, num_objects=num_objects)
+        return out
+
+    def weight_decay_loss(self):
+        """sum wd * l2_loss(kernel) over trainable kernels (the 'losses' collection of nn_skeleton.py:66-69)."""
+        tot = 0.0
+        for n in self.names:
+            if n.endswith("/kernels"):
+                tot += float((self.view[n].double() ** 2).sum().item()) * self.mc.WEIGHT_DECAY / 2
+        return tot

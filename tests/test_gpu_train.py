@@ -125,6 +125,72 @@ def test_loss_forward_backward_vs_oracle():
     _close(dp, dref, rel=5e-5, what="dpreds")
 
 
+def _trainer(img=(128, 256), batch=2, seed=0):
+    import squeezedet_amd as S
+    from squeezedet_amd import nets
+    from squeezedet_amd.train import SqueezeDetTrainer
+    mc = S.kitti_squeezeDet_config_for_input(*img)
+    mc.LOAD_PRETRAINED_MODEL = False
+    mc.IS_TRAINING = True
+    mc.BATCH_SIZE = batch
+    m = nets.SqueezeDet(mc, gpu_id="0", dtype=torch.float32)
+    params = O.init_params("squeezeDet", seed=seed)
+    m.load_params(params)
+    return SqueezeDetTrainer(m), mc, params
+
+
+def test_full_training_step_vs_oracle():
+    """forward(train) -> loss -> backward -> clipped Momentum update: every gradient and every updated
+    variable against PyTorch-CPU autograd + the restated train graph (nn_skeleton.py:285-361)."""
+    tr, mc, params = _trainer()
+    omc = O.squeezeDet_config_for_input(128, 256)
+    omc.IS_TRAINING = True
+    B = 2
+    x = O.synthetic_images(B, 128, 256, seed=11)
+    mask, delta, box, labels = TO.synthetic_labels(omc, B, seed=12)
+    gh, gw = O.squeezedet_grid(128, 256)
+    dm = torch.from_numpy((np.random.RandomState(13).uniform(size=(B, gh, gw, 768)) < 0.5).astype(np.float32))
+    ref = TO.loss_and_grads("squeezeDet", omc, params, x, dm, mask, delta, box, labels)
+    out = tr.step(x, mask, delta, box, labels, dropout_mask=dm, apply_update=False)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(out["class_loss"]), ref["class_loss"], rtol=2e-4)
+    np.testing.assert_allclose(float(out["conf_loss"]), ref["conf_loss"], rtol=2e-4)
+    np.testing.assert_allclose(float(out["bbox_loss"]), ref["bbox_loss"], rtol=2e-4)
+    _close(out["preds"], ref["preds"], rel=1e-4, what="preds (training forward, dropout on)")
+    _close(out["dpreds"], ref["dpreds"], rel=2e-4, what="dpreds")
+    assert "conv1/kernels" not in tr.gview                        # frozen (nets/squeezeDet.py:40-42)
+    worst = 0.0
+    for name, gref in ref["grads"].items():
+        wdg = omc.WEIGHT_DECAY * params[name] if name.endswith("/kernels") else 0.0   # added by the optimizer kernel
+        got = tr.gview[name].cpu() + wdg
+        scale = float(gref.abs().max())
+        err = float((got - gref).abs().max())
+        worst = max(worst, err / max(scale, 1e-12))
+        assert err <= 1e-3 * scale + 1e-7, "%s: grad err %g vs scale %g" % (name, err, scale)   # north_star 1e-3 rel
+    # the update itself
+    mom = {k: torch.zeros_like(v) for k, v in params.items()}
+    p_ref, m_ref = TO.apply_gradients(omc, params, mom, ref["grads"], step=0)
+    tr.opt.step(tr.flat_params, tr.flat_grads, tr.flat_accum, tr.learning_rate(), omc.MOMENTUM, omc.MAX_GRAD_NORM, 1.0)
+    torch.cuda.synchronize()
+    for name in ref["grads"]:
+        _close(tr.view[name], p_ref[name], rel=2e-5, what=name + " after update")
+    _close(tr.model.params["conv1/kernels"], params["conv1/kernels"], rel=0, what="frozen conv1")
+
+
+def test_training_reduces_loss_on_fixed_batch():
+    """A few steps on one fixed batch: the total loss must go down (sanity of signs / learning rate path)."""
+    tr, mc, params = _trainer(seed=3)
+    omc = O.squeezeDet_config_for_input(128, 256)
+    x = O.synthetic_images(2, 128, 256, seed=21)
+    mask, delta, box, labels = TO.synthetic_labels(omc, 2, seed=22)
+    hist = []
+    for _ in range(12):
+        o = tr.step(x, mask, delta, box, labels)
+        hist.append(float(o["class_loss"]) + float(o["conf_loss"]) + float(o["bbox_loss"]))
+    assert tr.global_step == 12 and np.isfinite(hist).all()
+    assert min(hist[-3:]) < hist[0], hist
+
+
 def test_momentum_clip_optimizer_vs_oracle():
     ops = _ops()
     mc = O.kitti_squeezeDet_config()
