@@ -151,13 +151,27 @@ __global__ void slab_reduce_kernel(const float* __restrict__ partial, float* __r
 }
 
 // bias gradient partials: partial[blockIdx.x][co] = sum over this block's pixels of dy[p][co]
-__global__ void bias_grad_partial_kernel(const float* __restrict__ dy, float* __restrict__ partial, int P, int cout,
-                                         int cstride, int coffset) {
-  const int co = blockIdx.y * blockDim.x + threadIdx.x;
-  if (co >= cout) return;
-  float s = 0.f;
-  for (int p = blockIdx.x; p < P; p += gridDim.x) s += dy[(size_t)p * cstride + coffset + co];
-  partial[(size_t)blockIdx.x * cout + co] = s;
+// 256 threads = (256/CW pixel lanes) x (CW channels): every thread streams pixels for one channel of
+// the current CW-channel chunk, lanes are summed through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dy, float* __restrict__ partial,
+                                                                int P, int cout, int cstride, int coffset, int cw) {
+  __shared__ float red[256];
+  const int tx = threadIdx.x % cw, ty = threadIdx.x / cw;
+  const int lanes = 256 / cw;
+  for (int cb = 0; cb < cout; cb += cw) {
+    const int co = cb + tx;
+    float s = 0.f;
+    if (co < cout)
+      for (int p = blockIdx.x * lanes + ty; p < P; p += gridDim.x * lanes) s += dy[(size_t)p * cstride + coffset + co];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (ty == 0 && co < cout) {
+      float t = 0.f;
+      for (int l = 0; l < lanes; ++l) t += red[l * cw + tx];
+      partial[(size_t)blockIdx.x * cout + co] = t;
+    }
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------ elementwise backward ops
@@ -454,6 +468,11 @@ extern "C" int sqdet_conv2d_nhwc_bwd_filter(const float* x, const float* dy, flo
   // enough workgroups to fill the chip, at most 64 slabs
   int ks = (2048 + gx * gy - 1) / (gx * gy);
   if (ks > 64) ks = 64;
+  {  // keep the slab buffer (and the reduction's read traffic) bounded: ks * |dW| <= 16 M floats
+    const long per = (long)k * k * cin * cout;
+    const long cap = (16L << 20) / (per > 0 ? per : 1);
+    if (cap >= 1 && ks > cap) ks = (int)cap;
+  }
   if (ks > a.nstages) ks = a.nstages;
   if (ks < 1) ks = 1;
   a.ksplit = ks;
@@ -470,8 +489,9 @@ extern "C" int sqdet_conv2d_nhwc_bwd_filter(const float* x, const float* dy, flo
   if (dbias) {
     float* bpart = workspace + (size_t)ks * count;
     int rows = (int)(P < 256 ? P : 256);
-    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(rows, (cout + 255) / 256), dim3(256), 0, st, dy, bpart, (int)P, cout,
-                       dy_cstride, dy_coffset);
+    const int cw = cout <= 16 ? 16 : (cout <= 32 ? 32 : 64);
+    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(rows), dim3(256), 0, st, dy, bpart, (int)P, cout, dy_cstride,
+                       dy_coffset, cw);
     SQDET_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(cout)), dim3(256), 0, st, bpart, dbias, (const float*)nullptr, 0.f,
                        (size_t)cout, rows);

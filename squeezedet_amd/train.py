@@ -20,6 +20,15 @@ from . import ops
 from ._lib import SqdetError
 
 
+def allreduce_gradients(flat_grads, world, group=None):
+    """The ONE collective of a training step: SUM all-reduce of the flat float32 gradient bucket over
+    RCCL (xGMI).  Returns the factor (1/world) the optimizer kernel multiplies the summed gradients
+    by before clipping -- i.e. replicas apply the MEAN gradient, identically on every rank."""
+    if world > 1:
+        torch.distributed.all_reduce(flat_grads, op=torch.distributed.ReduceOp.SUM, group=group)
+    return 1.0 / world
+
+
 class SqueezeDetTrainer:
     """model: a squeezedet_amd.nets.SqueezeDet built with mc.IS_TRAINING = True and dtype float32."""
 
@@ -174,11 +183,10 @@ class SqueezeDetTrainer:
                 if need_dx:
                     g = ops.conv2d_bwd_data(ds, ops.PackedConvBwd(P[sq.name + "/kernels"]))
         # ---------------- gradient all-reduce + update ----------------
-        if self.world > 1:
-            torch.distributed.all_reduce(self.flat_grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        grad_scale = allreduce_gradients(self.flat_grads, self.world, self.pg)
         if apply_update:
             self.opt.step(self.flat_params, self.flat_grads, self.flat_accum, self.learning_rate(), mc.MOMENTUM,
-                          mc.MAX_GRAD_NORM, 1.0 / self.world)
+                          mc.MAX_GRAD_NORM, grad_scale)
             self.global_step += 1
             m._packed.clear()
             m._plan_stale = True
