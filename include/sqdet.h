@@ -37,7 +37,7 @@ typedef void* sqdet_stream_t;
 enum { SQDET_OK = 0, SQDET_EINVAL = -1, SQDET_EUNSUPPORTED = -2, SQDET_EHIP = -3, SQDET_ESTATE = -4 };
 enum { SQDET_F32 = 0, SQDET_F16 = 1 };
 enum { SQDET_PAD_SAME = 0, SQDET_PAD_VALID = 1 };
-enum { SQDET_ARCH_SQUEEZEDET = 0, SQDET_ARCH_SQUEEZEDET_PLUS = 1 };
+enum { SQDET_ARCH_SQUEEZEDET = 0, SQDET_ARCH_SQUEEZEDET_PLUS = 1, SQDET_ARCH_RESNET50 = 2 };
 
 const char* sqdet_version(void);
 const char* sqdet_last_error(void);
@@ -67,6 +67,25 @@ int sqdet_conv_pack_weights(const float* w_hwio_f32, void* packed, int k, int ci
 int sqdet_conv2d_nhwc_fwd(const void* x, const void* w_packed, const float* bias, void* y,
                           int n, int h, int w, int cin, int cout, int k, int stride, int pad_mode, int relu,
                           int dtype, int y_cstride, int y_coffset, sqdet_stream_t stream);
+
+/* Residual form used by ResNet50ConvDet (nets/resnet50_convDet.py:55, `tf.nn.relu(branch1+branch2)`):
+ *   y = relu?(conv2d(x, W) + b + y)   -- y holds the shortcut branch on entry, the block output on exit
+ * (the branch2c 1x1 conv of a bottleneck adds its result to the shortcut in its own epilogue, so
+ * the sum never makes an extra HBM round trip).  Same arguments as sqdet_conv2d_nhwc_fwd. */
+int sqdet_conv2d_add_nhwc_fwd(const void* x, const void* w_packed, const float* bias, void* y_inout,
+                              int n, int h, int w, int cin, int cout, int k, int stride, int pad_mode, int relu,
+                              int dtype, int y_cstride, int y_coffset, sqdet_stream_t stream);
+
+/* ------------------------------------------------------------- batch norm --
+ * Replaces the frozen-statistics batch norm of ModelSkeleton._conv_bn_layer (nn_skeleton.py:374-468:
+ * tf.nn.batch_normalization(conv [+ biases], mean, var, offset=beta, scale=gamma, eps) with mean/var
+ * non-trainable constants) by folding it into the conv it follows:
+ *   inv = gamma / sqrt(var + eps);  w_folded[..., c] = w[..., c] * inv[c];
+ *   b_folded[c] = (conv_bias[c] - mean[c]) * inv[c] + beta[c]          (conv_bias may be NULL = 0)
+ * w_hwio / w_folded: float32 [k,k,cin,cout] (may alias); the per-channel vectors float32 [cout]. */
+int sqdet_fold_batchnorm(const float* w_hwio, const float* conv_bias, const float* gamma, const float* beta,
+                         const float* mean, const float* var, float eps, float* w_folded, float* b_folded,
+                         int k, int cin, int cout, sqdet_stream_t stream);
 
 /* ------------------------------------------------------------------ pool --
  * Replaces ModelSkeleton._pooling_layer (nn_skeleton.py:565-586): tf.nn.max_pool,
@@ -204,8 +223,13 @@ size_t sqdet_net_param_bytes(const sqdet_net_t* net);      /* packed kernels + f
 size_t sqdet_net_workspace_bytes(const sqdet_net_t* net);  /* activation buffers */
 int sqdet_net_bind(sqdet_net_t* net, void* param_mem, void* workspace_mem);
 
-/* value: device float32, HWIO for kernels / [cout] for biases. */
+/* value: device float32, HWIO for kernels / [cout] for biases.  SQDET_ARCH_RESNET50
+ * (nets/resnet50_convDet.py:20-169) also lists '<conv>/gamma', '/beta', '/mean', '/var' for its
+ * _conv_bn_layer convs (nn_skeleton.py:427-439); those layers keep the float32 values and fold
+ * them into the packed kernel + bias (sqdet_fold_batchnorm) on the next sqdet_net_forward. */
 int sqdet_net_set_param(sqdet_net_t* net, const char* name, const float* value_f32, sqdet_stream_t stream);
+/* mc.BATCH_NORM_EPSILON (config/config.py:131; default 1e-5). */
+int sqdet_net_set_bn_epsilon(sqdet_net_t* net, float eps);
 
 int sqdet_net_output_dims(const sqdet_net_t* net, int* gh, int* gw, int* channels);
 

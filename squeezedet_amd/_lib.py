@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_PKG, "libsqdet_hip.so")
 SQDET_OK = 0
 F32, F16 = 0, 1
 PAD_SAME, PAD_VALID = 0, 1
-ARCH_SQUEEZEDET, ARCH_SQUEEZEDET_PLUS = 0, 1
+ARCH_SQUEEZEDET, ARCH_SQUEEZEDET_PLUS, ARCH_RESNET50 = 0, 1, 2
 
 _lib = None
 
@@ -24,6 +24,8 @@ SIGNATURES = {
     "sqdet_conv_packed_bytes": (sz, [ci, ci, ci, ci]),
     "sqdet_conv_pack_weights": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "sqdet_conv2d_nhwc_fwd": (ci, [vp, vp, vp, vp] + [ci] * 12 + [vp]),
+    "sqdet_conv2d_add_nhwc_fwd": (ci, [vp, vp, vp, vp] + [ci] * 12 + [vp]),
+    "sqdet_fold_batchnorm": (ci, [vp] * 6 + [cf, vp, vp, ci, ci, ci, vp]),
     "sqdet_maxpool_nhwc_fwd": (ci, [vp, vp] + [ci] * 8 + [vp]),
     "sqdet_stem_conv_pool_fwd": (ci, [vp, vp, vp, vp] + [ci] * 8 + [vp]),
     "sqdet_fire_fwd": (ci, [vp] * 9 + [ci] * 8 + [vp]),
@@ -50,6 +52,7 @@ SIGNATURES = {
     "sqdet_net_workspace_bytes": (sz, [vp]),
     "sqdet_net_bind": (ci, [vp, vp, vp]),
     "sqdet_net_set_param": (ci, [vp, C.c_char_p, vp, vp]),
+    "sqdet_net_set_bn_epsilon": (ci, [vp, cf]),
     "sqdet_net_output_dims": (ci, [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]),
     "sqdet_net_forward": (ci, [vp, vp, vp, vp]),
     "sqdet_net_num_layers": (ci, [vp]),

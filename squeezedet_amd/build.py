@@ -27,6 +27,7 @@ SOURCES = [
     ("stem2.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("fire.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("pool.hip", []),
+    ("bn.hip", ["-ffp-contract=off"]),
     ("postproc.hip", ["-ffp-contract=off"]),
     ("filter_fast.hip", ["-ffp-contract=off"]),
     ("train.hip", ["-ffp-contract=off"]),

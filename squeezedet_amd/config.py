@@ -162,3 +162,18 @@ def kitti_squeezeDet_config_for_input(image_height, image_width):
     for _ in range(4):
         gh, gw = -(-gh // 2), -(-gw // 2)
     return _finish(_kitti_common(mc), gh, gw, SQUEEZEDET_ANCHOR_SHAPES)
+
+
+def kitti_res50_config_for_input(image_height, image_width):
+    """ResNet50+ConvDet on another input size: the grid is what conv1 7x7/s2 SAME, pool1 3x3/s2 VALID
+    and the stride-2 res3a / res4a blocks give (nets/resnet50_convDet.py:41-99); 375x1242 -> 24x78."""
+    mc = base_model_config("KITTI")
+    mc.IMAGE_WIDTH, mc.IMAGE_HEIGHT = int(image_width), int(image_height)
+    g = []
+    for n in (int(image_height), int(image_width)):
+        n = -(-n // 2)            # conv1
+        n = (n - 3) // 2 + 1      # pool1 VALID
+        n = -(-n // 2)            # res3a
+        n = -(-n // 2)            # res4a
+        g.append(n)
+    return _finish(_kitti_common(mc), g[0], g[1], RES50_ANCHOR_SHAPES)

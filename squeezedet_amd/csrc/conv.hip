@@ -382,3 +382,10 @@ extern "C" int sqdet_conv2d_nhwc_fwd(const void* x, const void* w_packed, const 
   return conv2d_launch(x, w_packed, bias, y, n, h, w, cin, cout, k, stride, pad_mode, relu, dtype, y_cstride,
                        y_coffset, as_stream(stream));
 }
+
+extern "C" int sqdet_conv2d_add_nhwc_fwd(const void* x, const void* w_packed, const float* bias, void* y_inout, int n,
+                                         int h, int w, int cin, int cout, int k, int stride, int pad_mode, int relu,
+                                         int dtype, int y_cstride, int y_coffset, sqdet_stream_t stream) {
+  return conv2d_launch_ex(x, w_packed, bias, y_inout, n, h, w, cin, cout, k, stride, pad_mode, relu, dtype, y_cstride,
+                          y_coffset, cin, 0, 1, as_stream(stream));
+}

@@ -1,7 +1,8 @@
 // Host-side executor: the plan that replaces SqueezeDet._add_forward_graph /
-// SqueezeDetPlus._add_forward_graph (reference src/nets/squeezeDet.py:30-79,
-// src/nets/squeezeDetPlus.py:30-79).  It owns no device memory: packed parameters and the
-// activation workspace are bound by the caller (sqdet_net_bind).
+// SqueezeDetPlus._add_forward_graph / ResNet50ConvDet._add_forward_graph (reference
+// src/nets/squeezeDet.py:30-79, src/nets/squeezeDetPlus.py:30-79, src/nets/resnet50_convDet.py:31-169).
+// It owns no device memory: packed parameters and the activation workspace are bound by the
+// caller (sqdet_net_bind).
 #include <string.h>
 
 #include <string>
@@ -13,6 +14,11 @@ namespace sqdet {
 int conv2d_launch(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
                   int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
                   hipStream_t st);
+int conv2d_launch_ex(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
+                     int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
+                     int x_cstride, int x_coffset, int accum, hipStream_t st);
+int fold_bn_launch(const float* w, const float* cbias, const float* gamma, const float* beta, const float* mean,
+                   const float* var, float eps, float* wf, float* bf, int k, int cin, int cout, hipStream_t st);
 int maxpool_launch(const void* x, void* y, int n, int h, int w, int c, int k, int stride, int pad_mode, int dtype,
                    hipStream_t st);
 int stem_launch(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cout, int k,
@@ -30,7 +36,7 @@ using namespace sqdet;
 
 namespace {
 
-enum { BUF_INPUT = -1, BUF_PREDS = -2, BUF_A = 0, BUF_B = 1, BUF_S = 2 };
+enum { BUF_INPUT = -1, BUF_PREDS = -2, BUF_A = 0, BUF_B = 1, BUF_S = 2, BUF_T = 3, NUM_BUFS = 4 };
 // L_STEM: conv(k, s2, Cin 3)+relu+maxpool(3, s2) in one launch; L_FIRE: squeeze + both expands in one launch
 enum { L_CONV = 0, L_POOL = 1, L_STEM = 2, L_FIRE = 3 };
 
@@ -40,6 +46,17 @@ struct Param {
   int ndim;
   size_t offset;  // into param_mem
   size_t bytes;
+  int fold = -1;  // index into sqdet_net::folds when the parameter belongs to a _conv_bn_layer
+};
+
+// One _conv_bn_layer (nn_skeleton.py:374-468): the float32 kernel and the BN vectors are kept as
+// set; the packed kernel + folded bias the conv launch reads are rebuilt when any of them changed.
+struct BnFold {
+  int k, cin, cout;
+  int kparam, cbias, gamma, beta, mean, var;  // params indices (cbias -1: conv_with_bias=False)
+  size_t raw_off;    // float32 HWIO copy of the kernel
+  size_t fbias_off;  // folded bias, float32 [cout]
+  bool dirty;
 };
 
 struct Layer {
@@ -50,6 +67,8 @@ struct Layer {
   int ho, wo;
   int y_cstride, y_coffset;
   int kparam, bparam;  // indices into params (conv)
+  int fold = -1;       // BnFold index: bias comes from the folded-bias slot
+  int accum = 0;       // y = act(conv + bias + y): the residual add of a bottleneck block
   int pool_pad_mode;   // L_STEM: padding of the fused pool
   // L_FIRE: cin = fire input channels, cout = e1 + e3; the three convs' parameters
   int fs, fe1, fe3;
@@ -66,8 +85,11 @@ struct sqdet_net {
   std::vector<Param> params;
   std::vector<Layer> layers;
   size_t param_bytes = 0;
-  size_t buf_elems[3] = {0, 0, 0};
-  size_t buf_off[3] = {0, 0, 0};
+  std::vector<BnFold> folds;
+  size_t fold_scratch_off = 0, fold_scratch_bytes = 0;  // folded float32 kernel before packing
+  float bn_eps = 1e-5f;                                 // config/config.py:131
+  size_t buf_elems[NUM_BUFS] = {0, 0, 0, 0};
+  size_t buf_off[NUM_BUFS] = {0, 0, 0, 0};
   size_t workspace_bytes = 0;
   int gh = 0, gw = 0, out_ch = 0;
   char* param_mem = nullptr;
@@ -131,6 +153,67 @@ struct Builder {
     net->layers.push_back(L);
   }
 
+  // _conv_bn_layer (nn_skeleton.py:374-468): variables kernels, [biases], gamma, beta, mean, var in
+  // the reference's creation order; executed as one conv with the BN folded in.
+  void conv_bn(const std::string& name, int in_buf, int out_buf, int cin, int cout, int k, int stride, int relu,
+               bool with_bias, int accum) {
+    Layer L;
+    L.type = L_CONV;
+    L.name = name;
+    L.in_buf = in_buf; L.out_buf = out_buf;
+    L.h = h; L.w = w; L.cin = cin; L.cout = cout; L.k = k; L.stride = stride; L.pad_mode = SQDET_PAD_SAME; L.relu = relu;
+    L.ho = out_size(h, k, stride, SQDET_PAD_SAME);
+    L.wo = out_size(w, k, stride, SQDET_PAD_SAME);
+    L.y_cstride = cout; L.y_coffset = 0;
+    L.accum = accum;
+    BnFold f;
+    f.k = k; f.cin = cin; f.cout = cout; f.dirty = true;
+    const int kshape[4] = {k, k, cin, cout};
+    const int vshape[1] = {cout};
+    const size_t raw_bytes = (size_t)k * k * cin * cout * 4;
+    f.kparam = L.kparam = add_param(name + "/kernels", 4, kshape, sqdet_conv_packed_bytes(k, cin, cout, net->dtype));
+    f.cbias = with_bias ? add_param(name + "/biases", 1, vshape, (size_t)cout * 4) : -1;
+    f.gamma = add_param(name + "/gamma", 1, vshape, (size_t)cout * 4);
+    f.beta = add_param(name + "/beta", 1, vshape, (size_t)cout * 4);
+    f.mean = add_param(name + "/mean", 1, vshape, (size_t)cout * 4);
+    f.var = add_param(name + "/var", 1, vshape, (size_t)cout * 4);
+    f.raw_off = net->param_bytes;
+    net->param_bytes = align_up(net->param_bytes + raw_bytes, 256);
+    f.fbias_off = net->param_bytes;
+    net->param_bytes = align_up(net->param_bytes + (size_t)cout * 4, 256);
+    if (raw_bytes > net->fold_scratch_bytes) net->fold_scratch_bytes = raw_bytes;
+    L.bparam = -1;
+    L.fold = (int)net->folds.size();
+    for (int pi : {f.kparam, f.cbias, f.gamma, f.beta, f.mean, f.var})
+      if (pi >= 0) net->params[pi].fold = L.fold;
+    net->folds.push_back(f);
+    const double npix = (double)net->batch * L.ho * L.wo;
+    L.flops = 2.0 * k * k * cin * cout * npix;
+    L.bytes = ((double)net->batch * h * w * cin + npix * cout * (accum ? 2.0 : 1.0) + (double)k * k * cin * cout) *
+                  (double)esz + cout * 4.0;
+    note_buf(out_buf, (size_t)net->batch * L.ho * L.wo * cout);
+    net->layers.push_back(L);
+  }
+
+  // One bottleneck of ResNet50ConvDet (resnet50_convDet.py:50-118 + _res_branch :134-169):
+  //   out = relu(shortcut + branch2c(branch2b(branch2a(x)))), shortcut = branch1(x) in the 'a'
+  // blocks, x itself otherwise; the stride sits on branch1 / branch2a (caffe-style).  branch2c
+  // adds into the shortcut buffer in its epilogue, so identity blocks update x in place.
+  void res_block(const std::string& stage, const std::string& n, int in_f, int out_f, bool down, bool has_branch1) {
+    const std::string blk = stage + "/res" + n + "/";
+    const std::string b2 = blk + "res" + n + "_branch2/res" + n;
+    const int X = cur, Y = other(cur);
+    const int stride = down ? 2 : 1;
+    const int h0 = h, w0 = w;
+    if (has_branch1) conv_bn(blk + "res" + n + "_branch1", X, Y, c, out_f, 1, stride, 0, false, 0);
+    conv_bn(b2 + "_branch2a", X, BUF_S, c, in_f, 1, stride, 1, false, 0);
+    h = out_size(h0, 1, stride, SQDET_PAD_SAME); w = out_size(w0, 1, stride, SQDET_PAD_SAME);
+    conv_bn(b2 + "_branch2b", BUF_S, BUF_T, in_f, in_f, 3, 1, 1, false, 0);
+    conv_bn(b2 + "_branch2c", BUF_T, has_branch1 ? Y : X, in_f, out_f, 1, 1, 1, false, 1);
+    c = out_f;
+    if (has_branch1) cur = Y;
+  }
+
   int other(int buf) { return buf == BUF_A ? BUF_B : BUF_A; }
 
   void conv_layer(const std::string& name, int cout, int k, int stride, int pad_mode, int relu, bool last) {
@@ -189,9 +272,10 @@ int run_layer(sqdet_net* net, const Layer& L, const void* input, void* preds, hi
   void* y = buf_ptr(net, L.out_buf, input, preds);
   if (L.type == L_CONV) {
     const void* wp = net->param_mem + net->params[L.kparam].offset;
-    const float* b = reinterpret_cast<const float*>(net->param_mem + net->params[L.bparam].offset);
-    return conv2d_launch(x, wp, b, y, net->batch, L.h, L.w, L.cin, L.cout, L.k, L.stride, L.pad_mode, L.relu,
-                         net->dtype, L.y_cstride, L.y_coffset, st);
+    const float* b = reinterpret_cast<const float*>(
+        net->param_mem + (L.fold >= 0 ? net->folds[L.fold].fbias_off : net->params[L.bparam].offset));
+    return conv2d_launch_ex(x, wp, b, y, net->batch, L.h, L.w, L.cin, L.cout, L.k, L.stride, L.pad_mode, L.relu,
+                            net->dtype, L.y_cstride, L.y_coffset, L.cin, 0, L.accum, st);
   }
   if (L.type == L_STEM) {
     const void* wp = net->param_mem + net->params[L.kparam].offset;
@@ -214,6 +298,25 @@ int run_layer(sqdet_net* net, const Layer& L, const void* input, void* preds, hi
     return SQDET_OK;
   }
   return maxpool_launch(x, y, net->batch, L.h, L.w, L.cin, L.k, L.stride, L.pad_mode, net->dtype, st);
+}
+
+// Re-folds (sqdet_fold_batchnorm) and re-packs every _conv_bn_layer whose parameters changed since
+// the last forward; stream-ordered before the layers that read them.
+int refresh_folds(sqdet_net* net, hipStream_t st) {
+  for (BnFold& f : net->folds) {
+    if (!f.dirty) continue;
+    auto vec = [&](int pi) { return pi >= 0 ? reinterpret_cast<const float*>(net->param_mem + net->params[pi].offset) : nullptr; };
+    float* scratch = reinterpret_cast<float*>(net->param_mem + net->fold_scratch_off);
+    int rc = fold_bn_launch(reinterpret_cast<const float*>(net->param_mem + f.raw_off), vec(f.cbias), vec(f.gamma),
+                            vec(f.beta), vec(f.mean), vec(f.var), net->bn_eps, scratch,
+                            reinterpret_cast<float*>(net->param_mem + f.fbias_off), f.k, f.cin, f.cout, st);
+    if (rc != SQDET_OK) return rc;
+    rc = sqdet_conv_pack_weights(scratch, net->param_mem + net->params[f.kparam].offset, f.k, f.cin, f.cout, net->dtype,
+                                 reinterpret_cast<sqdet_stream_t>(st));
+    if (rc != SQDET_OK) return rc;
+    f.dirty = false;
+  }
+  return SQDET_OK;
 }
 
 // squeeze1x1 + expand1x1 + expand3x3 -> one L_FIRE launch (decided at plan creation).  Heuristic
@@ -280,7 +383,8 @@ void fuse_stem(sqdet_net* net, size_t esz) {
 extern "C" int sqdet_net_create(sqdet_net_t** out, int arch, int dtype, int batch, int img_h, int img_w, int classes,
                                 int anchors_per_grid) {
   SQDET_REQUIRE(out, "net_create: null out");
-  SQDET_REQUIRE(arch == SQDET_ARCH_SQUEEZEDET || arch == SQDET_ARCH_SQUEEZEDET_PLUS, "net_create: bad arch %d", arch);
+  SQDET_REQUIRE(arch == SQDET_ARCH_SQUEEZEDET || arch == SQDET_ARCH_SQUEEZEDET_PLUS || arch == SQDET_ARCH_RESNET50,
+                "net_create: bad arch %d", arch);
   SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "net_create: bad dtype %d", dtype);
   SQDET_REQUIRE(batch > 0 && img_h >= 64 && img_w >= 64 && classes > 0 && anchors_per_grid > 0, "net_create: bad dims");
   sqdet_net* net = new sqdet_net();
@@ -298,6 +402,18 @@ extern "C" int sqdet_net_create(sqdet_net_t** out, int arch, int dtype, int batc
     b.fire_layer(f[2]); b.fire_layer(f[3]);
     b.pool_layer("pool5", 3, 2, SQDET_PAD_SAME);
     for (int i = 4; i < 10; ++i) b.fire_layer(f[i]);
+  } else if (arch == SQDET_ARCH_RESNET50) {
+    // resnet50_convDet.py:41-118: conv1 7x7/2 (+bias, BN) -> pool1 3x3/2 VALID -> res2a..res4f
+    b.conv_bn("conv1", BUF_INPUT, BUF_A, 3, 64, 7, 2, 1, true, 0);
+    b.h = net->layers.back().ho; b.w = net->layers.back().wo; b.c = 64; b.cur = BUF_A;
+    b.pool_layer("pool1", 3, 2, SQDET_PAD_VALID);
+    b.res_block("conv2_x", "2a", 64, 256, false, true);
+    b.res_block("conv2_x", "2b", 64, 256, false, false);
+    b.res_block("conv2_x", "2c", 64, 256, false, false);
+    b.res_block("conv3_x", "3a", 128, 512, true, true);
+    for (const char* n : {"3b", "3c", "3d"}) b.res_block("conv3_x", n, 128, 512, false, false);
+    b.res_block("conv4_x", "4a", 256, 1024, true, true);
+    for (const char* n : {"4b", "4c", "4d", "4e", "4f"}) b.res_block("conv4_x", n, 256, 1024, false, false);
   } else {
     const FireSpec* f = kSqueezeDetPlusFires;
     b.conv_layer("conv1", 96, 7, 2, SQDET_PAD_VALID, 1, false);
@@ -308,13 +424,15 @@ extern "C" int sqdet_net_create(sqdet_net_t** out, int arch, int dtype, int batc
     b.pool_layer("pool8", 3, 2, SQDET_PAD_VALID);
     b.fire_layer(f[7]); b.fire_layer(f[8]); b.fire_layer(f[9]);
   }
-  // dropout11 is the identity at inference (keep_prob = 1.0, nn_skeleton.py:78)
-  b.conv_layer("conv12", nout, 3, 1, SQDET_PAD_SAME, 0, true);
+  // dropout11 / drop4 is the identity at inference (keep_prob = 1.0, nn_skeleton.py:78)
+  b.conv_layer(arch == SQDET_ARCH_RESNET50 ? "conv5" : "conv12", nout, 3, 1, SQDET_PAD_SAME, 0, true);
   net->gh = b.h; net->gw = b.w; net->out_ch = nout;
   fuse_stem(net, b.esz);
   fuse_fires(net, b.esz);
+  net->fold_scratch_off = net->param_bytes;
+  net->param_bytes = align_up(net->param_bytes + net->fold_scratch_bytes, 256);
   size_t off = 0;
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < NUM_BUFS; ++i) {
     net->buf_off[i] = off;
     off = align_up(off + net->buf_elems[i] * b.esz, 256);
   }
@@ -365,6 +483,15 @@ extern "C" int sqdet_net_set_param(sqdet_net_t* net, const char* name, const flo
   if (!net->param_mem) { set_error("net_set_param: call sqdet_net_bind first"); return SQDET_ESTATE; }
   for (const Param& p : net->params) {
     if (p.name != name) continue;
+    if (p.fold >= 0) {  // _conv_bn_layer: keep the float32 value, fold + pack lazily
+      BnFold& f = net->folds[p.fold];
+      const bool kernel = p.ndim == 4;
+      SQDET_CHECK_HIP(hipMemcpyAsync(net->param_mem + (kernel ? f.raw_off : p.offset), value_f32,
+                                     kernel ? (size_t)f.k * f.k * f.cin * f.cout * 4 : (size_t)p.shape[0] * 4,
+                                     hipMemcpyDeviceToDevice, as_stream(stream)));
+      f.dirty = true;
+      return SQDET_OK;
+    }
     if (p.ndim == 4)
       return sqdet_conv_pack_weights(value_f32, net->param_mem + p.offset, p.shape[0], p.shape[2], p.shape[3],
                                      net->dtype, stream);
@@ -374,6 +501,13 @@ extern "C" int sqdet_net_set_param(sqdet_net_t* net, const char* name, const flo
   }
   set_error("net_set_param: no parameter named '%s'", name);
   return SQDET_EINVAL;
+}
+
+extern "C" int sqdet_net_set_bn_epsilon(sqdet_net_t* net, float eps) {
+  SQDET_REQUIRE(net && eps >= 0.f, "net_set_bn_epsilon: bad arguments");
+  net->bn_eps = eps;
+  for (BnFold& f : net->folds) f.dirty = true;
+  return SQDET_OK;
 }
 
 extern "C" int sqdet_net_output_dims(const sqdet_net_t* net, int* gh, int* gw, int* channels) {
@@ -388,6 +522,8 @@ extern "C" int sqdet_net_forward(sqdet_net_t* net, const void* image_input, void
   SQDET_REQUIRE(net && image_input && preds, "net_forward: null pointer");
   if (!net->param_mem || !net->workspace) { set_error("net_forward: call sqdet_net_bind first"); return SQDET_ESTATE; }
   hipStream_t st = as_stream(stream);
+  const int frc = refresh_folds(net, st);
+  if (frc != SQDET_OK) return frc;
   const int nl = (int)net->layers.size();
   const bool overlap = fire_overlap() != 0;
   if (overlap && !net->side) SQDET_CHECK_HIP(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking));
@@ -483,6 +619,8 @@ extern "C" int sqdet_net_forward_timed(sqdet_net_t* net, const void* image_input
     net->events.push_back(e);
   }
   hipStream_t st = as_stream(stream);
+  const int frc = refresh_folds(net, st);
+  if (frc != SQDET_OK) return frc;
   SQDET_CHECK_HIP(hipEventRecord(net->events[0], st));
   for (size_t i = 0; i < nl; ++i) {
     const int rc = run_layer(net, net->layers[i], image_input, preds, st);

@@ -63,6 +63,56 @@ class SqueezeDet(_FireNet):
                                       xavier=False, relu=False, stddev=0.0001)
 
 
+class ResNet50ConvDet(_FireNet):
+    """ResNet50 conv1..res4f + ConvDet (nets/resnet50_convDet.py:20-169)."""
+    NATIVE_ARCH = "resnet50"
+
+    def _add_forward_graph(self):
+        """NN architecture (nets/resnet50_convDet.py:31-132)."""
+        mc = self.mc
+        self._load_pretrained()
+        conv1 = self._conv_bn_layer(self.image_input, "conv1", "bn_conv1", "scale_conv1", filters=64, size=7, stride=2,
+                                    freeze=True, conv_with_bias=True)
+        pool1 = self._pooling_layer("pool1", conv1, size=3, stride=2, padding="VALID")
+        # (stage scope, block names, branch2a/b filters, output filters, frozen) -- :47-118
+        stages = [("conv2_x", ["2a", "2b", "2c"], 64, 256, True),
+                  ("conv3_x", ["3a", "3b", "3c", "3d"], 128, 512, True),
+                  ("conv4_x", ["4a", "4b", "4c", "4d", "4e", "4f"], 256, 1024, False)]
+        x = pool1
+        for scope, blocks, in_f, out_f, freeze in stages:
+            with self.variable_scope(scope):
+                for i, n in enumerate(blocks):
+                    with self.variable_scope("res" + n):
+                        first = i == 0
+                        down = first and scope != "conv2_x"
+                        shortcut = x
+                        if first:   # projection shortcut: 1x1, stride on the shortcut too, no relu (:51-53,71-73,97-99)
+                            shortcut = self._conv_bn_layer(x, "res%s_branch1" % n, "bn%s_branch1" % n, "scale%s_branch1" % n,
+                                                           filters=out_f, size=1, stride=2 if down else 1, freeze=freeze,
+                                                           relu=False)
+                        branch2 = self._res_branch(x, layer_name=n, in_filters=in_f, out_filters=out_f, down_sample=down,
+                                                   freeze=freeze)
+                        x = self._add_relu(shortcut, branch2, name="res" + n)
+        dropout4 = self._dropout(x, self.keep_prob, name="drop4")
+        num_output = mc.ANCHOR_PER_GRID * (mc.CLASSES + 1 + 4)
+        self.preds = self._conv_layer("conv5", dropout4, filters=num_output, size=3, stride=1, padding="SAME",
+                                      xavier=False, relu=False, stddev=0.0001)
+
+    def _res_branch(self, inputs, layer_name, in_filters, out_filters, down_sample=False, freeze=False):
+        """Residual branch constructor (nets/resnet50_convDet.py:134-169): 1x1 (stride 2 when
+        down-sampling) -> 3x3 -> 1x1 without relu, each conv + frozen BN."""
+        with self.variable_scope("res" + layer_name + "_branch2"):
+            stride = 2 if down_sample else 1
+            n = layer_name
+            out = self._conv_bn_layer(inputs, "res%s_branch2a" % n, "bn%s_branch2a" % n, "scale%s_branch2a" % n,
+                                      filters=in_filters, size=1, stride=stride, freeze=freeze)
+            out = self._conv_bn_layer(out, "res%s_branch2b" % n, "bn%s_branch2b" % n, "scale%s_branch2b" % n,
+                                      filters=in_filters, size=3, stride=1, freeze=freeze)
+            out = self._conv_bn_layer(out, "res%s_branch2c" % n, "bn%s_branch2c" % n, "scale%s_branch2c" % n,
+                                      filters=out_filters, size=1, stride=1, freeze=freeze, relu=False)
+            return out
+
+
 class SqueezeDetPlus(_FireNet):
     NATIVE_ARCH = "squeezeDet+"
 

@@ -7,6 +7,7 @@ libsqdet_hip.so.  Like TF 1.0 it is define-then-run: builders record symbolic no
 executes them on the GPU.  There is no CPU execution path.
 """
 import collections
+import contextlib
 
 import numpy as np
 import torch
@@ -21,8 +22,10 @@ class Node:
     def __init__(self, model, op, inputs=(), shape=None, name=None, **attrs):
         self.model, self.op, self.inputs, self.shape, self.name, self.attrs = model, op, tuple(inputs), shape, name, attrs
         self.consumers = 0
+        self.readers = []
         for i in self.inputs:
             i.consumers += 1
+            i.readers.append(self)
 
     def get_shape(self):
         return tuple(self.shape)
@@ -88,6 +91,7 @@ class ModelSkeleton:
         self.flop_counter = []
         self.activation_counter = [("input", mc.IMAGE_WIDTH * mc.IMAGE_HEIGHT * 3)]
         self._packed = {}
+        self._scope = []                          # tf.variable_scope stack
         self._plan = None
         self._plan_stale = True
         self._anchors_f32 = None
@@ -147,6 +151,61 @@ class ModelSkeleton:
         self.flop_counter.append((layer_name, num_flops))
         self.activation_counter.append((layer_name, out_shape[1] * out_shape[2] * out_shape[3]))
         return out
+
+    @contextlib.contextmanager
+    def variable_scope(self, name):
+        """tf.variable_scope: prefixes the names of the variables created inside (resnet50_convDet.py:47-49)."""
+        self._scope.append(name)
+        try:
+            yield
+        finally:
+            self._scope.pop()
+
+    def _conv_bn_layer(self, inputs, conv_param_name, bn_param_name, scale_param_name, filters, size, stride,
+                       padding="SAME", freeze=False, relu=True, conv_with_bias=False, stddev=0.001):
+        """Convolution + BatchNorm + [relu] layer (nn_skeleton.py:374-468).  Batch mean and var are
+        constants; variables '<scope>/<conv_param_name>/kernels' [, 'biases'], 'gamma', 'beta', 'mean',
+        'var'.  Executed as ONE conv: the frozen BN is folded into kernel and bias
+        (sqdet_fold_batchnorm)."""
+        mc = self.mc
+        channels = int(inputs.get_shape()[3])
+        if mc.LOAD_PRETRAINED_MODEL:
+            cw = self.caffemodel_weight
+            kernel = torch.from_numpy(np.ascontiguousarray(np.transpose(cw[conv_param_name][0], [2, 3, 1, 0]), dtype=np.float32))
+            bias = torch.from_numpy(np.ascontiguousarray(cw[conv_param_name][1], dtype=np.float32)) if conv_with_bias else None
+            vec = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).reshape(-1)
+            mean, var = vec(cw[bn_param_name][0]), vec(cw[bn_param_name][1])
+            gamma, beta = vec(cw[scale_param_name][0]), vec(cw[scale_param_name][1])
+        else:
+            kernel = _truncated_normal((size, size, channels, filters), stddev, self._gen, "cpu")
+            bias = torch.zeros(filters) if conv_with_bias else None
+            mean, var, gamma, beta = torch.zeros(filters), torch.ones(filters), torch.ones(filters), torch.zeros(filters)
+        if tuple(kernel.shape) != (size, size, channels, filters):
+            raise SqdetError("%s: pretrained kernel shape %s != %s" % (conv_param_name, tuple(kernel.shape), (size, size, channels, filters)))
+        name = "/".join(self._scope + [conv_param_name])
+        self._new_param(name + "/kernels", kernel, not freeze)
+        if conv_with_bias:
+            self._new_param(name + "/biases", bias, not freeze)
+        self._new_param(name + "/gamma", gamma, not freeze)
+        self._new_param(name + "/beta", beta, not freeze)
+        self._new_param(name + "/mean", mean, False)
+        self._new_param(name + "/var", var, False)
+        n, h, w, _ = inputs.get_shape()
+        out_shape = (n, _out_size(h, size, stride, padding), _out_size(w, size, stride, padding), filters)
+        out = Node(self, "conv_bn", [inputs], out_shape, name, size=size, stride=stride, padding=padding, relu=relu,
+                   with_bias=conv_with_bias)
+        self.model_size_counter.append((conv_param_name, (1 + size * size * channels) * filters))
+        num_flops = (1 + 2 * channels * size * size) * filters * out_shape[1] * out_shape[2]
+        if relu:
+            num_flops += 2 * filters * out_shape[1] * out_shape[2]
+        self.flop_counter.append((conv_param_name, num_flops))
+        self.activation_counter.append((conv_param_name, out_shape[1] * out_shape[2] * out_shape[3]))
+        return out
+
+    def _add_relu(self, shortcut, branch, name=None):
+        """tf.nn.relu(shortcut + branch, 'relu') (resnet50_convDet.py:55)."""
+        assert shortcut.get_shape() == branch.get_shape()
+        return Node(self, "add_relu", [shortcut, branch], shortcut.get_shape(), name)
 
     def _pooling_layer(self, layer_name, inputs, size, stride, padding="SAME"):
         """Pooling layer constructor (nn_skeleton.py:565-586)."""
@@ -211,12 +270,22 @@ class ModelSkeleton:
             self._packed[name] = ops.pack_conv_weights(self.params[name + "/kernels"], self.dtype)
         return self._packed[name]
 
+    def _folded_conv(self, name, with_bias):
+        """(PackedConv, folded bias) of a _conv_bn_layer: BN folded by sqdet_fold_batchnorm, then packed."""
+        if name not in self._packed:
+            P = self.params
+            wf, bf = ops.fold_batchnorm(P[name + "/kernels"], P[name + "/biases"] if with_bias else None, P[name + "/gamma"],
+                                        P[name + "/beta"], P[name + "/mean"], P[name + "/var"], self.mc.BATCH_NORM_EPSILON)
+            self._packed[name] = (ops.pack_conv_weights(wf, self.dtype), bf)
+        return self._packed[name]
+
     # ------------------------------------------------------------------ execution
     def _native_plan(self, batch):
         if self._plan is None or self._plan.batch != batch:
             mc = self.mc
             self._plan = ops.NetPlan(self.NATIVE_ARCH, self.dtype, batch, mc.IMAGE_HEIGHT, mc.IMAGE_WIDTH, mc.CLASSES,
                                      mc.ANCHOR_PER_GRID, self.device)
+            self._plan.set_bn_epsilon(mc.BATCH_NORM_EPSILON)
             self._plan_stale = True
         if self._plan_stale:
             specs = dict(self._plan.param_specs())
@@ -248,6 +317,27 @@ class ModelSkeleton:
             x = self._eval(node.inputs[0], env, use_plan)
             v = ops.conv2d_nhwc(x, self._packed_conv(node.name), self.params[node.name + "/biases"], node.attrs["stride"],
                                 node.attrs["padding"], node.attrs["relu"])
+        elif node.op == "conv_bn":
+            x = self._eval(node.inputs[0], env, use_plan)
+            pk, bf = self._folded_conv(node.name, node.attrs["with_bias"])
+            v = ops.conv2d_nhwc(x, pk, bf, node.attrs["stride"], node.attrs["padding"], node.attrs["relu"])
+        elif node.op == "add_relu":
+            shortcut, branch = node.inputs
+            if branch.op == "conv_bn" and not branch.attrs["relu"] and branch.consumers == 1:
+                # branch2c adds into the shortcut in its own epilogue: relu(conv + b + shortcut).  The
+                # shortcut tensor is updated in place when this add is its last reader (branch1 output,
+                # or a block input whose only other reader -- branch2a -- has already run).
+                bx = self._eval(branch.inputs[0], env, use_plan)
+                sv = self._eval(shortcut, env, use_plan)
+                in_place = (shortcut not in self._fetching and shortcut.op != "placeholder" and
+                            all(r in env for r in shortcut.readers if r is not node))
+                out = sv if in_place else sv.clone()
+                pk, bf = self._folded_conv(branch.name, branch.attrs["with_bias"])
+                v = ops.conv2d_nhwc(bx, pk, bf, branch.attrs["stride"], branch.attrs["padding"], True, out=out, accumulate=True)
+            else:
+                a = self._eval(shortcut, env, use_plan)
+                b = self._eval(branch, env, use_plan)
+                v = torch.relu(a + b)
         elif node.op == "pool":
             x = self._eval(node.inputs[0], env, use_plan)
             v = ops.maxpool_nhwc(x, node.attrs["size"], node.attrs["stride"], node.attrs["padding"])
@@ -289,6 +379,7 @@ class ModelSkeleton:
         if not self.has_device:
             raise SqdetError("squeezedet_amd needs a HIP device to run: there is no CPU path")
         env = {}
+        self._fetching = set(fetches)
         for k, v in feed_dict.items():
             if k is not self.image_input and k is not self.ph_image_input:
                 raise SqdetError("only image_input can be fed")

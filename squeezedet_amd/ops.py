@@ -47,11 +47,28 @@ def pack_conv_weights(w_hwio, dtype):
     return PackedConv(w_hwio, dtype)
 
 
-def conv2d_nhwc(x, packed, bias, stride=1, padding="SAME", relu=True, out=None, out_coffset=0):
+def fold_batchnorm(w_hwio, conv_bias, gamma, beta, mean, var, eps):
+    """Frozen batch norm of _conv_bn_layer (nn_skeleton.py:374-468) folded into its conv
+    (sqdet_fold_batchnorm): returns (w_folded [k,k,cin,cout] f32, b_folded [cout] f32)."""
+    w = w_hwio.detach().to(torch.float32).contiguous()
+    k, _, cin, cout = [int(v) for v in w.shape]
+    vecs =[v.detach().to(torch.float32).contiguous() for v in (gamma, beta, mean, var)]
+    cb = conv_bias.detach().to(torch.float32).contiguous() if conv_bias is not None else None
+    wf = torch.empty_like(w)
+    bf = torch.empty(cout, dtype=torch.float32, device=w.device)
+    check(lib().sqdet_fold_batchnorm(_dev(w, "w_hwio"), _dev(cb, "conv_bias") if cb is not None else None,
+                                     _dev(vecs[0], "gamma"), _dev(vecs[1], "beta"), _dev(vecs[2], "mean"),
+                                     _dev(vecs[3], "var"), float(eps), _dev(wf, "w_folded"), _dev(bf, "b_folded"),
+                                     k, cin, cout, stream_ptr()), "sqdet_fold_batchnorm")
+    return wf, bf
+
+
+def conv2d_nhwc(x, packed, bias, stride=1, padding="SAME", relu=True, out=None, out_coffset=0, accumulate=False):
     """relu?(conv2d(x, W) + b) with TF SAME/VALID semantics (nn_skeleton.py:471-563).
     x: [N,H,W,Cin] f16/f32 NHWC; packed: PackedConv; bias: f32 [Cout].  ``out`` (optional)
     is a [N,Ho,Wo,Ctot] tensor whose channels [out_coffset, out_coffset+Cout) are written
-    (fire-module concat without a concat pass)."""
+    (fire-module concat without a concat pass).  accumulate=True: out = relu?(conv + b + out), the
+    residual add of a ResNet bottleneck (resnet50_convDet.py:55) done in the conv epilogue."""
     n, h, w, cin = [int(v) for v in x.shape]
     if cin != packed.cin or x.dtype != packed.dtype:
         raise _lib.SqdetError("conv2d_nhwc: input [%d ch, %s] does not match packed kernel [%d ch, %s]"
@@ -60,12 +77,15 @@ def conv2d_nhwc(x, packed, bias, stride=1, padding="SAME", relu=True, out=None, 
     if out is None:
         out = torch.empty((n, ho, wo, packed.cout), dtype=x.dtype, device=x.device)
         out_coffset = 0
+        if accumulate:
+            raise _lib.SqdetError("conv2d_nhwc: accumulate=True needs `out` (the shortcut branch)")
     elif tuple(out.shape[:3]) != (n, ho, wo) or out.dtype != x.dtype:
         raise _lib.SqdetError("conv2d_nhwc: bad `out` shape/dtype")
-    check(lib().sqdet_conv2d_nhwc_fwd(_dev(x, "x"), _dev(packed.data, "packed"), _dev(bias, "bias", torch.float32),
-                                      _dev(out, "out"), n, h, w, cin, packed.cout, packed.k, int(stride),
-                                      pad_code(padding), int(bool(relu)), dtype_code(x.dtype), int(out.shape[3]),
-                                      int(out_coffset), stream_ptr()), "sqdet_conv2d_nhwc_fwd")
+    fn = lib().sqdet_conv2d_add_nhwc_fwd if accumulate else lib().sqdet_conv2d_nhwc_fwd
+    check(fn(_dev(x, "x"), _dev(packed.data, "packed"), _dev(bias, "bias", torch.float32),
+             _dev(out, "out"), n, h, w, cin, packed.cout, packed.k, int(stride),
+             pad_code(padding), int(bool(relu)), dtype_code(x.dtype), int(out.shape[3]),
+             int(out_coffset), stream_ptr()), "sqdet_conv2d_add_nhwc_fwd" if accumulate else "sqdet_conv2d_nhwc_fwd")
     return out
 
 
@@ -292,7 +312,11 @@ class NetPlan:
     """sqdet_net_*: the whole forward graph (nets/squeezeDet.py:30-79 /
     nets/squeezeDetPlus.py:30-79) as one native plan; device memory is torch-allocated."""
 
-    ARCH = {"squeezeDet": _lib.ARCH_SQUEEZEDET, "squeezeDet+": _lib.ARCH_SQUEEZEDET_PLUS}
+    ARCH = {"squeezeDet": _lib.ARCH_SQUEEZEDET, "squeezeDet+": _lib.ARCH_SQUEEZEDET_PLUS,
+            "resnet50": _lib.ARCH_RESNET50}
+
+    def set_bn_epsilon(self, eps):
+        check(lib().sqdet_net_set_bn_epsilon(self._h, float(eps)), "sqdet_net_set_bn_epsilon")
 
     def __init__(self, arch, dtype, batch, img_h, img_w, classes, anchors_per_grid, device):
         self.arch, self.dtype, self.batch, self.img_h, self.img_w = arch, dtype, batch, img_h, img_w

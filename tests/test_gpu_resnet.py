@@ -1,0 +1,143 @@
+"""GPU parity tests of the ResNet50+ConvDet path (BASELINE.json config 5):
+the BN fold kernel, the residual-add conv epilogue, the builder graph and the native plan
+(SQDET_ARCH_RESNET50) against oracle/resnet_oracle.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import resnet_oracle as R
+from oracle import sqdet_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _close(got, ref, dtype, what):
+    got = got.float().cpu().numpy()
+    ref = ref.numpy() if isinstance(ref, torch.Tensor) else ref
+    assert got.shape == ref.shape, what
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    tol = 1e-3 * scale + 1e-5 if dtype == torch.float32 else 1e-2 * scale + 1e-3   # north_star: 1e-3 rel in fp32
+    assert err <= tol, "%s: max err %g vs scale %g" % (what, err, scale)
+
+
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_fold_batchnorm_kernel(with_bias):
+    from squeezedet_amd import ops
+    g = torch.Generator().manual_seed(7)
+    k, cin, cout = 3, 24, 40
+    w = torch.randn(k, k, cin, cout, generator=g)
+    cb = torch.randn(cout, generator=g) if with_bias else None
+    gamma, var = torch.rand(cout, generator=g) + 0.5, torch.rand(cout, generator=g) + 0.5
+    beta, mean = torch.randn(cout, generator=g), torch.randn(cout, generator=g)
+    wf, bf = ops.fold_batchnorm(w.to(DEV), cb.to(DEV) if with_bias else None, gamma.to(DEV), beta.to(DEV), mean.to(DEV),
+                                var.to(DEV), R.BN_EPS)
+    rw, rb = R.fold_batchnorm(w, cb, gamma, beta, mean, var)
+    # same float32 operations in the same order; the device sqrt/divide may differ by an ulp
+    assert torch.allclose(wf.cpu(), rw, rtol=5e-7, atol=0)
+    assert torch.allclose(bf.cpu(), rb, rtol=5e-7, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("shape", [(1, 13, 17, 64, 256, 1), (2, 9, 11, 256, 1024, 1), (1, 8, 12, 32, 48, 3)],
+                         ids=["64->256", "256->1024", "3x3"])
+def test_conv_residual_add_epilogue(dtype, shape):
+    """sqdet_conv2d_add_nhwc_fwd: y = relu(conv(x) + b + y), the residual add of resnet50_convDet.py:55."""
+    from squeezedet_amd import ops
+    n, h, w, cin, cout, k = shape
+    st = "fp16" if dtype == torch.float16 else "fp32"
+    g = torch.Generator().manual_seed(11)
+    x = O._round_storage(torch.randn(n, h, w, cin, generator=g), st)
+    sc = O._round_storage(torch.randn(n, h, w, cout, generator=g), st)
+    wt = O._round_storage(torch.randn(k, k, cin, cout, generator=g) / (k * cin ** 0.5), st)
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = O._round_storage(torch.relu(O.conv_layer(x, wt, b, 1, "SAME", False, "fp32") + sc), st)
+    out = sc.to(DEV, dtype).contiguous()
+    y = ops.conv2d_nhwc(x.to(DEV, dtype), ops.pack_conv_weights(wt.to(DEV), dtype), b.to(DEV), 1, "SAME", True, out=out,
+                        accumulate=True)
+    assert y.data_ptr() == out.data_ptr()
+    _close(y, ref, dtype, "conv+add+relu")
+
+
+def _model(dtype, batch, size, seed=0):
+    import squeezedet_amd as S
+    from squeezedet_amd import nets
+    mc = S.kitti_res50_config_for_input(*size)
+    mc.LOAD_PRETRAINED_MODEL = False
+    mc.BATCH_SIZE = batch
+    m = nets.ResNet50ConvDet(mc, gpu_id="0", dtype=dtype)
+    params = R.init_params(seed=seed)
+    m.load_params(params)
+    return m, mc, params
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+def test_resnet50_block_by_block_vs_oracle(dtype):
+    """Builder-graph path: conv1, pool1 and every residual block output against the oracle's."""
+    size = (135, 200)
+    st = "fp16" if dtype == torch.float16 else "fp32"
+    m, mc, params = _model(dtype, 2, size)
+    x = O.synthetic_images(2, size[0], size[1], seed=1, storage=st)
+    col = {}
+    R.forward(params, x, st, collect=col)
+    nodes, stack, seen = {}, [m.preds], set()
+    while stack:
+        nd = stack.pop()
+        if nd in seen:
+            continue
+        seen.add(nd)
+        if nd.name in col and nd.op in ("conv_bn", "pool", "add_relu", "conv"):
+            nodes[nd.name] = nd
+        stack.extend(nd.inputs)
+    assert set(nodes) == set(col)
+    names = list(col)
+    outs = m.run([nodes[n] for n in names], {m.image_input: x}, use_plan=False)
+    for n, got in zip(names, outs):
+        _close(got, col[n], dtype, n)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+def test_resnet50_plan_equals_graph_and_oracle(dtype):
+    """Native plan (SQDET_ARCH_RESNET50: lazy BN fold + in-place residual epilogue) == builder graph bit
+    for bit, both within tolerance of the oracle; then detections through interpret_output."""
+    size = (135, 200)
+    st = "fp16" if dtype == torch.float16 else "fp32"
+    m, mc, params = _model(dtype, 2, size, seed=2)
+    x = O.synthetic_images(2, size[0], size[1], seed=4, storage=st)
+    ref = R.forward(params, x, st)
+    (pg,) = m.run([m.preds], {m.image_input: x}, use_plan=False)
+    (pp,) = m.run([m.preds], {m.image_input: x}, use_plan=True)
+    assert torch.equal(pg, pp)
+    _close(pp, ref, dtype, "preds")
+    # a parameter update re-folds: scale one gamma, plan and graph must follow
+    name = "conv4_x/res4b/res4b_branch2/res4b_branch2b/gamma"
+    params2 = dict(params)
+    params2[name] = params[name] * 1.5
+    m.load_params({name: params2[name]})
+    ref2 = R.forward(params2, x, st)
+    (pp2,) = m.run([m.preds], {m.image_input: x}, use_plan=True)
+    assert not torch.equal(pp2, pp)
+    _close(pp2, ref2, dtype, "preds after gamma update")
+    # decode + filter run on the plan's preds like every other net
+    boxes, probs, cls = m.detect(x)
+    r = O.interpret_output(pp2.float().cpu().numpy(), mc)
+    assert np.allclose(boxes.cpu().numpy(), r["det_boxes"], atol=1e-3)
+    assert np.allclose(probs.cpu().numpy(), r["det_probs"], atol=1e-5)
+    assert (cls.cpu().numpy() == r["det_class"]).mean() > 0.999      # equal up to exact class-score ties
+
+
+def test_resnet50_full_size_properties():
+    """BASELINE.json config 5 shape (375x1242, batch 8, fp16) on the plan: finite, deterministic,
+    per-image independence (image i alone gives the same preds as inside the batch)."""
+    m, mc, params = _model(torch.float16, 8, (375, 1242))
+    x = O.synthetic_images(8, 375, 1242, seed=9, storage="fp16")
+    (p1,) = m.run([m.preds], {m.image_input: x})
+    (p2,) = m.run([m.preds], {m.image_input: x})
+    assert tuple(p1.shape) == (8, 24, 78, 72)
+    assert torch.isfinite(p1.float()).all()
+    assert torch.equal(p1, p2)
+    assert float(p1.float().abs().max()) > 0.1
+    m1, _, _ = _model(torch.float16, 1, (375, 1242))
+    (q,) = m1.run([m1.preds], {m1.image_input: x[5:6]})
+    assert torch.equal(q[0], p1[5])
