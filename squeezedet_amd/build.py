@@ -26,6 +26,7 @@ SOURCES = [
     ("stem.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("stem2.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("fire.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    ("fire2.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("pool.hip", []),
     ("bn.hip", ["-ffp-contract=off"]),
     ("postproc.hip", ["-ffp-contract=off"]),

@@ -322,9 +322,9 @@ static int g_fire_overlap = 0;  // measured on MI355X: the cross-stream fork/joi
 int fire_overlap() { return g_fire_overlap; }
 
 // Experiment knobs (0 = built-in heuristic): see tune() call sites.
-static const char* const kTuneNames[] = {"c1_waves", "c1_mt", "c1_min_tiles", "fire_fuse", "stem_algo"};
-constexpr int kNumTune = 5;
-static int g_tune[kNumTune] = {0, 0, 0, 0, 0};
+static const char* const kTuneNames[] = {"c1_waves", "c1_mt", "c1_min_tiles", "fire_fuse", "stem_algo", "dbg"};
+constexpr int kNumTune = 6;
+static int g_tune[kNumTune] = {0, 0, 0, 0, 0, 0};
 int tune(int which) { return g_tune[which]; }
 
 }  // namespace sqdet

@@ -81,9 +81,14 @@ __device__ __forceinline__ void store_couts(T* dst, const f32x4 (&v)[NT], int nt
 int conv_algo();
 // experiment knobs set through sqdet_set_option (0 = built-in heuristic)
 // fire_fuse: 0 heuristic, 1 always, 2 never; stem_algo: 0 strip kernel (in-register pool), 1 LDS-conv-tile kernel
-enum { TUNE_C1_WAVES = 0, TUNE_C1_MT = 1, TUNE_C1_MIN_TILES = 2, TUNE_FIRE_FUSE = 3, TUNE_STEM_ALGO = 4 };
+enum { TUNE_C1_WAVES = 0, TUNE_C1_MT = 1, TUNE_C1_MIN_TILES = 2, TUNE_FIRE_FUSE = 3, TUNE_STEM_ALGO = 4, TUNE_DBG = 5 };
 int tune(int which);
 
+// fire2.hip: persistent streaming fused fire for the large, few-channel modules
+bool fire_stream_eligible(int cin, int s, int e1, int e3, int dtype);
+int fire_stream_launch(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
+                       const float* b3, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
+                       hipStream_t st, bool* handled);
 int conv3x3_tile_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);
 int conv1x1_stream_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);
 

@@ -37,8 +37,12 @@ struct FireArgs {
   int e1_tiles, e3_tiles;   // cout tiles (all groups) of expand1x1 / expand3x3
 };
 
-template <typename T, int NTS, int NTW>
-__global__ __launch_bounds__(256, (NTW <= 3 ? 3 : 2)) void fire_fused(FireArgs a) {  // 3 waves/SIMD when 96 accumulators fit in 168 VGPRs
+// MT = tile rows per phase-B work item: 8 (a wave walks the whole tile per cout item) or 4 (two row
+// blocks per cout item -- the small fire modules have only 2-4 cout items, which left waves idle or
+// paired one 9-tap item with one 1-tap item; with MT = 4 every wave gets the same work and the
+// accumulators halve, so 4 workgroups fit on a CU instead of 2).
+template <typename T, int NTS, int NTW, int MT>
+__global__ __launch_bounds__(256, (MT == 4 ? 4 : (NTW <= 3 ? 3 : 2))) void fire_fused(FireArgs a) {  // 3 waves/SIMD when 96 accumulators fit in 168 VGPRs
   constexpr int KG = Tr<T>::KG;
   constexpr int KC = 4 * KG;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -126,12 +130,13 @@ __global__ __launch_bounds__(256, (NTW <= 3 ? 3 : 2)) void fire_fused(FireArgs a
   __syncthreads();
 
   // ---------------------------------------------------------------- phase B: expand3x3 + expand1x1
-  constexpr int MT = FROWS;
+  constexpr int RB = FROWS / MT;   // row blocks per cout item
   T* y = reinterpret_cast<T*>(a.y);
   const int ox = ox0 + j;
   const int ctot = a.E1 + a.E3;
   const int n3 = a.e3_tiles / NTW, n1 = a.e1_tiles / NTW;
-  for (int item = wave; item < n3 + n1; item += 4) {
+  for (int witem = wave; witem < (n3 + n1) * RB; witem += 4) {   // heavy (9-tap) items first, then the 1-tap ones
+    const int item = witem / RB, m0 = (witem - item * RB) * MT;
     const bool is3 = item < n3;
     const int tile0 = (is3 ? item : item - n3) * NTW;
     const int group = tile0 / a.e_nt, n0 = tile0 - group * a.e_nt;
@@ -173,8 +178,8 @@ __global__ __launch_bounds__(256, (NTW <= 3 ? 3 : 2)) void fire_fused(FireArgs a
       i32x4 bf[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int slot = g ^ ((h0 + m) & 3);
-        bf[m] = *reinterpret_cast<const i32x4*>(lchunk + (P0 + (FCOLS + 2) * m) * 64 + (slot << 4));
+        const int slot = g ^ ((h0 + m0 + m) & 3);
+        bf[m] = *reinterpret_cast<const i32x4*>(lchunk + (P0 + (FCOLS + 2) * (m0 + m)) * 64 + (slot << 4));
       }
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256, (NTW <= 3 ? 3 : 2)) void fire_fused(FireArgs a
     if (ox < a.W) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int oy = oy0 + m;
+        const int oy = oy0 + m0 + m;
         if (oy >= a.H) break;
         T* dst = y + (((size_t)n * a.H + oy) * a.W + ox) * ctot + coff + cb;
         f32x4 v[NTW];
@@ -220,10 +225,21 @@ __global__ __launch_bounds__(256, (NTW <= 3 ? 3 : 2)) void fire_fused(FireArgs a
 template <typename T, int NTS>
 static bool dispatch_fire_ntw(const FireArgs& a, int ntw, size_t lds, hipStream_t st) {
   const dim3 grid((unsigned)(a.N * a.tiles_x * a.tiles_y));
+  // few cout items (fire2..5: 2 or 4): split the tile rows too, so all four waves carry equal work
+  const bool split_rows = (a.e3_tiles + a.e1_tiles) / ntw <= 4;
   switch (ntw) {
-    case 2: hipLaunchKernelGGL((fire_fused<T, NTS, 2>), grid, dim3(256), lds, st, a); return true;
-    case 3: hipLaunchKernelGGL((fire_fused<T, NTS, 3>), grid, dim3(256), lds, st, a); return true;
-    case 4: hipLaunchKernelGGL((fire_fused<T, NTS, 4>), grid, dim3(256), lds, st, a); return true;
+    case 2:
+      if (split_rows) hipLaunchKernelGGL((fire_fused<T, NTS, 2, 4>), grid, dim3(256), lds, st, a);
+      else hipLaunchKernelGGL((fire_fused<T, NTS, 2, 8>), grid, dim3(256), lds, st, a);
+      return true;
+    case 3:
+      if (split_rows) hipLaunchKernelGGL((fire_fused<T, NTS, 3, 4>), grid, dim3(256), lds, st, a);
+      else hipLaunchKernelGGL((fire_fused<T, NTS, 3, 8>), grid, dim3(256), lds, st, a);
+      return true;
+    case 4:
+      if (split_rows) hipLaunchKernelGGL((fire_fused<T, NTS, 4, 4>), grid, dim3(256), lds, st, a);
+      else hipLaunchKernelGGL((fire_fused<T, NTS, 4, 8>), grid, dim3(256), lds, st, a);
+      return true;
     default: return false;
   }
 }
@@ -243,6 +259,7 @@ static bool dispatch_fire(const FireArgs& a, int nts, int ntw, size_t lds, hipSt
 // Same checks as fire_fused_launch, for the executor's plan-time decision.
 bool fire_fused_eligible(int cin, int s, int e1, int e3, int dtype) {
   if (conv_algo() != 0) return false;
+  if (tune(TUNE_FIRE_FUSE) != 3 && fire_stream_eligible(cin, s, e1, e3, dtype)) return true;
   const int esz = dtype == SQDET_F16 ? 2 : 4;
   const ConvGeom gs = conv_geom(1, cin, s, dtype), g1 = conv_geom(1, s, e1, dtype), g3 = conv_geom(3, s, e3, dtype);
   if (gs.gather || g1.gather || g3.gather || gs.ngroups != 1) return false;
@@ -261,6 +278,10 @@ int fire_fused_launch(const void* x, const void* ws, const float* bs, const void
                       hipStream_t st, bool* handled) {
   *handled = false;
   if (conv_algo() != 0) return SQDET_OK;
+  if (tune(TUNE_FIRE_FUSE) != 3) {   // large maps with few channels: the persistent streaming kernel (fire2.hip)
+    const int rc = fire_stream_launch(x, ws, bs, w1, b1, w3, b3, y, n, h, w, cin, s, e1, e3, dtype, st, handled);
+    if (rc != SQDET_OK || *handled) return rc;
+  }
   const int esz = dtype == SQDET_F16 ? 2 : 4;
   const ConvGeom gs = conv_geom(1, cin, s, dtype), g1 = conv_geom(1, s, e1, dtype), g3 = conv_geom(3, s, e3, dtype);
   if (gs.gather || g1.gather || g3.gather || gs.ngroups != 1) return SQDET_OK;

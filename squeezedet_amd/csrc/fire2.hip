@@ -1,0 +1,352 @@
+// Fused fire module, persistent streaming form, for the LARGE feature maps with FEW channels
+// (fire2..fire5 of SqueezeDet: squeeze <= 32 fp16 channels, expand 64/128; reference
+// src/nets/squeezeDet.py:81-106).  These modules are HBM-bound (fire2: 58 FLOP/B): the kernel is built
+// so that the only thing a workgroup ever waits for is the input stream.
+//
+//   * PERSISTENT workgroups (one or two per CU) walk 8 x 16 output tiles; every XCD owns a contiguous
+//     band of tiles so the halo re-reads of neighbouring tiles hit that XCD's L2.
+//   * A wave owns one PAIR of 16-cout MFMA tiles of expand3x3 and of expand1x1 (8 consecutive output
+//     channels per lane -> 16-byte stores) for HALF of the tile rows, and keeps ALL its weights -- 18
+//     expand3x3 + 2 expand1x1 fragments -- in REGISTERS for its whole life: the steady state reads no
+//     weights at all.  (The squeeze weights live in LDS, copied once.)
+//   * Software pipeline per tile:   A  squeeze MFMAs on the 10 x 18 halo from the input fragments
+//     PREFETCHED during the previous tile, bias + ReLU -> LDS squeeze tile (double-buffered);
+//     P  issue the 16-byte loads of the NEXT tile's halo into registers;   barrier;
+//     B  expand3x3 (9 taps) + expand1x1 (centre tap) from LDS, bias + ReLU, stores.
+//     One barrier per tile; the input loads have a whole phase B (+ the other workgroup) to land.
+// Accumulation order equals conv3x3_tile / conv1x1 (chunk-major, taps 0..8): results are bitwise
+// those of the unfused kernels.
+#include "conv_common.h"
+
+namespace sqdet {
+
+constexpr int SROWS = 8, SCOLS = 16;
+constexpr int SHP = (SROWS + 2) * (SCOLS + 2);   // 180 halo pixels
+constexpr int SBLK = (SHP + 15) / 16;            // 12 pixel blocks of 16
+constexpr int STILE = SHP * 64;                  // bytes of one squeeze tile (one 64-byte chunk per pixel)
+
+struct FireSArgs {
+  const void* x;
+  void* y;
+  const void *ws, *w1, *w3;
+  const float *bs, *b1, *b3;
+  int N, H, W, Cin, S, E;      // E = expand1x1 = expand3x3 filters
+  int tiles_x, tiles_y, ntiles;
+  int x_pieces;                // Cin*sizeof(T)/16
+  unsigned x_bytes, y_bytes;   // tensor sizes (< 2^31: 32-bit buffer offsets)
+};
+
+template <typename T, int NCHX, int NTS, int NWAVES, int PF>
+__global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs a) {   // 2 waves per SIMD: 256 VGPRs
+  constexpr int KG = Tr<T>::KG;
+  constexpr int KC = 4 * KG;
+  constexpr int MB = (SBLK + NWAVES - 1) / NWAVES;   // halo pixel blocks per wave in phase A
+  constexpr int MT = SROWS / 2;                      // tile rows per wave in phase B
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* sq = lds;                           // [2][STILE]
+  unsigned char* wsl = lds + 2 * STILE;              // squeeze weights [NCHX][NTS][64 lanes][16 B]
+  unsigned char* w1l = wsl + NCHX * NTS * 1024;      // expand1x1 weights [E/16 tiles][64 lanes][16 B]
+  float* bl = reinterpret_cast<float*>(w1l + (NWAVES / 4) * 4 * 1024);   // biases
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+
+  // ---- one-time set-up ------------------------------------------------------------------------
+  {
+    const i32x4* src = reinterpret_cast<const i32x4*>(a.ws);
+    for (int i = threadIdx.x; i < NCHX * NTS * 64; i += NWAVES * 64) reinterpret_cast<i32x4*>(wsl)[i] = src[i];
+    const i32x4* src1 = reinterpret_cast<const i32x4*>(a.w1);
+    for (int i = threadIdx.x; i < (NWAVES / 4) * 4 * 64; i += NWAVES * 64) reinterpret_cast<i32x4*>(w1l)[i] = src1[i];
+    // biases -> LDS [b1 (E) | b3 (E) | bs (S)]: read back with ds_read (lgkmcnt).  A global bias load inside
+    // the tile loop would sit behind the prefetched input loads and the stores in the in-order vmcnt queue
+    // and drain them every time it is waited for.
+    for (int i = threadIdx.x; i < 2 * a.E + a.S; i += NWAVES * 64)
+      bl[i] = i < a.E ? a.b1[i] : (i < 2 * a.E ? a.b3[i - a.E] : a.bs[i - 2 * a.E]);
+    // channel padding of the squeeze tile (S*sizeof(T) < 64 bytes) is zero in both buffers, forever
+    const int s_pieces = a.S * (int)sizeof(T) / 16;
+    const int pad = 4 - s_pieces;
+    for (int idx = threadIdx.x; idx < 2 * SHP * pad; idx += NWAVES * 64) {
+      const int bsel = idx / (SHP * pad), r = idx - bsel * SHP * pad;
+      const int P = r / pad, q = s_pieces + (r - P * pad);
+      *reinterpret_cast<i32x4*>(sq + bsel * STILE + P * 64 + ((q ^ ((P >> 1) & 3)) << 4)) = i32x4{0, 0, 0, 0};
+    }
+  }
+  const int cp = wave >> 1, rh = wave & 1;           // cout pair, row half
+  const int m0 = rh * MT;
+  // This wave's two MFMA tiles t = 0,1 cover the 32 consecutive couts [cp*32, cp*32+32) with
+  //   tile row i  <->  cout cp*32 + 8*(i>>2) + 4*t + (i&3),
+  // so lane group g ends up with the 8 consecutive couts cp*32 + 8g + [0,8): one 16-byte store per pixel,
+  // and the four lane groups write 64 contiguous bytes per pixel per store instruction (measured
+  // 6.2-6.8 TB/s against 3.4-5.7 TB/s for lane-owned 32/64-byte runs, tools/microbench/store_patterns.hip).
+  // The packed weights hold cout c of a 64-cout group in tile (c%16)/4, row 4*(c/16) + c%4 (conv.hip
+  // pack_weights_kernel): every lane gathers its A-fragment row from there -- once, weights are resident.
+  int wsrc[2];   // i32x4 index of this lane's fragment data inside one (group, tap) block of 4 tiles, for t = 0,1
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int c = (cp & 1) * 32 + 8 * (j >> 2) + 4 * t + (j & 3);     // cout within the 64-cout group
+    wsrc[t] = ((c & 15) >> 2) * 64 + (4 * (c >> 4) + (c & 3)) + 16 * g;
+  }
+  const int group = cp >> 1;
+  i32x4 w3r[9][2];
+  {
+    const i32x4* p3 = reinterpret_cast<const i32x4*>(a.w3) + (size_t)group * 9 * 4 * 64;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      w3r[tap][0] = p3[tap * 4 * 64 + wsrc[0]];
+      w3r[tap][1] = p3[tap * 4 * 64 + wsrc[1]];
+    }
+  }
+  const int cb = cp * 32 + g * 8;                     // this lane's 8 consecutive couts (of both expand convs)
+
+  // tiles of this workgroup: XCD x (= blockIdx % 8) owns the contiguous band [x*per, (x+1)*per)
+  const int xcd = blockIdx.x & 7, lid = blockIdx.x >> 3, nl = gridDim.x >> 3;   // gridDim.x is a multiple of 8
+  const int per = (a.ntiles + 7) >> 3;
+  const int band_end = min(a.ntiles, (xcd + 1) * per);
+  int tile = xcd * per + lid;
+
+  // Raw buffer resources: an out-of-range offset makes a load return 0 (exactly the zero padding) and
+  // drops a store, so neither needs a branch -- and with branch-free memory instructions the compiler
+  // knows how many are in flight: its s_waitcnt for the prefetched input lets the stores issued after it
+  // stay outstanding instead of draining the whole in-order queue.
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xfffffff0u;
+  const int ctot = 2 * a.E;
+
+  // PF tiles of input are in flight (registers): xr[q] / inimg[q] belong to the tile processed q steps ahead.
+  // Loads are issued unconditionally (an invalid tile turns every offset out of range: no traffic, zeros)
+  // so the number of memory instructions per step is fixed and the waits stay exact.
+  i32x4 xr[PF][MB][NCHX];
+  bool inimgs[PF][MB];
+  auto issue_loads = [&](int tl, bool tile_ok, i32x4 (&xq)[MB][NCHX], bool (&inimg)[MB]) {
+    int b = tl;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y;
+    const int n = b / a.tiles_y;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int P = (wave + NWAVES * mb) * 16 + j;
+      const int r = P / (SCOLS + 2), c = P - r * (SCOLS + 2);
+      const int iy = ty * SROWS - 1 + r, ix = tx * SCOLS - 1 + c;
+      inimg[mb] = tile_ok && P < SHP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const unsigned base = (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + g * KG) * (int)sizeof(T));
+#pragma unroll
+      for (int c2 = 0; c2 < NCHX; ++c2)
+        xq[mb][c2] = __builtin_amdgcn_raw_buffer_load_b128(rx, (inimg[mb] && c2 * 4 + g < a.x_pieces) ? base + c2 * 64 : OOB, 0, 0);
+    }
+  };
+
+  auto step = [&](int tile, i32x4 (&xq)[MB][NCHX], bool (&inimg)[MB], unsigned char* sqb) {
+    // ---------------- phase A: squeeze on the halo, from the prefetched fragments ----------------
+    {
+      f32x4 acc[MB][NTS];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int t = 0; t < NTS; ++t) acc[mb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NCHX; ++c) {
+        i32x4 af[NTS];
+#pragma unroll
+        for (int t = 0; t < NTS; ++t) af[t] = *reinterpret_cast<const i32x4*>(wsl + ((c * NTS + t) * 64 + lane) * 16);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int t = 0; t < NTS; ++t) mma16<T>(acc[mb][t], af[t], xq[mb][c]);
+      }
+#pragma unroll
+      for (int t = 0; t < NTS; ++t) {
+        const int ch0 = g * 4 * NTS + 4 * t;
+        if (ch0 < a.S) {
+          const f32x4 biass = *reinterpret_cast<const f32x4*>(bl + 2 * a.E + ch0);
+          const int q = ch0 / KG;
+          const int sub = (ch0 - q * KG) * (int)sizeof(T);
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            const int P = (wave + NWAVES * mb) * 16 + j;
+            if (P < SHP) {
+              f32x4 v = acc[mb][t] + biass;
+              v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+              if (!inimg[mb]) v = f32x4{0.f, 0.f, 0.f, 0.f};   // SAME padding of the squeeze tensor
+              store4<T>(reinterpret_cast<T*>(sqb + P * 64 + ((q ^ ((P >> 1) & 3)) << 4) + sub), v);
+            }
+          }
+        }
+      }
+    }
+    // output coordinates of THIS tile (before xr / inimg are reused for the next one)
+    int b = tile;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y;
+    const int n = b / a.tiles_y;
+    // ---------------- prefetch: the halo of the tile PF steps ahead, into the registers just consumed ----------------
+    issue_loads(tile + PF * nl, tile + PF * nl < band_end, xq, inimg);
+    __syncthreads();
+    // ---------------- phase B: expand3x3, then expand1x1, on rows [m0, m0 + MT) ----------------
+    const int ox = tx * SCOLS + j;
+    const unsigned ybase = (unsigned)(((((n * a.H + ty * SROWS + m0) * a.W + ox) * ctot) + cb) * (int)sizeof(T));
+    const unsigned yrow = (unsigned)(a.W * ctot * (int)sizeof(T));
+    auto epilogue = [&](f32x4 (&acc)[MT][2], const float* bias_lds, unsigned off0) {
+      f32x4 bias[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const f32x4*>(bias_lds + cb + t * 4);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const unsigned off = (ox < a.W && ty * SROWS + m0 + m < a.H) ? off0 + m * yrow : OOB;   // OOB stores are dropped
+        f32x4 v[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          v[t] = acc[m][t] + bias[t];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[t][e] = fmaxf(v[t][e], 0.f);
+        }
+        if constexpr (sizeof(T) == 2) {
+          const f16x8 h = {(f16)v[0][0], (f16)v[0][1], (f16)v[0][2], (f16)v[0][3], (f16)v[1][0], (f16)v[1][1], (f16)v[1][2], (f16)v[1][3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, h), ry, off, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v[0]), ry, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v[1]), ry, off == OOB ? OOB : off + 16, 0, 0);
+        }
+      }
+    };
+    {
+      f32x4 acc3[MT][2];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc3[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // B fragments double-buffered by hand, one tap ahead; the scheduling barriers keep the compiler
+      // from hoisting all 36 LDS reads to the top (that spilled registers into the tile loop, and every
+      // scratch reload drains the in-order vmcnt queue, i.e. waits for the prefetched input)
+      // jo / go: j and g behind an empty asm, so the 36 per-(tap,row) LDS addresses are recomputed per tile
+      // (a handful of VALU ops) instead of being hoisted out of the tile loop into 36 live registers
+      int jo = j, go = g;
+      asm volatile("" : "+v"(jo), "+v"(go));
+      auto load_tap = [&](int tap, i32x4 (&bf)[MT]) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const int P0 = dy * (SCOLS + 2) + jo + dx;
+        const int h0 = P0 >> 1;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          bf[m] = *reinterpret_cast<const i32x4*>(sqb + (P0 + (SCOLS + 2) * (m0 + m)) * 64 + ((go ^ ((h0 + m0 + m) & 3)) << 4));
+      };
+      i32x4 bfa[MT], bfb[MT];
+      load_tap(0, bfa);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        i32x4 (&cur)[MT] = (tap & 1) ? bfb : bfa;
+        i32x4 (&nxt)[MT] = (tap & 1) ? bfa : bfb;
+        if (tap + 1 < 9) load_tap(tap + 1, nxt);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) mma16<T>(acc3[m][t], w3r[tap][t], cur[m]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      epilogue(acc3, bl + a.E, ybase + a.E * (int)sizeof(T));   // expand3x3 -> channels [E, 2E)
+    }
+    {
+      f32x4 acc1[MT][2];
+      i32x4 w1f[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) w1f[t] = *reinterpret_cast<const i32x4*>(w1l + (group * 4 * 64 + wsrc[t]) * 16);
+      const int P0 = (SCOLS + 2) + j + 1;             // centre tap
+      const int h0 = P0 >> 1;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const i32x4 bf = *reinterpret_cast<const i32x4*>(sqb + (P0 + (SCOLS + 2) * (m0 + m)) * 64 + ((g ^ ((h0 + m0 + m) & 3)) << 4));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc1[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          mma16<T>(acc1[m][t], w1f[t], bf);
+        }
+      }
+      epilogue(acc1, bl, ybase);                      // expand1x1 -> channels [0, E)
+    }
+  };
+
+  issue_loads(tile, tile < band_end, xr[0], inimgs[0]);
+  if constexpr (PF == 2) issue_loads(tile + nl, tile + nl < band_end, xr[1], inimgs[1]);
+  __syncthreads();                                    // squeeze weights / padding / biases visible
+  if constexpr (PF == 1) {
+    int buf = 0;
+    for (; tile < band_end; tile += nl, buf ^= 1) step(tile, xr[0], inimgs[0], sq + buf * STILE);
+  } else {
+    while (tile < band_end) {
+      step(tile, xr[0], inimgs[0], sq);
+      tile += nl;
+      if (tile >= band_end) break;
+      step(tile, xr[PF - 1], inimgs[PF - 1], sq + STILE);
+      tile += nl;
+    }
+  }
+}
+
+static bool stream_shape(int cin, int s, int e1, int e3, int dtype, int* nchx, int* nts, int* nwaves) {
+  if (conv_algo() != 0 || e1 != e3) return false;
+  const int esz = dtype == SQDET_F16 ? 2 : 4;
+  const ConvGeom gs = conv_geom(1, cin, s, dtype), g1 = conv_geom(1, s, e1, dtype), g3 = conv_geom(3, s, e3, dtype);
+  if (gs.gather || g1.gather || g3.gather || gs.ngroups != 1) return false;
+  if (g1.nchunk != 1 || g3.nchunk != 1 || g1.nt != 4 || g3.nt != 4) return false;   // squeeze fits one 64-byte chunk; E % 64 == 0
+  if (e1 % 64 != 0 || (g1.ngroups != 1 && g1.ngroups != 2)) return false;
+  if (!(gs.nt == 1 || gs.nt == 2)) return false;
+  if (!(gs.nchunk == 2 || gs.nchunk == 4)) return false;                              // input fragments stay in registers
+  if ((cin * esz) % 16 != 0 || (s * esz) % 16 != 0 || s % 4 != 0) return false;
+  *nchx = gs.nchunk; *nts = gs.nt; *nwaves = 4 * g1.ngroups;
+  return true;
+}
+
+bool fire_stream_eligible(int cin, int s, int e1, int e3, int dtype) {
+  int a, b, c;
+  return stream_shape(cin, s, e1, e3, dtype, &a, &b, &c);
+}
+
+template <typename T, int NCHX, int NTS, int NWAVES>
+static void launch_stream(const FireSArgs& a, hipStream_t st) {
+  const size_t lds = 2 * (size_t)STILE + (size_t)NCHX * NTS * 1024 + (size_t)(NWAVES / 4) * 4 * 1024 + (size_t)(2 * a.E + a.S) * 4;
+  // persistent: 8 waves per CU (the register-resident weights + prefetched input allow 2 per SIMD)
+  int grid = 256 * (8 / NWAVES);
+  if (grid > (a.ntiles + 7) / 8 * 8) grid = (a.ntiles + 7) / 8 * 8;
+  // two tiles of input in flight when their fragments fit the register budget next to the resident weights
+  if (tune(TUNE_DBG) != 8)   // (all shapes compile to <= 252 VGPRs without spills)
+    hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 2>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
+  else
+    hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 1>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
+}
+
+template <typename T>
+static bool dispatch_stream(const FireSArgs& a, int nchx, int nts, int nwaves, hipStream_t st) {
+#define SQDET_FS(NC, NS, NW) \
+  if (nchx == NC && nts == NS && nwaves == NW) { launch_stream<T, NC, NS, NW>(a, st); return true; }
+  SQDET_FS(2, 1, 4) SQDET_FS(4, 1, 4) SQDET_FS(2, 2, 4) SQDET_FS(4, 2, 4)
+  SQDET_FS(2, 1, 8) SQDET_FS(4, 1, 8) SQDET_FS(2, 2, 8) SQDET_FS(4, 2, 8)
+#undef SQDET_FS
+  return false;
+}
+
+// *handled = false: shape not covered (fire_fused_launch / the three separate convs take over).
+int fire_stream_launch(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
+                       const float* b3, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
+                       hipStream_t st, bool* handled) {
+  *handled = false;
+  int nchx, nts, nwaves;
+  if (!stream_shape(cin, s, e1, e3, dtype, &nchx, &nts, &nwaves)) return SQDET_OK;
+  FireSArgs a;
+  a.x = x; a.y = y; a.ws = ws; a.w1 = w1; a.w3 = w3; a.bs = bs; a.b1 = b1; a.b3 = b3;
+  a.N = n; a.H = h; a.W = w; a.Cin = cin; a.S = s; a.E = e1;
+  a.tiles_x = (w + SCOLS - 1) / SCOLS; a.tiles_y = (h + SROWS - 1) / SROWS;
+  const long nt = (long)n * a.tiles_x * a.tiles_y;
+  if (nt > 0x3fffffffL) return SQDET_OK;
+  a.ntiles = (int)nt;
+  const int esz = dtype == SQDET_F16 ? 2 : 4;
+  a.x_pieces = cin * esz / 16;
+  const long xb = (long)n * h * w * cin * esz, yb = (long)n * h * w * 2 * e1 * esz;
+  if (xb >= (1L << 31) || yb >= (1L << 31)) return SQDET_OK;   // 32-bit buffer offsets
+  a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb;
+  const bool ok = dtype == SQDET_F16 ? dispatch_stream<f16>(a, nchx, nts, nwaves, st) : dispatch_stream<float>(a, nchx, nts, nwaves, st);
+  if (!ok) return SQDET_OK;
+  SQDET_CHECK_HIP(hipGetLastError());
+  *handled = true;
+  return SQDET_OK;
+}
+
+}  // namespace sqdet

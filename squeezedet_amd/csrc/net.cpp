@@ -27,6 +27,7 @@ int fire_fused_launch(const void* x, const void* ws, const float* bs, const void
                       const float* b3, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
                       hipStream_t st, bool* handled);
 bool fire_fused_eligible(int cin, int s, int e1, int e3, int dtype);
+bool fire_stream_eligible(int cin, int s, int e1, int e3, int dtype);
 int conv_algo();
 int fire_overlap();
 int tune(int which);
@@ -331,7 +332,8 @@ void fuse_fires(sqdet_net* net, size_t esz) {
                       in[i].out_buf == BUF_S && in[i + 1].in_buf == BUF_S && in[i + 2].in_buf == BUF_S && in[i].k == 1 &&
                       in[i + 1].k == 1 && in[i + 2].k == 3 && in[i + 1].out_buf == in[i + 2].out_buf;
     const long pixels = (long)net->batch * in[i].h * in[i].w;
-    if (!trio || !(tune(3) == 1 || pixels <= 100000) ||
+    const bool streams = trio && tune(3) != 3 && fire_stream_eligible(in[i].cin, in[i].cout, in[i + 1].cout, in[i + 2].cout, net->dtype);
+    if (!trio || !(tune(3) == 1 || pixels <= 100000 || streams) ||
         !fire_fused_eligible(in[i].cin, in[i].cout, in[i + 1].cout, in[i + 2].cout, net->dtype)) {
       out.push_back(in[i]);
       continue;

@@ -10,6 +10,9 @@
 //     the strip starts at conv column 2*p0 - pad so windows never straddle strips;
 //   * the VERTICAL max keeps one previous row in registers: out[q] = max(h[2q], h[2q+1], h[2q+2]);
 //   * lanes j = 0,2,..,12 store the 7 pooled pixels, 16 channels (32 B in fp16) per lane.
+//   * ReLU is applied once to the pooled value (it commutes with
+//     max and with the monotonic fp16 rounding), the vertical max runs before the horizontal one: the
+//     epilogue is ~1/3 of the VALU work of the straightforward order -- this kernel is VALU-bound.
 // Conv activations never touch LDS or HBM; LDS holds only the 35 x 117 x 3 input patch (24.6 KB,
 // 6 workgroups per CU).  Out-of-range conv pixels are -inf (TF SAME max-pool never picks padding).
 #include "stem.h"
@@ -27,14 +30,37 @@ template <> struct Pk<float> { static constexpr int R = 16; };
 
 template <typename T>
 __device__ __forceinline__ unsigned int pkmax(unsigned int a, unsigned int b);
+// Written as the instruction itself: through fmaxf / elementwise_max the compiler first canonicalises
+// both operands (one extra v_pk_max_f16 x, x per input), which more than doubled the pooling VALU work.
 template <>
 __device__ __forceinline__ unsigned int pkmax<f16>(unsigned int a, unsigned int b) {
-  typedef f16 h2 __attribute__((ext_vector_type(2)));
-  return __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b)));
+  unsigned int r;
+  asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 template <>
 __device__ __forceinline__ unsigned int pkmax<float>(unsigned int a, unsigned int b) {
-  return __float_as_uint(fmaxf(__uint_as_float(a), __uint_as_float(b)));
+  unsigned int r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// First chunk of a K loop: the accumulator input is the inline constant 0 (no register zeroing).
+template <typename T>
+__device__ __forceinline__ f32x4 mma16_first(const i32x4& a, const i32x4& b);
+template <>
+__device__ __forceinline__ f32x4 mma16_first<f16>(const i32x4& a, const i32x4& b) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b),
+                                                f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4 mma16_first<float>(const i32x4& a, const i32x4& b) {
+  const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+  f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], acc, 0, 0, 0);
+  return acc;
 }
 
 template <typename T, int KS, int NT, bool ALIGNED4>
@@ -46,7 +72,6 @@ __global__ __launch_bounds__(256) void stem_strip(StemArgs a) {
   constexpr int LROW = (TC * 3 + 3) / 4 * 4;        // LDS row stride in elements (4-byte aligned rows)
   constexpr int NCHK = (KS * KS * 3 + KC - 1) / KC;
   constexpr bool PRE = NCHK * KG <= 16;
-  constexpr int R = Pk<T>::R;
   static_assert(NT == 4 || NT == 6, "16*NT couts");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   T* lin = reinterpret_cast<T*>(lds);
@@ -160,12 +185,19 @@ __global__ __launch_bounds__(256) void stem_strip(StemArgs a) {
   const bool col_ok = cx >= 0 && cx < a.Wc;
   const unsigned int NEG = sizeof(T) == 2 ? 0xfc00fc00u : 0xff800000u;   // -inf (packed)
 
-  // conv row rr (relative to cy0) -> horizontally pooled registers h[RT]
-  auto conv_row = [&](int rr, unsigned int (&h)[RT]) {
+  // conv row rr (relative to cy0) -> conv + bias of this lane's column, packed to storage type, NOT yet
+  // rectified (ReLU commutes with max and with the monotonic f16 rounding: it is applied once, to the
+  // pooled value).  Rows outside the conv map are -inf without computing anything (wave-uniform).
+  const bool edge_cols = cx0 < 0 || cx0 + ZCC > a.Wc;     // workgroup-uniform: some lanes sit outside the conv map
+  auto conv_row = [&](int rr, unsigned int (&v)[RT]) {
+    const int cy = cy0 + rr;
+    if (cy < 0 || cy >= a.Hc) {
+#pragma unroll
+      for (int i = 0; i < RT; ++i) v[i] = NEG;
+      return;
+    }
     const T* patch = lin + (2 * rr) * LROW + (2 * cc) * 3;
     f32x4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < NCHK; ++c) {
       TV bv;
@@ -178,51 +210,53 @@ __global__ __launch_bounds__(256) void stem_strip(StemArgs a) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const i32x4 af = PRE ? afr[PRE ? c * NT + t : 0] : wp[(c * NT + t) * 64];
-        mma16<T>(acc[t], af, bfrag);
+        if (c == 0) acc[t] = mma16_first<T>(af, bfrag);
+        else mma16<T>(acc[t], af, bfrag);
       }
     }
-    const int cy = cy0 + rr;
-    const bool valid = col_ok && cy >= 0 && cy < a.Hc;
-    unsigned int v[RT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      f32x4 s = acc[t] + bias[t];
-      s[0] = fmaxf(s[0], 0.f); s[1] = fmaxf(s[1], 0.f); s[2] = fmaxf(s[2], 0.f); s[3] = fmaxf(s[3], 0.f);
+      acc[t] += bias[t];    // after the accumulation, like every other conv kernel here (bitwise-equal results)
       if constexpr (sizeof(T) == 2) {
         typedef f16 h2 __attribute__((ext_vector_type(2)));
-        const h2 lo = {(f16)s[0], (f16)s[1]}, hi = {(f16)s[2], (f16)s[3]};
-        v[2 * t] = valid ? __builtin_bit_cast(unsigned int, lo) : NEG;
-        v[2 * t + 1] = valid ? __builtin_bit_cast(unsigned int, hi) : NEG;
+        const h2 lo = {(f16)acc[t][0], (f16)acc[t][1]}, hi = {(f16)acc[t][2], (f16)acc[t][3]};
+        v[2 * t] = __builtin_bit_cast(unsigned int, lo);
+        v[2 * t + 1] = __builtin_bit_cast(unsigned int, hi);
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * t + e] = valid ? __float_as_uint(s[e]) : NEG;
+        for (int e = 0; e < 4; ++e) v[4 * t + e] = __float_as_uint(acc[t][e]);
       }
     }
-    // horizontal 3-tap max: lane j takes columns j, j+1, j+2 of its 16-lane row (DPP row_shl)
+    if (edge_cols && !col_ok) {
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-      const unsigned int s1 = (unsigned int)__builtin_amdgcn_update_dpp((int)NEG, (int)v[i], 0x101, 0xf, 0xf, false);
-      const unsigned int s2 = (unsigned int)__builtin_amdgcn_update_dpp((int)NEG, (int)v[i], 0x102, 0xf, 0xf, false);
-      h[i] = pkmax<T>(v[i], pkmax<T>(s1, s2));
+      for (int i = 0; i < RT; ++i) v[i] = NEG;
     }
   };
 
-  // ---- walk the conv rows; vertical max with one row kept in registers ----
+  // ---- walk the conv rows: vertical 3-max first (plain registers), then ONE horizontal 3-tap max per
+  // pooled row (lane j takes columns j, j+1, j+2 of its 16-lane row: DPP row_shl), then ReLU ----
   T* y = reinterpret_cast<T*>(a.y);
   const int pxl = ZSP * wave + (j >> 1);                  // pooled column within the tile
   const int px = px0 + pxl;
   const bool store_lane = (j & 1) == 0 && j < 2 * ZSP && px < a.Wp && cb < a.Cout;
-  unsigned int prev[RT], ha[RT], hb[RT];
+  unsigned int prev[RT], va[RT], vb[RT];
   conv_row(0, prev);
 #pragma unroll 1
   for (int q = 0; q < ZPR; ++q) {
-    conv_row(2 * q + 1, ha);
-    conv_row(2 * q + 2, hb);
     const int py = py0 + q;
-    if (store_lane && py < a.Hp) {
-      unsigned int o[RT];
+    if (py >= a.Hp) break;                                // workgroup-uniform
+    conv_row(2 * q + 1, va);
+    conv_row(2 * q + 2, vb);
+    unsigned int o[RT];
 #pragma unroll
-      for (int i = 0; i < RT; ++i) o[i] = pkmax<T>(prev[i], pkmax<T>(ha[i], hb[i]));
+    for (int i = 0; i < RT; ++i) {
+      const unsigned int m = pkmax<T>(prev[i], pkmax<T>(va[i], vb[i]));
+      const unsigned int s1 = (unsigned int)__builtin_amdgcn_update_dpp((int)NEG, (int)m, 0x101, 0xf, 0xf, false);
+      const unsigned int s2 = (unsigned int)__builtin_amdgcn_update_dpp((int)NEG, (int)m, 0x102, 0xf, 0xf, false);
+      o[i] = pkmax<T>(pkmax<T>(m, pkmax<T>(s1, s2)), 0u);   // 0u = +0.0 (packed): the ReLU
+      prev[i] = vb[i];
+    }
+    if (store_lane) {
       unsigned int* dst = reinterpret_cast<unsigned int*>(y + (((size_t)n * a.Hp + py) * a.Wp + px) * a.y_cstride + a.y_coffset + cb);
 #pragma unroll
       for (int i = 0; i < RT; i += 4) {
@@ -231,8 +265,6 @@ __global__ __launch_bounds__(256) void stem_strip(StemArgs a) {
           *reinterpret_cast<i32x4*>(dst + i) = i32x4{(int)o[i], (int)o[i + 1], (int)o[i + 2], (int)o[i + 3]};
       }
     }
-#pragma unroll
-    for (int i = 0; i < RT; ++i) prev[i] = hb[i];
   }
 }
 
