@@ -289,7 +289,8 @@ static bool stream_shape(int cin, int s, int e1, int e3, int dtype, int* nchx, i
   if (g1.nchunk != 1 || g3.nchunk != 1 || g1.nt != 4 || g3.nt != 4) return false;   // squeeze fits one 64-byte chunk; E % 64 == 0
   if (e1 % 64 != 0 || (g1.ngroups != 1 && g1.ngroups != 2)) return false;
   if (!(gs.nt == 1 || gs.nt == 2)) return false;
-  if (!(gs.nchunk == 2 || gs.nchunk == 4)) return false;                              // input fragments stay in registers
+  // input fragments stay in registers: 2 or 4 chunks with two tiles in flight, 8 chunks (8-wave form only) with one
+  if (!(gs.nchunk == 2 || gs.nchunk == 4 || (gs.nchunk == 8 && g1.ngroups == 2))) return false;
   if ((cin * esz) % 16 != 0 || (s * esz) % 16 != 0 || s % 4 != 0) return false;
   *nchx = gs.nchunk; *nts = gs.nt; *nwaves = 4 * g1.ngroups;
   return true;
@@ -307,10 +308,13 @@ static void launch_stream(const FireSArgs& a, hipStream_t st) {
   int grid = 256 * (8 / NWAVES);
   if (grid > (a.ntiles + 7) / 8 * 8) grid = (a.ntiles + 7) / 8 * 8;
   // two tiles of input in flight when their fragments fit the register budget next to the resident weights
-  if (tune(TUNE_DBG) != 8)   // (all shapes compile to <= 252 VGPRs without spills)
-    hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 2>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
-  else
-    hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 1>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
+  if constexpr (NCHX <= 4) {   // (compile to <= 252 VGPRs without spills)
+    if (tune(TUNE_DBG) != 8) {
+      hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 2>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 1>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
 }
 
 template <typename T>
@@ -318,7 +322,7 @@ static bool dispatch_stream(const FireSArgs& a, int nchx, int nts, int nwaves, h
 #define SQDET_FS(NC, NS, NW) \
   if (nchx == NC && nts == NS && nwaves == NW) { launch_stream<T, NC, NS, NW>(a, st); return true; }
   SQDET_FS(2, 1, 4) SQDET_FS(4, 1, 4) SQDET_FS(2, 2, 4) SQDET_FS(4, 2, 4)
-  SQDET_FS(2, 1, 8) SQDET_FS(4, 1, 8) SQDET_FS(2, 2, 8) SQDET_FS(4, 2, 8)
+  SQDET_FS(2, 1, 8) SQDET_FS(4, 1, 8) SQDET_FS(2, 2, 8) SQDET_FS(4, 2, 8) SQDET_FS(8, 1, 8) SQDET_FS(8, 2, 8)
 #undef SQDET_FS
   return false;
 }

@@ -42,6 +42,46 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T
   }
 }
 
+// 3x3 window, any stride (every pool of the reference's nets): the nine 16-byte loads of an output are
+// issued back to back from clamped addresses and only then reduced -- with a run-time window size the
+// loop above waits for each load before the next max, i.e. pays nine memory latencies per output.
+template <typename T>
+__device__ __forceinline__ typename PoolTr<T>::vec vmax(typename PoolTr<T>::vec a, typename PoolTr<T>::vec b) {
+  return __builtin_elementwise_max(a, b);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
+                                                       int C, int stride, int pt, int pl, int Ho, int Wo) {
+  constexpr int V = PoolTr<T>::V;
+  typedef typename PoolTr<T>::vec vec;
+  const int cv = C / V;
+  const size_t total = (size_t)N * Ho * Wo * cv;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cv);
+    size_t p = idx / cv;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const int y0 = oy * stride - pt, x0 = ox * stride - pl;
+    vec v[9];
+    bool ok[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int iy = y0 + t / 3, ix = x0 + t % 3;
+      ok[t] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);   // clamped: a valid address, masked below
+      v[t] = *reinterpret_cast<const vec*>(x + (((size_t)n * H + cy) * W + cx) * C + c * V);
+    }
+    vec m;
+#pragma unroll
+    for (int e = 0; e < V; ++e) m[e] = (T)(-__builtin_huge_valf());
+#pragma unroll
+    for (int t = 0; t < 9; ++t) m = ok[t] ? vmax<T>(m, v[t]) : m;
+    *reinterpret_cast<vec*>(y + idx * V) = m;
+  }
+}
+
 int maxpool_launch(const void* x, void* y, int n, int h, int w, int c, int k, int stride, int pad_mode, int dtype,
                    hipStream_t st) {
   SQDET_REQUIRE(x && y, "maxpool: null pointer");
@@ -56,7 +96,14 @@ int maxpool_launch(const void* x, void* y, int n, int h, int w, int c, int k, in
   const size_t total = (size_t)n * Ho * Wo * (c / V);
   size_t blocks = (total + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;
-  if (dtype == SQDET_F16)
+  if (k == 3) {
+    if (dtype == SQDET_F16)
+      hipLaunchKernelGGL(maxpool3_kernel<f16>, dim3((unsigned)blocks), dim3(256), 0, st, (const f16*)x, (f16*)y, n, h,
+                         w, c, stride, pt, pl, Ho, Wo);
+    else
+      hipLaunchKernelGGL(maxpool3_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (float*)y,
+                         n, h, w, c, stride, pt, pl, Ho, Wo);
+  } else if (dtype == SQDET_F16)
     hipLaunchKernelGGL(maxpool_kernel<f16>, dim3((unsigned)blocks), dim3(256), 0, st, (const f16*)x, (f16*)y, n, h, w,
                        c, k, stride, pt, pl, Ho, Wo);
   else

@@ -53,9 +53,8 @@ def test_net_plan_tables_without_gpu(lib):
     """The plan is host-side: parameter table, workspace sizes and the layer table can be
     inspected without a device."""
     h = C.c_void_p()
-    # default plan: conv1+pool1 fused; one launch per fire module on the large few-channel maps (fire2-4: the
-    # persistent streaming kernel) and on the small late maps (fire6-11); fire5 (256 input channels on the
-    # 47x156 map) runs as three convs
+    # default plan: conv1+pool1 fused; one launch per fire module -- the persistent streaming kernel on the large
+    # few-channel maps (fire2-5), the tile kernel on the small late maps (fire6-11)
     assert lib.sqdet_net_create(C.byref(h), _lib.ARCH_SQUEEZEDET, _lib.F16, 32, 375, 1242, 3, 9) == 0
     nm = C.create_string_buffer(128)
     names_default = []
@@ -63,8 +62,8 @@ def test_net_plan_tables_without_gpu(lib):
         assert lib.sqdet_net_layer_info(h, i, nm, 128, None, None) == 0
         names_default.append(nm.value.decode())
     assert names_default[0] == "conv1+pool1" and "fire2" in names_default and "fire11" in names_default
-    assert "fire5/expand3x3" in names_default
-    assert len(names_default) == 34 - 2 * 9
+    assert "fire5" in names_default and "pool5" in names_default
+    assert len(names_default) == 34 - 2 * 10
     lib.sqdet_net_destroy(h)
     # the rest of this test inspects the per-conv plan (fire fusion off)
     assert lib.sqdet_set_option(b"fire_fuse", 2) == 0
