@@ -87,6 +87,21 @@ int sqdet_fold_batchnorm(const float* w_hwio, const float* conv_bias, const floa
                          const float* mean, const float* var, float eps, float* w_folded, float* b_folded,
                          int k, int cin, int cout, sqdet_stream_t stream);
 
+/* Training of a _conv_bn_layer conv (the trainable res4* blocks, resnet50_convDet.py:94-118): the conv
+ * backward kernels produce the gradients of the FOLDED kernel / bias; this turns them into the
+ * gradients of the variables (float32):  dw = dw_folded * gamma/sqrt(var+eps)  (may alias dw_folded),
+ *   dgamma = (sum over k,k,cin of dw_folded * w + (conv_bias - mean) * db_folded) / sqrt(var+eps),
+ *   dbeta = db_folded.   conv_bias may be NULL.  Deterministic. */
+int sqdet_fold_batchnorm_bwd(const float* w_hwio, const float* dw_folded, const float* db_folded,
+                             const float* conv_bias, const float* gamma, const float* mean, const float* var, float eps,
+                             float* dw, float* dgamma, float* dbeta, int k, int cin, int cout, sqdet_stream_t stream);
+
+/* y[n,oy,ox,:] = x[n,oy*stride,ox*stride,:], y: [n,ceil(h/stride),ceil(w/stride),c] -- the pixels a 1x1
+ * stride-s SAME conv reads (res3a/res4a branch1 and branch2a), so that their filter gradient can use
+ * sqdet_conv2d_nhwc_bwd_filter (stride 1) on the gathered tensor. */
+int sqdet_subsample_nhwc(const void* x, void* y, int n, int h, int w, int c, int stride, int dtype,
+                         sqdet_stream_t stream);
+
 /* ------------------------------------------------------------------ pool --
  * Replaces ModelSkeleton._pooling_layer (nn_skeleton.py:565-586): tf.nn.max_pool,
  * SAME-padded cells never win.  x: [n,h,w,c] -> y: [n,ho,wo,c]. */

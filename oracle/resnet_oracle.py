@@ -144,6 +144,63 @@ def forward(params, x, storage="fp32", collect=None, folded=None):
     return note("conv5", so.conv_layer(t, w5, params["conv5/biases"], 1, "SAME", False, storage))
 
 
+# --------------------------------------------------------------------------
+# training graph (differentiable, float32, BN UNFOLDED): resnet50_convDet.py:31-132 with IS_TRAINING,
+# loss / optimizer from oracle/train_oracle.py (nn_skeleton.py:285-361)
+# --------------------------------------------------------------------------
+def trainable_names(params):
+    """conv1..res3d frozen (resnet50_convDet.py:41-92, freeze=True); res4* kernels/gamma/beta and conv5 train;
+    mean / var are never trainable (nn_skeleton.py:437-438)."""
+    out = []
+    for n in params:
+        leaf = n.rsplit("/", 1)[1]
+        if n.startswith("conv5/") or (n.startswith("conv4_x/") and leaf in ("kernels", "gamma", "beta")):
+            out.append(n)
+    return out
+
+
+def forward_train(params, x, dropout_mask, keep_prob=0.5):
+    from . import train_oracle as TO
+
+    def cbn(t, name, stride, relu, with_bias):
+        P = params
+        y = TO._conv(t, P[name + "/kernels"], P[name + "/biases"] if with_bias else torch.zeros_like(P[name + "/mean"]), stride, "SAME", False)
+        inv = torch.rsqrt(P[name + "/var"] + BN_EPS) * P[name + "/gamma"]
+        y = y * inv + (P[name + "/beta"] - P[name + "/mean"] * inv)
+        return torch.relu(y) if relu else y
+
+    t = cbn(x, "conv1", 2, True, True)
+    t = so.pooling_layer(t, 3, 2, "VALID")
+    for scope, blocks, in_f, out_f in STAGES:
+        for i, n in enumerate(blocks):
+            blk = "%s/res%s/" % (scope, n)
+            stride = 2 if (i == 0 and scope != "conv2_x") else 1
+            shortcut = cbn(t, blk + "res%s_branch1" % n, stride, False, False) if i == 0 else t
+            b2 = blk + "res%s_branch2/res%s" % (n, n)
+            u = cbn(t, b2 + "_branch2a", stride, True, False)
+            u = cbn(u, b2 + "_branch2b", 1, True, False)
+            u = cbn(u, b2 + "_branch2c", 1, False, False)
+            t = torch.relu(shortcut + u)
+    t = t * dropout_mask / keep_prob                       # drop4 (resnet50_convDet.py:126)
+    return TO._conv(t, params["conv5/kernels"], params["conv5/biases"], 1, "SAME", False)
+
+
+def loss_and_grads(mc, params, x, dropout_mask, input_mask, box_delta_input, box_input, labels):
+    """Total loss (incl. weight decay on the trainable kernels) and its gradient w.r.t. every trainable variable."""
+    from . import train_oracle as TO
+    names = trainable_names(params)
+    p = {k: v.clone().requires_grad_(k in names) for k, v in params.items()}
+    preds = forward_train(p, x, dropout_mask, 0.5)
+    parts = TO.loss_graph(mc, preds, input_mask, box_delta_input, box_input, labels)
+    wd = sum(mc.WEIGHT_DECAY * (p[k] ** 2).sum() / 2 for k in names if k.endswith("/kernels"))
+    main = parts["class_loss"] + parts["conf_loss"] + parts["bbox_loss"]
+    grads = torch.autograd.grad(main + wd, [p[k] for k in names], retain_graph=True)
+    dpreds = torch.autograd.grad(main, preds)[0]
+    return dict(class_loss=float(parts["class_loss"].detach()), conf_loss=float(parts["conf_loss"].detach()),
+                bbox_loss=float(parts["bbox_loss"].detach()), grads=dict(zip(names, [g.detach() for g in grads])),
+                preds=preds.detach(), dpreds=dpreds.detach())
+
+
 def forward_float64(params, x):
     """Independent check of the float32 restatement: the same graph in float64, BN unfolded."""
     P = {k: v.double() for k, v in params.items()}

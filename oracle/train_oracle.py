@@ -169,8 +169,8 @@ def loss_and_grads(arch, mc, params, x, dropout_mask, input_mask, box_delta_inpu
     names = trainable_names(arch, params)
     grads = torch.autograd.grad(loss, [p[k] for k in names], retain_graph=True)
     dpreds = torch.autograd.grad(parts["class_loss"] + parts["conf_loss"] + parts["bbox_loss"], preds)[0]
-    return dict(loss=float(loss), class_loss=float(parts["class_loss"]), conf_loss=float(parts["conf_loss"]),
-                bbox_loss=float(parts["bbox_loss"]), grads=dict(zip(names, [g.detach() for g in grads])),
+    return dict(loss=float(loss.detach()), class_loss=float(parts["class_loss"].detach()),
+                conf_loss=float(parts["conf_loss"].detach()), bbox_loss=float(parts["bbox_loss"].detach()), grads=dict(zip(names, [g.detach() for g in grads])),
                 preds=preds.detach(), dpreds=dpreds.detach(), ious=parts["ious"])
 
 

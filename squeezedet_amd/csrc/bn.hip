@@ -45,7 +45,98 @@ int fold_bn_launch(const float* w, const float* cbias, const float* gamma, const
   return SQDET_OK;
 }
 
+// Backward of the fold (training of the _conv_bn_layer convs, float32): given the gradients of the
+// FOLDED kernel / bias (what the conv backward kernels produce), the gradients of the variables:
+//   Wf = W * gamma * r,  bf = (cb - mean) * gamma * r + beta,   r = 1/sqrt(var + eps)
+//   dW = dWf * gamma * r;   dgamma = r * (sum_rows(dWf * W) + (cb - mean) * dbf);   dbeta = dbf
+// One workgroup owns 64 output channels: thread (row partition rp = tid/64, channel) walks rows
+// rp, rp+4, ... in order, the four partitions are summed in fixed order through LDS (deterministic).
+__global__ __launch_bounds__(256) void fold_bn_bwd_kernel(const float* __restrict__ w, const float* dwf,
+                                                          const float* __restrict__ dbf, const float* __restrict__ cbias,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ var, float eps, float* dw,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          int rows, int cout) {
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, rp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s = 0.f, inv = 0.f, r = 0.f;
+  if (c < cout) {
+    r = 1.f / sqrtf(var[c] + eps);
+    inv = gamma[c] * r;
+    for (int row = rp; row < rows; row += 4) {
+      const size_t i = (size_t)row * cout + c;
+      const float g = dwf[i];
+      s += g * w[i];
+      dw[i] = g * inv;   // dw may alias dwf: each element is read, then written, by this thread only
+    }
+  }
+  part[rp][cl] = s;
+  __syncthreads();
+  if (rp == 0 && c < cout) {
+    const float tot = ((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl];
+    const float db = dbf[c];
+    dgamma[c] = r * (tot + ((cbias ? cbias[c] : 0.f) - mean[c]) * db);
+    dbeta[c] = db;
+  }
+}
+
+int fold_bn_bwd_launch(const float* w, const float* dwf, const float* dbf, const float* cbias, const float* gamma,
+                       const float* mean, const float* var, float eps, float* dw, float* dgamma, float* dbeta, int k,
+                       int cin, int cout, hipStream_t st) {
+  SQDET_REQUIRE(w && dwf && dbf && gamma && mean && var && dw && dgamma && dbeta, "fold_batchnorm_bwd: null pointer");
+  SQDET_REQUIRE(k > 0 && cin > 0 && cout > 0 && eps >= 0.f, "fold_batchnorm_bwd: bad dims");
+  hipLaunchKernelGGL(fold_bn_bwd_kernel, dim3((unsigned)((cout + 63) / 64)), dim3(256), 0, st, w, dwf, dbf, cbias, gamma,
+                     mean, var, eps, dw, dgamma, dbeta, k * k * cin, cout);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
+// y[n, oy, ox, :] = x[n, oy*stride, ox*stride, :]: the pixels a 1x1 / stride-s SAME conv reads (the
+// projection shortcut and branch2a of res3a / res4a, resnet50_convDet.py:71-73,150-156), gathered so the
+// stride-1 filter-gradient kernel can be used on them.  16 bytes per thread.
+__global__ __launch_bounds__(256) void subsample_kernel(const i32x4* __restrict__ x, i32x4* __restrict__ y, int N, int H,
+                                                        int W, int cv, int stride, int Ho, int Wo) {
+  const size_t total = (size_t)N * Ho * Wo * cv;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cv);
+    size_t p = idx / cv;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    y[idx] = x[(((size_t)n * H + (size_t)oy * stride) * W + (size_t)ox * stride) * cv + c];
+  }
+}
+
+int subsample_launch(const void* x, void* y, int n, int h, int w, int c, int stride, int dtype, hipStream_t st) {
+  SQDET_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && stride > 0, "subsample: bad arguments");
+  SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "subsample: bad dtype %d", dtype);
+  const int esz = dtype == SQDET_F16 ? 2 : 4;
+  SQDET_UNSUPPORTED((c * esz) % 16 != 0, "subsample: channel bytes %d not a multiple of 16", c * esz);
+  const int Ho = (h + stride - 1) / stride, Wo = (w + stride - 1) / stride, cv = c * esz / 16;
+  const size_t total = (size_t)n * Ho * Wo * cv;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(subsample_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const i32x4*)x, (i32x4*)y, n, h, w, cv,
+                     stride, Ho, Wo);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
 }  // namespace sqdet
+
+extern "C" int sqdet_fold_batchnorm_bwd(const float* w_hwio, const float* dw_folded, const float* db_folded,
+                                        const float* conv_bias, const float* gamma, const float* mean, const float* var,
+                                        float eps, float* dw, float* dgamma, float* dbeta, int k, int cin, int cout,
+                                        sqdet_stream_t stream) {
+  return sqdet::fold_bn_bwd_launch(w_hwio, dw_folded, db_folded, conv_bias, gamma, mean, var, eps, dw, dgamma, dbeta, k,
+                                   cin, cout, sqdet::as_stream(stream));
+}
+
+extern "C" int sqdet_subsample_nhwc(const void* x, void* y, int n, int h, int w, int c, int stride, int dtype,
+                                    sqdet_stream_t stream) {
+  return sqdet::subsample_launch(x, y, n, h, w, c, stride, dtype, sqdet::as_stream(stream));
+}
 
 extern "C" int sqdet_fold_batchnorm(const float* w_hwio, const float* conv_bias, const float* gamma, const float* beta,
                                     const float* mean, const float* var, float eps, float* w_folded, float* b_folded,

@@ -226,6 +226,33 @@ def conv2d_bwd_filter(x, dy, k, cin, cout, w_for_decay=None, weight_decay=0.0, x
     return dw, db
 
 
+def fold_batchnorm_bwd(w_hwio, dw_folded, db_folded, conv_bias, gamma, mean, var, eps, dw=None, dgamma=None, dbeta=None):
+    """Gradients of kernels / gamma / beta of a _conv_bn_layer from the gradients of its folded kernel / bias
+    (sqdet_fold_batchnorm_bwd).  Returns (dw, dgamma, dbeta); dw may be dw_folded itself (in place)."""
+    k, _, cin, cout = [int(v) for v in w_hwio.shape]
+    dev = w_hwio.device
+    dw = torch.empty_like(dw_folded) if dw is None else dw
+    dgamma = torch.empty(cout, dtype=torch.float32, device=dev) if dgamma is None else dgamma
+    dbeta = torch.empty(cout, dtype=torch.float32, device=dev) if dbeta is None else dbeta
+    check(lib().sqdet_fold_batchnorm_bwd(_dev(w_hwio, "w", torch.float32), _dev(dw_folded, "dw_folded", torch.float32),
+                                         _dev(db_folded, "db_folded", torch.float32),
+                                         _dev(conv_bias, "conv_bias", torch.float32) if conv_bias is not None else None,
+                                         _dev(gamma, "gamma", torch.float32), _dev(mean, "mean", torch.float32),
+                                         _dev(var, "var", torch.float32), float(eps), _dev(dw, "dw", torch.float32),
+                                         _dev(dgamma, "dgamma", torch.float32), _dev(dbeta, "dbeta", torch.float32),
+                                         k, cin, cout, stream_ptr()), "sqdet_fold_batchnorm_bwd")
+    return dw, dgamma, dbeta
+
+
+def subsample_nhwc(x, stride):
+    """x[:, ::stride, ::stride, :] as a dense tensor (sqdet_subsample_nhwc)."""
+    n, h, w, c = [int(v) for v in x.shape]
+    y = torch.empty((n, -(-h // stride), -(-w // stride), c), dtype=x.dtype, device=x.device)
+    check(lib().sqdet_subsample_nhwc(_dev(x, "x"), _dev(y, "y"), n, h, w, c, int(stride), dtype_code(x.dtype), stream_ptr()),
+          "sqdet_subsample_nhwc")
+    return y
+
+
 def relu_bwd(y, dy):
     """In place: dy *= (y > 0)."""
     check(lib().sqdet_relu_bwd(_dev(y, "y", torch.float32), _dev(dy, "dy", torch.float32), y.numel(), stream_ptr()), "sqdet_relu_bwd")

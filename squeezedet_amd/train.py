@@ -29,8 +29,9 @@ def allreduce_gradients(flat_grads, world, group=None):
     return 1.0 / world
 
 
-class SqueezeDetTrainer:
-    """model: a squeezedet_amd.nets.SqueezeDet built with mc.IS_TRAINING = True and dtype float32."""
+class _TrainerBase:
+    """Flat float32 parameter / gradient / momentum buffers over the trainable variables of a model built with
+    mc.IS_TRAINING = True and dtype float32, the gradient all-reduce and the optimizer step."""
 
     def __init__(self, model, process_group=None):
         if model.dtype != torch.float32:
@@ -66,6 +67,40 @@ class SqueezeDetTrainer:
         model._packed.clear()
         model._plan_stale = True
         self.opt = ops.MomentumOptimizer(offs, cnts, decs, self.dev)
+
+    def learning_rate(self):
+        mc = self.mc
+        return mc.LEARNING_RATE * mc.LR_DECAY_FACTOR ** (self.global_step // mc.DECAY_STEPS)   # staircase decay
+
+    def _labels(self, B, input_mask, box_delta_input, box_input, labels):
+        t = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))).to(self.dev, torch.float32).contiguous()
+        mask = t(input_mask).reshape(B, -1)
+        return t, mask, t(box_delta_input), t(box_input), t(labels), float(mask.sum().item())
+
+    def _finish_step(self, apply_update):
+        """Gradient all-reduce (the one collective) + clipped Momentum update on the flat buffers."""
+        grad_scale = allreduce_gradients(self.flat_grads, self.world, self.pg)
+        if apply_update:
+            self.opt.step(self.flat_params, self.flat_grads, self.flat_accum, self.learning_rate(), self.mc.MOMENTUM,
+                          self.mc.MAX_GRAD_NORM, grad_scale)
+            self.global_step += 1
+            self.model._packed.clear()
+            self.model._plan_stale = True
+
+    def weight_decay_loss(self):
+        """sum wd * l2_loss(kernel) over trainable kernels (the 'losses' collection of nn_skeleton.py:66-69)."""
+        tot = 0.0
+        for n in self.names:
+            if n.endswith("/kernels"):
+                tot += float((self.view[n].double() ** 2).sum().item()) * self.mc.WEIGHT_DECAY / 2
+        return tot
+
+
+class SqueezeDetTrainer(_TrainerBase):
+    """model: a squeezedet_amd.nets.SqueezeDet built with mc.IS_TRAINING = True and dtype float32."""
+
+    def __init__(self, model, process_group=None):
+        _TrainerBase.__init__(self, model, process_group)
         self.layers = self._layer_list()
 
     # ---- the forward graph as a list (nets/squeezeDet.py:30-79) ----
@@ -93,10 +128,6 @@ class SqueezeDetTrainer:
     def _pack(self, name):
         return ops.pack_conv_weights(self.model.params[name + "/kernels"], torch.float32)
 
-    def learning_rate(self):
-        mc = self.mc
-        return mc.LEARNING_RATE * mc.LR_DECAY_FACTOR ** (self.global_step // mc.DECAY_STEPS)   # staircase decay
-
     def step(self, images, input_mask, box_delta_input, box_input, labels, dropout_mask=None, apply_update=True):
         """One training step.  images [B,H,W,3]; input_mask [B,A] or [B,A,1]; box_delta_input / box_input
         [B,A,4]; labels [B,A,C] (the reference's placeholders, nn_skeleton.py:81-97).  Returns a dict
@@ -104,10 +135,7 @@ class SqueezeDetTrainer:
         m, mc, P = self.model, self.mc, self.model.params
         x = m._to_input(images)
         B = int(x.shape[0])
-        t = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))).to(self.dev, torch.float32).contiguous()
-        mask = t(input_mask).reshape(B, -1)
-        delta, box, lab = t(box_delta_input), t(box_input), t(labels)
-        num_objects = float(mask.sum().item())
+        t, mask, delta, box, lab, num_objects = self._labels(B, input_mask, box_delta_input, box_input, labels)
         keep = m.keep_prob
         # ---------------- forward, keeping what the backward needs ----------------
         saved = []
@@ -183,21 +211,134 @@ class SqueezeDetTrainer:
                 if need_dx:
                     g = ops.conv2d_bwd_data(ds, ops.PackedConvBwd(P[sq.name + "/kernels"]))
         # ---------------- gradient all-reduce + update ----------------
-        grad_scale = allreduce_gradients(self.flat_grads, self.world, self.pg)
-        if apply_update:
-            self.opt.step(self.flat_params, self.flat_grads, self.flat_accum, self.learning_rate(), mc.MOMENTUM,
-                          mc.MAX_GRAD_NORM, grad_scale)
-            self.global_step += 1
-            m._packed.clear()
-            m._plan_stale = True
+        self._finish_step(apply_update)
         out = collections.OrderedDict(class_loss=losses[0], conf_loss=losses[1], bbox_loss=losses[2], ious=ious, preds=preds,
                                       dpreds=dpreds, num_objects=num_objects)
         return out
 
-    def weight_decay_loss(self):
-        """sum wd * l2_loss(kernel) over trainable kernels (the 'losses' collection of nn_skeleton.py:66-69)."""
-        tot = 0.0
-        for n in self.names:
-            if n.endswith("/kernels"):
-                tot += float((self.view[n].double() ** 2).sum().item()) * self.mc.WEIGHT_DECAY / 2
-        return tot
+
+class ResNet50ConvDetTrainer(_TrainerBase):
+    """Training step of ResNet50ConvDet (nets/resnet50_convDet.py:20-169 + nn_skeleton.py:285-361): conv1..res3d
+    are frozen (:41-92), so the forward below res4a runs on the inference kernels and the backward stops at
+    res4a's input.  The trainable _conv_bn_layer convs run with the batch norm FOLDED (frozen statistics make
+    it affine): forward = sqdet_fold_batchnorm + conv, backward = the conv backward kernels on the folded
+    kernel + sqdet_fold_batchnorm_bwd for d(kernels), d(gamma), d(beta).  float32, like the reference."""
+
+    def __init__(self, model, process_group=None):
+        _TrainerBase.__init__(self, model, process_group)
+        m = model
+        order, seen = [], set()
+
+        def topo(n):
+            if n in seen:
+                return
+            seen.add(n)
+            for i in n.inputs:
+                topo(i)
+            order.append(n)
+        topo(m.preds)
+        has_tr = lambda n: n.op in ("conv", "conv_bn") and m.trainable[n.name + "/kernels"]
+        first = next(n for n in order if has_tr(n))
+        self.boundary = first.inputs[0]                 # last frozen activation (res3d)
+        below, stack = set(), [self.boundary]
+        while stack:
+            n = stack.pop()
+            if n not in below:
+                below.add(n)
+                stack.extend(n.inputs)
+        self.region = [n for n in order if n not in below]   # trainable suffix, topological order
+        for n in self.region:
+            if n.op in ("conv", "conv_bn") and not has_tr(n):
+                raise SqdetError("frozen conv %s above the first trainable one is not supported" % n.name)
+
+    def step(self, images, input_mask, box_delta_input, box_input, labels, dropout_mask=None, apply_update=True):
+        m, mc, P = self.model, self.mc, self.model.params
+        eps = mc.BATCH_NORM_EPSILON
+        (xb,) = m.run([self.boundary], {m.image_input: images}, use_plan=False)
+        B = int(xb.shape[0])
+        t, mask, delta, box, lab, num_objects = self._labels(B, input_mask, box_delta_input, box_input, labels)
+        # ---------------- forward over the trainable region ----------------
+        val, aux = {self.boundary: xb}, {}
+        for n in self.region:
+            if n.op == "conv_bn":
+                x = val[n.inputs[0]]
+                wf, bf = ops.fold_batchnorm(P[n.name + "/kernels"], None, P[n.name + "/gamma"], P[n.name + "/beta"],
+                                            P[n.name + "/mean"], P[n.name + "/var"], eps)
+                aux[n], aux[(n, "bf")] = wf, bf
+                fused_add = len(n.readers) == 1 and n.readers[0].op == "add_relu" and n.readers[0].inputs[1] is n and not n.attrs["relu"]
+                if fused_add:
+                    continue        # evaluated by its add_relu reader (residual epilogue)
+                val[n] = ops.conv2d_nhwc(x, ops.pack_conv_weights(wf, torch.float32), bf, n.attrs["stride"], n.attrs["padding"], n.attrs["relu"])
+            elif n.op == "add_relu":
+                sc, br = n.inputs
+                if br in val:
+                    val[n] = torch.relu(val[sc] + val[br])
+                else:
+                    wf, bf = aux[br], aux[(br, "bf")]
+                    out = val[sc].clone()         # the shortcut is branch2a's input: its value is needed by the backward
+                    val[n] = ops.conv2d_nhwc(val[br.inputs[0]], ops.pack_conv_weights(wf, torch.float32), bf, br.attrs["stride"],
+                                             br.attrs["padding"], True, out=out, accumulate=True)
+            elif n.op == "dropout":
+                x = val[n.inputs[0]]
+                keep = n.attrs["keep_prob"]
+                if dropout_mask is None:
+                    dropout_mask = torch.floor(keep + torch.rand(x.shape, device=self.dev))
+                aux[n] = t(dropout_mask)
+                val[n] = ops.scale_mask(x, aux[n], 1.0 / keep)
+            elif n.op == "conv":
+                x = val[n.inputs[0]]
+                val[n] = ops.conv2d_nhwc(x, ops.pack_conv_weights(P[n.name + "/kernels"], torch.float32), P[n.name + "/biases"],
+                                         n.attrs["stride"], n.attrs["padding"], n.attrs["relu"])
+            else:
+                raise SqdetError("ResNet50ConvDetTrainer: unsupported op %s in the trainable region" % n.op)
+        preds = val[m.preds]
+        dpreds, ious, losses = ops.loss_fwd_bwd(preds, m.anchors_f32(), mask, delta, box, lab, mc, num_objects)
+        # ---------------- backward ----------------
+        self.flat_grads.zero_()
+        g = {m.preds: dpreds}
+
+        def give(node, dy, packed_bwd):
+            """d(input) of a stride-1 conv into g[node] (accumulating when the node already has a gradient)."""
+            if node is self.boundary:
+                return
+            if node in g:
+                ops.conv2d_bwd_data(dy, packed_bwd, dx=g[node], accumulate=True)
+            else:
+                g[node] = ops.conv2d_bwd_data(dy, packed_bwd)
+
+        for n in reversed(self.region):
+            gy = g.pop(n)
+            if n.op == "conv":
+                x = val[n.inputs[0]]
+                if n.attrs["relu"]:
+                    ops.relu_bwd(val[n], gy)
+                k, cin, cout = n.attrs["size"], int(x.shape[3]), int(n.shape[3])
+                ops.conv2d_bwd_filter(x, gy, k, cin, cout, dw=self.gview[n.name + "/kernels"], db=self.gview[n.name + "/biases"])
+                give(n.inputs[0], gy, ops.PackedConvBwd(P[n.name + "/kernels"]))
+            elif n.op == "dropout":
+                g[n.inputs[0]] = ops.scale_mask(gy, aux[n], 1.0 / n.attrs["keep_prob"])
+            elif n.op == "add_relu":
+                ops.relu_bwd(val[n], gy)
+                sc, br = n.inputs
+                g[br] = gy                              # both summands receive the same gradient;
+                if sc is not self.boundary:             # the branch's last d(input) is accumulated into it
+                    g[sc] = gy
+            elif n.op == "conv_bn":
+                x = val[n.inputs[0]]
+                if n.attrs["relu"]:
+                    ops.relu_bwd(val[n], gy)
+                k, stride = n.attrs["size"], n.attrs["stride"]
+                cin, cout = int(x.shape[3]), int(n.shape[3])
+                if stride != 1:
+                    if k != 1 or n.inputs[0] is not self.boundary:
+                        raise SqdetError("ResNet50ConvDetTrainer: strided conv %s needs an input gradient" % n.name)
+                    x = ops.subsample_nhwc(x, stride)
+                dwf, dbf = ops.conv2d_bwd_filter(x, gy, k, cin, cout)
+                ops.fold_batchnorm_bwd(P[n.name + "/kernels"], dwf, dbf, None, P[n.name + "/gamma"], P[n.name + "/mean"],
+                                       P[n.name + "/var"], eps, dw=self.gview[n.name + "/kernels"],
+                                       dgamma=self.gview[n.name + "/gamma"], dbeta=self.gview[n.name + "/beta"])
+                if stride == 1:
+                    give(n.inputs[0], gy, ops.PackedConvBwd(aux[n]))
+        self._finish_step(apply_update)
+        return collections.OrderedDict(class_loss=losses[0], conf_loss=losses[1], bbox_loss=losses[2], ious=ious, preds=preds,
+                                       dpreds=dpreds, num_objects=num_objects)

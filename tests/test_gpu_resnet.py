@@ -141,3 +141,89 @@ def test_resnet50_full_size_properties():
     m1, _, _ = _model(torch.float16, 1, (375, 1242))
     (q,) = m1.run([m1.preds], {m1.image_input: x[5:6]})
     assert torch.equal(q[0], p1[5])
+
+
+# ------------------------------------------------------------------ training (BASELINE.json config 5)
+def test_fold_batchnorm_backward_and_subsample():
+    from squeezedet_amd import ops
+    g = torch.Generator().manual_seed(17)
+    k, cin, cout = 3, 20, 72
+    w = torch.randn(k, k, cin, cout, generator=g).requires_grad_(True)
+    gamma = (torch.rand(cout, generator=g) + 0.5).requires_grad_(True)
+    beta = torch.randn(cout, generator=g).requires_grad_(True)
+    mean, var = torch.randn(cout, generator=g), torch.rand(cout, generator=g) + 0.5
+    dwf, dbf = torch.randn(k, k, cin, cout, generator=g), torch.randn(cout, generator=g)
+    wf, bf = R.fold_batchnorm(w, None, gamma, beta, mean, var)
+    ((wf * dwf).sum() + (bf * dbf).sum()).backward()
+    dw, dg, db = ops.fold_batchnorm_bwd(w.detach().to(DEV), dwf.to(DEV), dbf.to(DEV), None, gamma.detach().to(DEV), mean.to(DEV),
+                                        var.to(DEV), R.BN_EPS)
+    assert torch.allclose(dw.cpu(), w.grad, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(dg.cpu(), gamma.grad, rtol=1e-4, atol=1e-4)
+    assert torch.equal(db.cpu(), beta.grad)
+    x = torch.randn(2, 7, 9, 16, generator=g)
+    for dt in (torch.float32, torch.float16):
+        assert torch.equal(ops.subsample_nhwc(x.to(DEV, dt), 2).cpu(), x.to(dt)[:, ::2, ::2, :])
+
+
+def _trainer(size=(96, 160), batch=2, seed=0):
+    import squeezedet_amd as S
+    from squeezedet_amd import nets
+    from squeezedet_amd.train import ResNet50ConvDetTrainer
+    mc = S.kitti_res50_config_for_input(*size)
+    mc.LOAD_PRETRAINED_MODEL = False
+    mc.BATCH_SIZE = batch
+    mc.IS_TRAINING = True
+    m = nets.ResNet50ConvDet(mc, gpu_id="0", dtype=torch.float32)
+    params = R.init_params(seed=seed)
+    m.load_params(params)
+    return ResNet50ConvDetTrainer(m), mc, params
+
+
+def test_resnet50_training_step_vs_oracle():
+    """forward(train) -> loss -> backward -> clipped Momentum on the trainable res4* + conv5 variables (kernels,
+    gamma, beta; nets/resnet50_convDet.py:94-132) against PyTorch-CPU autograd of the UNFOLDED graph."""
+    from oracle import train_oracle as TO
+    size, B = (96, 160), 2
+    tr, mc, params = _trainer(size, B)
+    x = O.synthetic_images(B, size[0], size[1], seed=31)
+    mask, delta, box, labels = TO.synthetic_labels(mc, B, seed=32)
+    gh, gw = tr.model.preds.get_shape()[1:3]
+    dm = torch.from_numpy((np.random.RandomState(33).uniform(size=(B, gh, gw, 1024)) < 0.5).astype(np.float32))
+    ref = R.loss_and_grads(mc, params, x, dm, mask, delta, box, labels)
+    out = tr.step(x, mask, delta, box, labels, dropout_mask=dm, apply_update=False)
+    torch.cuda.synchronize()
+    for k in ("class_loss", "conf_loss", "bbox_loss"):
+        np.testing.assert_allclose(float(out[k]), ref[k], rtol=5e-4)
+    _close(out["preds"], ref["preds"], torch.float32, "preds (training forward)")
+    assert set(tr.names) == set(ref["grads"])
+    assert "conv3_x/res3d/res3d_branch2/res3d_branch2c/kernels" not in tr.gview and "conv4_x/res4a/res4a_branch1/mean" not in tr.gview
+    for name, gref in ref["grads"].items():
+        wdg = mc.WEIGHT_DECAY * params[name] if name.endswith("/kernels") else 0.0   # added by the optimizer kernel
+        got = tr.gview[name].cpu() + wdg
+        scale = float(gref.abs().max())
+        err = float((got - gref).abs().max())
+        assert err <= 2e-3 * scale + 1e-7, "%s: grad err %g vs scale %g" % (name, err, scale)
+    mom = {k: torch.zeros_like(v) for k, v in params.items()}
+    p_ref, _ = TO.apply_gradients(mc, params, mom, ref["grads"], step=0)
+    tr.opt.step(tr.flat_params, tr.flat_grads, tr.flat_accum, tr.learning_rate(), mc.MOMENTUM, mc.MAX_GRAD_NORM, 1.0)
+    torch.cuda.synchronize()
+    for name in ref["grads"]:
+        got, want = tr.view[name].cpu(), p_ref[name]
+        assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-7, name
+
+
+def test_resnet50_training_reduces_loss():
+    from oracle import train_oracle as TO
+    tr, mc, params = _trainer(seed=5)
+    x = O.synthetic_images(2, 96, 160, seed=41)
+    mask, delta, box, labels = TO.synthetic_labels(mc, 2, seed=42)
+    hist = []
+    for _ in range(10):
+        o = tr.step(x, mask, delta, box, labels)
+        hist.append(float(o["class_loss"]) + float(o["conf_loss"]) + float(o["bbox_loss"]))
+    assert tr.global_step == 10 and np.isfinite(hist).all()
+    assert min(hist[-3:]) < hist[0], hist
+    # the inference path sees the updated variables (plan re-folds lazily)
+    tr.model.keep_prob = 1.0
+    (p,) = tr.model.run([tr.model.preds], {tr.model.image_input: x})
+    assert torch.isfinite(p).all()
