@@ -25,10 +25,15 @@ def synthetic_params(model, seed=0):
             sigma = math.sqrt(2.0 / (shp[0] * shp[1] * shp[2]))
             if name.startswith("conv1/"):
                 sigma /= 64.0   # inputs are pixel-scale (rms ~74): bring activations to O(1)
-            if name.startswith("conv12"):
+            if name.startswith("conv12") or name.startswith("conv5/"):
                 sigma *= 2.0    # preds of std ~2: scores spread without saturating
             z = np.clip(rng.standard_normal(size=shp), -2.0, 2.0)
             out[name] = torch.from_numpy((z * sigma).astype(np.float32))
+        elif name.endswith("/gamma") or name.endswith("/var"):
+            # frozen batch-norm statistics / scales of _conv_bn_layer: positive, O(1); the last conv of a
+            # residual branch is scaled down so the residual stream stays O(1) through the 13 blocks
+            v = rng.uniform(0.5, 1.5, size=shp) * (0.3 if name.endswith("_branch2c/gamma") else 1.0)
+            out[name] = torch.from_numpy(v.astype(np.float32))
         else:
             out[name] = torch.from_numpy(rng.uniform(-0.1, 0.1, size=shp).astype(np.float32))
     return out

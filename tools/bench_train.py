@@ -48,8 +48,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: 20 squeezeDet, 8 resnet50)")
+    ap.add_argument("--arch", default="squeezeDet", choices=["squeezeDet", "resnet50"],
+                    help="squeezeDet = BASELINE.json configs[2]; resnet50 = configs[4] (ResNet50+ConvDet, 1242x375, in float32)")
     args = ap.parse_args()
+    if args.batch <= 0:
+        args.batch = 20 if args.arch == "squeezeDet" else 8
     rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -59,14 +63,15 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     import squeezedet_amd as S
     from squeezedet_amd import nets, synthetic
-    from squeezedet_amd.train import SqueezeDetTrainer
-    mc = S.kitti_squeezeDet_config()
+    from squeezedet_amd.train import ResNet50ConvDetTrainer, SqueezeDetTrainer
+    mc = S.kitti_squeezeDet_config() if args.arch == "squeezeDet" else S.kitti_res50_config()
     mc.LOAD_PRETRAINED_MODEL = False
     mc.IS_TRAINING = True
     mc.BATCH_SIZE = args.batch
-    model = nets.SqueezeDet(mc, gpu_id=str(local_rank), dtype=torch.float32)
+    cls, trainer = (nets.SqueezeDet, SqueezeDetTrainer) if args.arch == "squeezeDet" else (nets.ResNet50ConvDet, ResNet50ConvDetTrainer)
+    model = cls(mc, gpu_id=str(local_rank), dtype=torch.float32)
     model.load_params(synthetic.synthetic_params(model, seed=0))      # same weights on every rank
-    tr = SqueezeDetTrainer(model)
+    tr = trainer(model)
     x = synthetic.synthetic_images(args.batch, mc.IMAGE_HEIGHT, mc.IMAGE_WIDTH, seed=100 + rank).to(dev)
     lab = [torch.from_numpy(a).to(dev) for a in synthetic_dense_labels(mc, args.batch, seed=200 + rank)]
     for _ in range(args.warmup):
@@ -86,11 +91,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     if rank == 0:
-        print(json.dumps({"metric": "images/sec SqueezeDet 1248x384 fp32 training", "value": round(args.batch * world * args.steps / el, 2),
+        label = "SqueezeDet 1248x384" if args.arch == "squeezeDet" else "ResNet50+ConvDet 1242x375"
+        print(json.dumps({"metric": "images/sec %s fp32 training" % label, "value": round(args.batch * world * args.steps / el, 2),
                           "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(el / args.steps * 1e3, 3), "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "SqueezeDet fp32 training, batch=%d per GPU, 1248x384, forward+loss+backward+"
-                                                 "all-reduce+clipped Momentum" % args.batch, "parallelism": "dp%d" % world},
+                          "config": {"workload": "%s fp32 training, batch=%d per GPU, forward+loss+backward+"
+                                                 "all-reduce+clipped Momentum" % (label, args.batch), "parallelism": "dp%d" % world},
                           "losses": {k: float(out[k]) for k in ("class_loss", "conf_loss", "bbox_loss")}}))
     if world > 1:
         dist.destroy_process_group()
