@@ -270,6 +270,14 @@ int sqdet_net_forward_timed(sqdet_net_t* net, const void* image_input, void* pre
 int sqdet_net_set_probe(sqdet_net_t* net, int layer_index, int max_records);
 int sqdet_net_read_probe(sqdet_net_t* net, float* host_ms, int capacity, int* count);
 
+/* -------------------------------------------------------- pre-processing --
+ * Replaces the caller-side image preparation of demo.py:186-190 / imdb.py:101-118:
+ *   im = cv2.imread(f).astype(float32); im = cv2.resize(im, (dst_w, dst_h)); input = im - BGR_MEANS
+ * src_bgr_u8: device uint8 [n,src_h,src_w,3] (BGR, as cv2.imread delivers) -> dst [n,dst_h,dst_w,3] in
+ * dtype storage, ready to be image_input.  Bilinear with cv2 INTER_LINEAR coordinates, float32. */
+int sqdet_preprocess_bgr(const uint8_t* src_bgr_u8, void* dst, int n, int src_h, int src_w, int dst_h, int dst_w,
+                         float mean_b, float mean_g, float mean_r, int dtype, sqdet_stream_t stream);
+
 /* ------------------------------------------------------------ utilities --
  * Hardware self-test used by the GPU test-suite: runs one MFMA of each shape
  * the kernels rely on with index-encoded operands and writes the observed

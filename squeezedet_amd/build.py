@@ -29,6 +29,7 @@ SOURCES = [
     ("fire2.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("pool.hip", []),
     ("bn.hip", ["-ffp-contract=off"]),
+    ("preproc.hip", ["-ffp-contract=off"]),
     ("postproc.hip", ["-ffp-contract=off"]),
     ("filter_fast.hip", ["-ffp-contract=off"]),
     ("train.hip", ["-ffp-contract=off"]),

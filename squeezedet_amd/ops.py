@@ -7,6 +7,7 @@ file) so graph-level callers can use them.
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -319,6 +320,19 @@ class MomentumOptimizer:
                 self._h = None
         except Exception:
             pass
+
+
+def preprocess_bgr(images_u8, dst_h, dst_w, bgr_means, dtype=torch.float32):
+    """uint8 BGR [N,H,W,3] (device) -> resized (cv2 INTER_LINEAR), mean-subtracted NHWC network input
+    (demo.py:186-190) in `dtype`."""
+    n, h, w, c = [int(v) for v in images_u8.shape]
+    if c != 3 or images_u8.dtype != torch.uint8:
+        raise _lib.SqdetError("preprocess_bgr: expected uint8 [N,H,W,3]")
+    out = torch.empty((n, int(dst_h), int(dst_w), 3), dtype=dtype, device=images_u8.device)
+    m = [float(v) for v in np.asarray(bgr_means).reshape(-1)[:3]]
+    check(lib().sqdet_preprocess_bgr(_dev(images_u8, "images"), _dev(out, "out"), n, h, w, int(dst_h), int(dst_w), m[0], m[1], m[2],
+                                     dtype_code(dtype), stream_ptr()), "sqdet_preprocess_bgr")
+    return out
 
 
 def set_option(name, value):
