@@ -270,6 +270,19 @@ int sqdet_net_forward_timed(sqdet_net_t* net, const void* image_input, void* pre
 int sqdet_net_set_probe(sqdet_net_t* net, int layer_index, int max_records);
 int sqdet_net_read_probe(sqdet_net_t* net, float* host_ms, int capacity, int* count);
 
+/* ------------------------------------------------------- training labels --
+ * Replaces the per-image Python of imdb.read_batch (dataset/imdb.py:195-239: every ground-truth box, in order,
+ * claims the free anchor of highest IoU, or the nearest free anchor when nothing overlaps) and the dense
+ * placeholder build of train.py:163-224 (sparse_to_dense).  anchors_f64: [num_anchors,4] float64 =
+ * mc.ANCHOR_BOX; gt_boxes_f64: [batch,max_objects,4] (cx,cy,w,h, already scaled to the network input);
+ * gt_classes / gt_counts: int32 [batch,max_objects] / [batch].  Outputs (all device, float32, fully
+ * written): input_mask [batch,A], box_delta_input / box_input [batch,A,4], labels [batch,A,classes];
+ * anchor_index int32 [batch,max_objects] (-1 beyond gt_counts). */
+int sqdet_build_labels(const double* anchors_f64, const double* gt_boxes_f64, const int* gt_classes,
+                       const int* gt_counts, float* input_mask, float* box_delta_input, float* box_input, float* labels,
+                       int* anchor_index, int batch, int num_anchors, int max_objects, int classes,
+                       sqdet_stream_t stream);
+
 /* -------------------------------------------------------- pre-processing --
  * Replaces the caller-side image preparation of demo.py:186-190 / imdb.py:101-118:
  *   im = cv2.imread(f).astype(float32); im = cv2.resize(im, (dst_w, dst_h)); input = im - BGR_MEANS

@@ -30,6 +30,7 @@ SOURCES = [
     ("pool.hip", []),
     ("bn.hip", ["-ffp-contract=off"]),
     ("preproc.hip", ["-ffp-contract=off"]),
+    ("labels.hip", ["-ffp-contract=off"]),
     ("postproc.hip", ["-ffp-contract=off"]),
     ("filter_fast.hip", ["-ffp-contract=off"]),
     ("train.hip", ["-ffp-contract=off"]),

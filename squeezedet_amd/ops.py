@@ -322,6 +322,28 @@ class MomentumOptimizer:
             pass
 
 
+def build_labels(anchor_box, gt_boxes, gt_classes, gt_counts, classes, device=None):
+    """Anchor assignment + dense label tensors on the GPU (imdb.py:195-239, train.py:163-224).
+    anchor_box: mc.ANCHOR_BOX [A,4] float64; gt_boxes [B,M,4] float64 (cx,cy,w,h in network-input pixels, rows
+    beyond gt_counts[b] ignored); gt_classes [B,M]; gt_counts [B].  Returns (input_mask [B,A], box_delta_input
+    [B,A,4], box_input [B,A,4], labels [B,A,C]) float32 and anchor_index [B,M] int32, all on the device."""
+    dev = torch.device(device) if device is not None else (gt_boxes.device if isinstance(gt_boxes, torch.Tensor) else torch.device("cuda", torch.cuda.current_device()))
+    to = lambda v, dt: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))).to(dev, dt).contiguous()
+    anc, gt = to(anchor_box, torch.float64), to(gt_boxes, torch.float64)
+    cls, cnt = to(gt_classes, torch.int32), to(gt_counts, torch.int32)
+    B, M = int(gt.shape[0]), int(gt.shape[1])
+    A = int(anc.shape[0])
+    mask = torch.empty((B, A), dtype=torch.float32, device=dev)
+    delta = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
+    box = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
+    lab = torch.empty((B, A, int(classes)), dtype=torch.float32, device=dev)
+    aidx = torch.empty((B, M), dtype=torch.int32, device=dev)
+    check(lib().sqdet_build_labels(_dev(anc, "anchors"), _dev(gt, "gt_boxes"), _dev(cls, "gt_classes"), _dev(cnt, "gt_counts"),
+                                   _dev(mask, "mask"), _dev(delta, "delta"), _dev(box, "box"), _dev(lab, "labels"),
+                                   _dev(aidx, "aidx"), B, A, M, int(classes), stream_ptr()), "sqdet_build_labels")
+    return mask, delta, box, lab, aidx
+
+
 def preprocess_bgr(images_u8, dst_h, dst_w, bgr_means, dtype=torch.float32):
     """uint8 BGR [N,H,W,3] (device) -> resized (cv2 INTER_LINEAR), mean-subtracted NHWC network input
     (demo.py:186-190) in `dtype`."""

@@ -215,3 +215,55 @@ def test_momentum_clip_optimizer_vs_oracle():
     for k, off, c in zip(shapes, offs, cnts):
         _close(P[off:off + c].reshape(shapes[k]), p_ref[k], rel=1e-6, what=k + " param")
         _close(M[off:off + c].reshape(shapes[k]), m_ref[k], rel=1e-6, what=k + " momentum")
+
+
+@pytest.mark.parametrize("cfg", ["squeezeDet", "res50"])
+def test_build_labels_vs_oracle(cfg):
+    """sqdet_build_labels (anchor assignment + dense placeholders, imdb.py:195-239 + train.py:163-224) against the
+    restated per-image Python: anchor indices bit-exact, incl. boxes competing for one anchor (identical boxes),
+    a box that overlaps nothing (nearest free anchor) and empty images."""
+    ops = _ops()
+    mc = O.kitti_squeezeDet_config() if cfg == "squeezeDet" else O.kitti_res50_config()
+    rs = np.random.RandomState(77)
+    B, M, A, C = 6, 12, mc.ANCHORS, mc.CLASSES
+    gt = np.zeros((B, M, 4), np.float64)
+    cls = rs.randint(0, C, size=(B, M)).astype(np.int32)
+    cnt = np.array([8, 12, 0, 5, 3, 1], np.int32)
+    for b in range(B):
+        n = cnt[b]
+        gt[b, :n] = np.stack([rs.uniform(0, mc.IMAGE_WIDTH, n), rs.uniform(0, mc.IMAGE_HEIGHT, n), rs.uniform(10, 400, n), rs.uniform(10, 250, n)], 1)
+    gt[1, 1] = gt[1, 0]; gt[1, 2] = gt[1, 0]                  # three identical boxes: 2nd / 3rd take the next-best anchors
+    gt[3, 2] = [-900.0, -700.0, 30.0, 20.0]                   # overlaps no anchor: nearest free anchor (imdb.py:222-229)
+    gt[4, 0] = [mc.ANCHOR_BOX[5000][0], mc.ANCHOR_BOX[5000][1], mc.ANCHOR_BOX[5000][2], mc.ANCHOR_BOX[5000][3]]   # IoU exactly 1
+    mask, delta, box, lab, aidx = ops.build_labels(mc.ANCHOR_BOX, gt, cls, cnt, C, device=DEV)
+    torch.cuda.synchronize()
+    r_mask, r_delta = np.zeros((B, A), np.float32), np.zeros((B, A, 4), np.float32)
+    r_box, r_lab = np.zeros((B, A, 4), np.float32), np.zeros((B, A, C), np.float32)
+    for b in range(B):
+        aidxs, deltas = TO.assign_anchors(mc, gt[b, :cnt[b]])
+        assert len(set(aidxs)) == len(aidxs)
+        assert aidx[b, :cnt[b]].cpu().tolist() == aidxs, "image %d" % b
+        assert (aidx[b, cnt[b]:] == -1).all()
+        for j, a in enumerate(aidxs):
+            r_mask[b, a] = 1
+            r_delta[b, a] = np.asarray(deltas[j], np.float64).astype(np.float32)
+            r_box[b, a] = gt[b, j].astype(np.float32)
+            r_lab[b, a, cls[b, j]] = 1
+    assert aidx[4, 0].item() == 5000
+    assert np.array_equal(mask.cpu().numpy(), r_mask) and np.array_equal(lab.cpu().numpy(), r_lab)
+    assert np.array_equal(box.cpu().numpy(), r_box)
+    np.testing.assert_allclose(delta.cpu().numpy(), r_delta, rtol=1e-6, atol=1e-7)
+
+
+def test_training_step_from_gpu_built_labels():
+    """The trainer accepts the device tensors of build_labels directly (no host round trip of the labels)."""
+    ops = _ops()
+    tr, mc, params = _trainer()
+    omc = O.squeezeDet_config_for_input(128, 256)
+    rs = np.random.RandomState(3)
+    gt = np.stack([rs.uniform(0, 256, (2, 4)), rs.uniform(0, 128, (2, 4)), rs.uniform(20, 120, (2, 4)), rs.uniform(20, 90, (2, 4))], 2)
+    cls, cnt = rs.randint(0, 3, (2, 4)).astype(np.int32), np.array([4, 2], np.int32)
+    mask, delta, box, lab, _ = ops.build_labels(omc.ANCHOR_BOX, gt, cls, cnt, 3, device=DEV)
+    x = O.synthetic_images(2, 128, 256, seed=9)
+    out = tr.step(x, mask, delta, box, lab)
+    assert out["num_objects"] == 6.0 and np.isfinite(float(out["bbox_loss"]))

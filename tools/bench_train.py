@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Training throughput of SqueezeDet on MI355X: BASELINE.json configs[2], "SqueezeDet fp32 training
 batch=20/GPU, RCCL grad all-reduce, synthetic KITTI labels" (network input 1248x384, the reference's
-training size).  One step = forward (dropout on) + loss + backward + flat-bucket gradient all-reduce
+training size).  One step = GPU label build + forward (dropout on) + loss + backward + flat-bucket gradient all-reduce
 + clipped Momentum update.  Launch with torch.distributed.run for N > 1 (one process per GPU).
 
     python tools/bench_train.py --steps 10 --warmup 3
@@ -18,30 +18,18 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def synthetic_dense_labels(mc, batch, seed):
-    """Seeded KITTI-like dense labels without the oracle: n~U{1..8} boxes per image,
-    each assigned to the anchor of highest IoU (dataset/imdb.py:195-239 semantics, vectorised)."""
+def synthetic_ground_truth(mc, batch, seed, max_objects=8):
+    """Seeded KITTI-like ground truth: n~U{1..8} boxes per image, w in [20,300], h in [20,200],
+    centre uniform in the image, class U{0..C-1} -- as padded arrays for sqdet_build_labels."""
     rs = np.random.RandomState(seed)
-    anchor = np.asarray(mc.ANCHOR_BOX)
-    A, C = mc.ANCHORS, mc.CLASSES
-    mask = np.zeros((batch, A), np.float32)
-    delta = np.zeros((batch, A, 4), np.float32)
-    box = np.zeros((batch, A, 4), np.float32)
-    labels = np.zeros((batch, A, C), np.float32)
-    for b in range(batch):
-        for _ in range(rs.randint(1, 9)):
-            g = np.array([rs.uniform(0, mc.IMAGE_WIDTH), rs.uniform(0, mc.IMAGE_HEIGHT), rs.uniform(20, 300), rs.uniform(20, 200)])
-            lr = np.maximum(np.minimum(anchor[:, 0] + anchor[:, 2] / 2, g[0] + g[2] / 2) - np.maximum(anchor[:, 0] - anchor[:, 2] / 2, g[0] - g[2] / 2), 0)
-            tb = np.maximum(np.minimum(anchor[:, 1] + anchor[:, 3] / 2, g[1] + g[3] / 2) - np.maximum(anchor[:, 1] - anchor[:, 3] / 2, g[1] - g[3] / 2), 0)
-            inter = lr * tb
-            iou = inter / (anchor[:, 2] * anchor[:, 3] + g[2] * g[3] - inter)
-            iou[mask[b] > 0] = -1
-            a = int(np.argmax(iou)) if iou.max() > 0 else int(np.argmin(((anchor - g) ** 2).sum(1) + 1e12 * (mask[b] > 0)))
-            mask[b, a] = 1
-            delta[b, a] = [(g[0] - anchor[a, 0]) / anchor[a, 2], (g[1] - anchor[a, 1]) / anchor[a, 3], np.log(g[2] / anchor[a, 2]), np.log(g[3] / anchor[a, 3])]
-            box[b, a] = g
-            labels[b, a, rs.randint(0, C)] = 1
-    return mask, delta, box, labels
+    gt = np.zeros((batch, max_objects, 4), np.float64)
+    cls = rs.randint(0, mc.CLASSES, size=(batch, max_objects)).astype(np.int32)
+    cnt = rs.randint(1, max_objects + 1, size=batch).astype(np.int32)
+    gt[..., 0] = rs.uniform(0, mc.IMAGE_WIDTH, (batch, max_objects))
+    gt[..., 1] = rs.uniform(0, mc.IMAGE_HEIGHT, (batch, max_objects))
+    gt[..., 2] = rs.uniform(20, 300, (batch, max_objects))
+    gt[..., 3] = rs.uniform(20, 200, (batch, max_objects))
+    return gt, cls, cnt
 
 
 def main():
@@ -73,15 +61,20 @@ def main():
     model.load_params(synthetic.synthetic_params(model, seed=0))      # same weights on every rank
     tr = trainer(model)
     x = synthetic.synthetic_images(args.batch, mc.IMAGE_HEIGHT, mc.IMAGE_WIDTH, seed=100 + rank).to(dev)
-    lab = [torch.from_numpy(a).to(dev) for a in synthetic_dense_labels(mc, args.batch, seed=200 + rank)]
+    # ground truth lives on the device; the anchor assignment + dense label build (imdb.py:195-239,
+    # train.py:163-224) runs on the GPU inside every step, like the reference's per-batch _load_data
+    from squeezedet_amd import ops
+    anchors = torch.from_numpy(np.asarray(mc.ANCHOR_BOX, np.float64)).to(dev)
+    gt, gcls, gcnt = [torch.from_numpy(a).to(dev) for a in synthetic_ground_truth(mc, args.batch, seed=200 + rank)]
+    one_step = lambda: tr.step(x, *ops.build_labels(anchors, gt, gcls, gcnt, mc.CLASSES)[:4])
     for _ in range(args.warmup):
-        out = tr.step(x, *lab)
+        out = one_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier(device_ids=[local_rank])
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = tr.step(x, *lab)
+        out = one_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier(device_ids=[local_rank])
