@@ -35,6 +35,7 @@ struct FireArgs {
   int nch_s;       // 64-byte chunks of the squeeze channels
   int e_nt;        // tiles per packed group of the expand convs (same for both)
   int e1_tiles, e3_tiles;   // cout tiles (all groups) of expand1x1 / expand3x3
+  unsigned x_bytes;         // size of the input tensor (32-bit buffer offsets)
 };
 
 // MT = tile rows per phase-B work item: 8 (a wave walks the whole tile per cout item) or 4 (two row
@@ -42,7 +43,7 @@ struct FireArgs {
 // paired one 9-tap item with one 1-tap item; with MT = 4 every wave gets the same work and the
 // accumulators halve, so 4 workgroups fit on a CU instead of 2).
 template <typename T, int NTS, int NTW, int MT>
-__global__ __launch_bounds__(256, (MT == 4 ? 4 : (NTW <= 3 ? 3 : 2))) void fire_fused(FireArgs a) {  // 3 waves/SIMD when 96 accumulators fit in 168 VGPRs
+__global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused(FireArgs a) {
   constexpr int KG = Tr<T>::KG;
   constexpr int KC = 4 * KG;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -53,57 +54,91 @@ __global__ __launch_bounds__(256, (MT == 4 ? 4 : (NTW <= 3 ? 3 : 2))) void fire_
   const int ty = b % a.tiles_y;
   const int n = b / a.tiles_y;
   const int oy0 = ty * FROWS, ox0 = tx * FCOLS;
+  float* bl = reinterpret_cast<float*>(lds + a.nch_s * FCHUNK);                 // biases [b1 | b3 | bs]
+  unsigned char* wring = lds + a.nch_s * FCHUNK + ((a.E1 + a.E3 + a.S) * 4 + 15) / 16 * 16;   // squeeze-weight ring
 
   // ---------------------------------------------------------------- phase A: squeeze on the halo
+  // The K loop has only MB*NTS <= 18 MFMAs per 64-byte chunk of input channels, far less than a memory
+  // latency, and up to 16 chunks: with a one-chunk look-ahead every chunk cost a full latency (17 us of a
+  // 62 us fire10).  Now PD chunks are in flight: the input fragments in registers (raw buffer loads: an
+  // out-of-range offset returns the zero padding without a branch, so the load count per chunk is fixed),
+  // the squeeze weights straight into an LDS ring by global_load_lds (no registers; every wave fetches
+  // FW of the NTS fragments and all four waves read all of them).  One barrier per chunk; the ring has
+  // PD+1 slots, so the refill issued after the barrier of chunk c lands in the slot chunk c-1 just left.
   {
-    // zero the channel padding of the last squeeze chunk (S not a multiple of 64 bytes)
-    const int s_pieces = a.S * (int)sizeof(T) / 16;
-    const int pad = a.nch_s * 4 - s_pieces;
-    for (int idx = threadIdx.x; idx < FHP * pad; idx += 256) {
-      const int P = idx / pad, q = s_pieces + (idx - P * pad);
-      *reinterpret_cast<i32x4*>(lds + (q >> 2) * FCHUNK + P * 64 + (((q & 3) ^ ((P >> 1) & 3)) << 4)) = i32x4{0, 0, 0, 0};
-    }
     constexpr int MB = FBLK / 4;   // 3 pixel blocks per wave
+    constexpr int PD = 4;          // chunks in flight
+    constexpr int RS = PD + 1;     // ring slots
+    constexpr int FW = (NTS + 3) / 4;   // weight fragments fetched per wave per chunk
+    constexpr int PER = MB + FW;   // memory instructions per wave per chunk
     int P[MB];
     bool inimg[MB];
-    const T* src[MB];
-    const T* x = reinterpret_cast<const T*>(a.x);
+    unsigned xoff[MB];
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       P[mb] = (wave * MB + mb) * 16 + j;
       const int r = P[mb] / (FCOLS + 2), c = P[mb] - r * (FCOLS + 2);
       const int iy = oy0 - 1 + r, ix = ox0 - 1 + c;
       inimg[mb] = P[mb] < FHP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      src[mb] = x + (((size_t)n * a.H + (inimg[mb] ? iy : 0)) * a.W + (inimg[mb] ? ix : 0)) * a.Cin + g * KG;
+      xoff[mb] = inimg[mb] ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + g * KG) * (int)sizeof(T)) : OOB;
+    }
+    i32x4 xq[PD][MB];
+    const i32x4* wsg = reinterpret_cast<const i32x4*>(a.ws) + lane;
+    auto issue = [&](int c, i32x4 (&xr)[MB]) {          // chunk c (uniform c < nch_x)
+      const bool k_ok = c * 4 + g < a.x_pieces;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+        xr[mb] = __builtin_amdgcn_raw_buffer_load_b128(rx, (k_ok && xoff[mb] != OOB) ? xoff[mb] + c * 64 : OOB, 0, 0);
+      unsigned char* slot = wring + (c % RS) * (NTS * 1024);
+#pragma unroll
+      for (int f = 0; f < FW; ++f) {
+        const int t = (wave + 4 * f) % NTS;               // (duplicates when NTS is not a multiple of 4: same bytes)
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(wsg + (c * NTS + t) * 64),
+                                         (void __attribute__((address_space(3)))*)(slot + t * 1024), 16, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < PD; ++u)
+      if (u < a.nch_x) issue(u, xq[u]);
+    // biases -> LDS (read back with ds_read: off the global-memory critical path); visible after the first barrier
+    for (int i = threadIdx.x; i < a.E1 + a.E3 + a.S; i += 256)
+      bl[i] = i < a.E1 ? a.b1[i] : (i < a.E1 + a.E3 ? a.b3[i - a.E1] : a.bs[i - a.E1 - a.E3]);
+    // zero the channel padding of the last squeeze chunk (S not a multiple of 64 bytes)
+    const int s_pieces = a.S * (int)sizeof(T) / 16;
+    const int pad = a.nch_s * 4 - s_pieces;
+    for (int idx = threadIdx.x; idx < FHP * pad; idx += 256) {
+      const int PP = idx / pad, q = s_pieces + (idx - PP * pad);
+      *reinterpret_cast<i32x4*>(lds + (q >> 2) * FCHUNK + PP * 64 + (((q & 3) ^ ((PP >> 1) & 3)) << 4)) = i32x4{0, 0, 0, 0};
     }
     f32x4 acc[MB][NTS];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int t = 0; t < NTS; ++t) acc[mb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const i32x4* wsp = reinterpret_cast<const i32x4*>(a.ws) + lane;
-    const i32x4 zero = {0, 0, 0, 0};
-    auto load_step = [&](int c, i32x4 (&bf)[MB], i32x4 (&af)[NTS]) {
-      const bool k_ok = c * 4 + g < a.x_pieces;
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) bf[mb] = (inimg[mb] && k_ok) ? *reinterpret_cast<const i32x4*>(src[mb] + c * KC) : zero;
-#pragma unroll
-      for (int t = 0; t < NTS; ++t) af[t] = wsp[(c * NTS + t) * 64];
-    };
-    i32x4 bc[MB], bn[MB], ac[NTS], an[NTS];
-    load_step(0, bc, ac);
 #pragma unroll 1
-    for (int c = 0; c < a.nch_x; ++c) {
-      if (c + 1 < a.nch_x) load_step(c + 1, bn, an);
+    for (int c0 = 0; c0 < a.nch_x; c0 += PD) {
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
+      for (int u = 0; u < PD; ++u) {
+        const int c = c0 + u;
+        if (c >= a.nch_x) break;
+        // everything up to chunk c has landed when at most the later chunks' instructions are outstanding
+        const int later = min(PD - 1, a.nch_x - 1 - c);
+        if (later >= 3) __builtin_amdgcn_s_waitcnt(0x0F70 | ((3 * PER) & 0xF) | (((3 * PER) >> 4) << 14));
+        else if (later == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * PER) & 0xF) | (((2 * PER) >> 4) << 14));
+        else if (later == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | ((1 * PER) & 0xF) | (((1 * PER) >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();                                  // every wave's share of the weights is in the ring
+        const unsigned char* slot = wring + (c % RS) * (NTS * 1024);
+        i32x4 af[NTS];
 #pragma unroll
-        for (int t = 0; t < NTS; ++t) mma16<T>(acc[mb][t], ac[t], bc[mb]);
-      if (c + 1 < a.nch_x) {
+        for (int t = 0; t < NTS; ++t) af[t] = *reinterpret_cast<const i32x4*>(slot + t * 1024 + lane * 16);
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) bc[mb] = bn[mb];
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int t = 0; t < NTS; ++t) ac[t] = an[t];
+          for (int t = 0; t < NTS; ++t) mma16<T>(acc[mb][t], af[t], xq[u][mb]);
+        if (c + PD < a.nch_x) issue(c + PD, xq[u]);
       }
     }
     // bias + ReLU -> storage type -> LDS squeeze tile; lane = pixel P, channels g*4*NTS + 4t .. +4
@@ -111,7 +146,7 @@ __global__ __launch_bounds__(256, (MT == 4 ? 4 : (NTW <= 3 ? 3 : 2))) void fire_
     for (int t = 0; t < NTS; ++t) {
       const int ch0 = g * 4 * NTS + 4 * t;
       if (ch0 < a.S) {
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bs + ch0);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + a.E1 + a.E3 + ch0);
         const int q = ch0 / KG;                         // 16-byte piece of the pixel's channel vector
         const int sub = (ch0 - q * KG) * (int)sizeof(T);  // byte offset inside the piece (0 or 8 for f16, 0 for f32)
 #pragma unroll
@@ -130,77 +165,103 @@ __global__ __launch_bounds__(256, (MT == 4 ? 4 : (NTW <= 3 ? 3 : 2))) void fire_
   __syncthreads();
 
   // ---------------------------------------------------------------- phase B: expand3x3 + expand1x1
+  // On the small late maps the whole grid is ONE wave of workgroups: the kernel time is a single workgroup's
+  // critical path, so every exposed memory latency on it counts.  Hence: biases come from LDS (filled at
+  // kernel start), the weight fragments run through a ring of WD steps kept in flight (they come from L2,
+  // ~1-2k cycles away under load, and one step is only MT*NTW <= 24 MFMAs), and the NEXT item's first
+  // fragments are requested before the current item's epilogue, so they land while the stores go out.
   constexpr int RB = FROWS / MT;   // row blocks per cout item
+  constexpr int WD = (MT == 4 && NTW <= 4) ? 2 : (NTW <= 3 ? 4 : 3);
   T* y = reinterpret_cast<T*>(a.y);
   const int ox = ox0 + j;
   const int ctot = a.E1 + a.E3;
   const int n3 = a.e3_tiles / NTW, n1 = a.e1_tiles / NTW;
-  for (int witem = wave; witem < (n3 + n1) * RB; witem += 4) {   // heavy (9-tap) items first, then the 1-tap ones
-    const int item = witem / RB, m0 = (witem - item * RB) * MT;
-    const bool is3 = item < n3;
-    const int tile0 = (is3 ? item : item - n3) * NTW;
-    const int group = tile0 / a.e_nt, n0 = tile0 - group * a.e_nt;
-    const int taps = is3 ? 9 : 1;
-    const int steps = taps * a.nch_s;
-    const i32x4* wbase = reinterpret_cast<const i32x4*>(is3 ? a.w3 : a.w1) + ((size_t)group * steps * a.e_nt + n0) * 64 + lane;
+  const int nw = (n3 + n1) * RB;   // work items: heavy (9-tap) ones first, then the 1-tap ones
+  struct Item {
+    bool is3;
+    int steps, group, n0, m0;
+    const i32x4* wbase;
+  };
+  auto item_of = [&](int witem) {
+    Item it;
+    const int item = witem / RB;
+    it.m0 = (witem - item * RB) * MT;
+    it.is3 = item < n3;
+    const int tile0 = (it.is3 ? item : item - n3) * NTW;
+    it.group = tile0 / a.e_nt;
+    it.n0 = tile0 - it.group * a.e_nt;
+    it.steps = (it.is3 ? 9 : 1) * a.nch_s;
+    it.wbase = reinterpret_cast<const i32x4*>(it.is3 ? a.w3 : a.w1) + ((size_t)it.group * (it.is3 ? 9 : 1) * a.nch_s * a.e_nt + it.n0) * 64 + lane;
+    return it;
+  };
+  // Steps walk chunk-major, tap-minor -- the accumulation order of conv3x3_tile, so the result is bitwise
+  // the unfused one; the packed fragment of (tap, chunk) sits at step tap*nch_s + chunk.  expand1x1 = the
+  // centre tap only.
+  auto frag = [&](const Item& it, int s) {
+    const int c = it.is3 ? s / 9 : s;
+    const int tap = it.is3 ? s - c * 9 : 0;
+    return it.wbase + (size_t)(tap * a.nch_s + c) * a.e_nt * 64;
+  };
+  i32x4 afr[WD][NTW];
+  auto fill = [&](const Item& it) {
+#pragma unroll
+    for (int u = 0; u < WD; ++u) {
+      if (u < it.steps) {
+        const i32x4* wp = frag(it, u);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) afr[u][t] = wp[t * 64];
+      }
+    }
+  };
+  if (wave < nw) fill(item_of(wave));
+  for (int witem = wave; witem < nw; witem += 4) {
+    const Item it = item_of(witem);
+    const int m0 = it.m0;
     f32x4 acc[MT][NTW];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // Steps walk chunk-major, tap-minor -- the accumulation order of conv3x3_tile, so the result is
-    // bitwise the unfused one; the packed fragment of (tap, chunk) sits at step tap*nch_s + chunk.
-    // expand1x1 = the centre tap only.
-    auto frag = [&](int s) {
-      const int c = is3 ? s / 9 : s;
-      const int tap = is3 ? s - c * 9 : 0;
-      return wbase + (size_t)(tap * a.nch_s + c) * a.e_nt * 64;
-    };
-    i32x4 af[NTW], afn[NTW];
-    {
-      const i32x4* wp = frag(0);
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) af[t] = wp[t * 64];
-    }
 #pragma unroll 1
-    for (int s = 0; s < steps; ++s) {
-      if (s + 1 < steps) {
-        const i32x4* wp = frag(s + 1);
+    for (int s0 = 0; s0 < it.steps; s0 += WD) {
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) afn[t] = wp[t * 64];
-      }
-      const int c = is3 ? s / 9 : s;
-      const int tap = is3 ? s - c * 9 : 4;
-      const int dy = tap / 3, dx = tap - dy * 3;
-      const unsigned char* lchunk = lds + c * FCHUNK;
-      const int P0 = dy * (FCOLS + 2) + j + dx;
-      const int h0 = P0 >> 1;
-      i32x4 bf[MT];
+      for (int u = 0; u < WD; ++u) {
+        const int s = s0 + u;
+        if (s >= it.steps) break;
+        const int c = it.is3 ? s / 9 : s;
+        const int tap = it.is3 ? s - c * 9 : 4;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const unsigned char* lchunk = lds + c * FCHUNK;
+        const int P0 = dy * (FCOLS + 2) + j + dx;
+        const int h0 = P0 >> 1;
+        i32x4 bf[MT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int slot = g ^ ((h0 + m0 + m) & 3);
-        bf[m] = *reinterpret_cast<const i32x4*>(lchunk + (P0 + (FCOLS + 2) * (m0 + m)) * 64 + (slot << 4));
-      }
+        for (int m = 0; m < MT; ++m) {
+          const int slot = g ^ ((h0 + m0 + m) & 3);
+          bf[m] = *reinterpret_cast<const i32x4*>(lchunk + (P0 + (FCOLS + 2) * (m0 + m)) * 64 + (slot << 4));
+        }
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], af[t], bf[m]);
-      if (s + 1 < steps) {
+          for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], afr[u][t], bf[m]);
+        if (s + WD < it.steps) {
+          const i32x4* wp = frag(it, s + WD);
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) af[t] = afn[t];
+          for (int t = 0; t < NTW; ++t) afr[u][t] = wp[t * 64];
+        }
       }
     }
+    if (witem + 4 < nw) fill(item_of(witem + 4));   // the ring is empty here: next item's first fragments
     // epilogue: bias + ReLU, 4*NTW consecutive channels per lane into the concat tensor
-    const int cout = is3 ? a.E3 : a.E1;
-    const int coff = is3 ? a.E1 : 0;
-    const float* bias_p = is3 ? a.b3 : a.b1;
-    const int cb = group * 16 * a.e_nt + g * 4 * a.e_nt + n0 * 4;
+    const int cout = it.is3 ? a.E3 : a.E1;
+    const int coff = it.is3 ? a.E1 : 0;
+    const int cb = it.group * 16 * a.e_nt + g * 4 * a.e_nt + it.n0 * 4;
     f32x4 bias[NTW];
     int nt_valid = 0;
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
       const bool ok = cb + t * 4 < cout;
-      bias[t] = ok ? *reinterpret_cast<const f32x4*>(bias_p + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      bias[t] = ok ? *reinterpret_cast<const f32x4*>(bl + coff + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       nt_valid += ok ? 1 : 0;
     }
     if (ox < a.W) {
@@ -222,23 +283,36 @@ __global__ __launch_bounds__(256, (MT == 4 ? 4 : (NTW <= 3 ? 3 : 2))) void fire_
   }
 }
 
+template <typename T, int NTS, int NTW, int MT>
+static void launch_ff(const FireArgs& a, size_t lds, hipStream_t st) {
+  static bool big_lds_ok = false;   // > 64 KiB of dynamic LDS has to be allowed once per kernel
+  if (lds > 65536 && !big_lds_ok) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_fused<T, NTS, NTW, MT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    big_lds_ok = true;
+  }
+  const dim3 grid((unsigned)(a.N * a.tiles_x * a.tiles_y));
+  hipLaunchKernelGGL((fire_fused<T, NTS, NTW, MT>), grid, dim3(256), lds, st, a);
+}
+
 template <typename T, int NTS>
 static bool dispatch_fire_ntw(const FireArgs& a, int ntw, size_t lds, hipStream_t st) {
-  const dim3 grid((unsigned)(a.N * a.tiles_x * a.tiles_y));
   // few cout items (fire2..5: 2 or 4): split the tile rows too, so all four waves carry equal work
   const bool split_rows = (a.e3_tiles + a.e1_tiles) / ntw <= 4;
   switch (ntw) {
     case 2:
-      if (split_rows) hipLaunchKernelGGL((fire_fused<T, NTS, 2, 4>), grid, dim3(256), lds, st, a);
-      else hipLaunchKernelGGL((fire_fused<T, NTS, 2, 8>), grid, dim3(256), lds, st, a);
+      if (split_rows) launch_ff<T, NTS, 2, 4>(a, lds, st);
+      else launch_ff<T, NTS, 2, 8>(a, lds, st);
       return true;
     case 3:
-      if (split_rows) hipLaunchKernelGGL((fire_fused<T, NTS, 3, 4>), grid, dim3(256), lds, st, a);
-      else hipLaunchKernelGGL((fire_fused<T, NTS, 3, 8>), grid, dim3(256), lds, st, a);
+      // (96-cout groups.  A whole group -- 6 tiles -- per item for half of the rows gives a lane 24 consecutive
+      // channels = 16-byte stores instead of 8-byte ones, but measured equal: not instantiated.)
+      if (split_rows) launch_ff<T, NTS, 3, 4>(a, lds, st);
+      else launch_ff<T, NTS, 3, 8>(a, lds, st);
       return true;
     case 4:
-      if (split_rows) hipLaunchKernelGGL((fire_fused<T, NTS, 4, 4>), grid, dim3(256), lds, st, a);
-      else hipLaunchKernelGGL((fire_fused<T, NTS, 4, 8>), grid, dim3(256), lds, st, a);
+      if (split_rows) launch_ff<T, NTS, 4, 4>(a, lds, st);
+      else launch_ff<T, NTS, 4, 8>(a, lds, st);
       return true;
     default: return false;
   }
@@ -269,7 +343,7 @@ bool fire_fused_eligible(int cin, int s, int e1, int e3, int dtype) {
   const int ntw = g1.nt == 6 ? 3 : (g1.nt == 4 ? 4 : (g1.nt == 2 ? 2 : 0));
   if (!ntw) return false;
   if ((g1.nt * g1.ngroups) % ntw || (g3.nt * g3.ngroups) % ntw) return false;
-  return (size_t)g1.nchunk * FCHUNK <= 60000;
+  return (size_t)g1.nchunk * FCHUNK + (size_t)(e1 + e3 + s) * 4 + 16 + 5 * (size_t)gs.nt * 1024 <= 80000;
 }
 
 // *handled = false: not eligible, run the three convs separately.
@@ -291,14 +365,17 @@ int fire_fused_launch(const void* x, const void* ws, const float* bs, const void
   if (!ntw) return SQDET_OK;
   const int e1_tiles = g1.nt * g1.ngroups, e3_tiles = g3.nt * g3.ngroups;
   if (e1_tiles % ntw || e3_tiles % ntw) return SQDET_OK;
-  const size_t lds = (size_t)g1.nchunk * FCHUNK;
-  if (lds > 60000) return SQDET_OK;
+  // squeeze tile + biases + the 5-slot squeeze-weight ring
+  const size_t lds = (size_t)g1.nchunk * FCHUNK + (size_t)(e1 + e3 + s) * 4 + 16 + 5 * (size_t)gs.nt * 1024;
+  if (lds > 80000) return SQDET_OK;
+  if ((long)n * h * w * cin * esz >= (1L << 31)) return SQDET_OK;   // 32-bit buffer offsets
   FireArgs a;
   a.x = x; a.y = y; a.ws = ws; a.w1 = w1; a.w3 = w3; a.bs = bs; a.b1 = b1; a.b3 = b3;
   a.N = n; a.H = h; a.W = w; a.Cin = cin; a.S = s; a.E1 = e1; a.E3 = e3;
   a.tiles_x = (w + FCOLS - 1) / FCOLS; a.tiles_y = (h + FROWS - 1) / FROWS;
   a.nch_x = gs.nchunk; a.x_pieces = cin * esz / 16; a.nch_s = g1.nchunk;
   a.e_nt = g1.nt; a.e1_tiles = e1_tiles; a.e3_tiles = e3_tiles;
+  a.x_bytes = (unsigned)((long)n * h * w * cin * esz);
   if ((long)n * a.tiles_x * a.tiles_y > 0x7fffffffL) return SQDET_OK;
   const bool ok = dtype == SQDET_F16 ? dispatch_fire<f16>(a, gs.nt, ntw, lds, st) : dispatch_fire<float>(a, gs.nt, ntw, lds, st);
   if (!ok) return SQDET_OK;
