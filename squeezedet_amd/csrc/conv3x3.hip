@@ -77,7 +77,10 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
   const int wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
 
-  int b = blockIdx.x;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (own L2 each); every XCD gets a contiguous band of
+  // tiles so the halos shared by neighbouring tiles are fetched into ONE L2 instead of up to eight.
+  int b = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));   // gridDim.x is a multiple of 8
+  if (b >= a.c.N * a.tiles_x * a.tiles_y) return;
   const int tx = b % a.tiles_x; b /= a.tiles_x;
   const int ty = b % a.tiles_y;
   const int n = b / a.tiles_y;
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
 
 template <typename T, int MT, int NTW, bool SPLITK>
 static void launch_tile(const TileArgs& a, int grid_y, size_t lds, hipStream_t st) {
-  const dim3 grid((unsigned)(a.c.N * a.tiles_x * a.tiles_y), (unsigned)grid_y);
+  const dim3 grid((unsigned)((a.c.N * a.tiles_x * a.tiles_y + 7) / 8 * 8), (unsigned)grid_y);
   hipLaunchKernelGGL((conv3x3_tile<T, MT, NTW, SPLITK>), grid, dim3(256), lds, st, a);
 }
 

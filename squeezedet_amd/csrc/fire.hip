@@ -49,7 +49,10 @@ __global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
-  int b = blockIdx.x;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (own L2 each); every XCD gets a contiguous band of
+  // tiles so the halos shared by neighbouring tiles are fetched into ONE L2 instead of up to eight.
+  int b = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));   // gridDim.x is a multiple of 8
+  if (b >= a.N * a.tiles_x * a.tiles_y) return;
   const int tx = b % a.tiles_x; b /= a.tiles_x;
   const int ty = b % a.tiles_y;
   const int n = b / a.tiles_y;
@@ -291,7 +294,7 @@ static void launch_ff(const FireArgs& a, size_t lds, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     big_lds_ok = true;
   }
-  const dim3 grid((unsigned)(a.N * a.tiles_x * a.tiles_y));
+  const dim3 grid((unsigned)((a.N * a.tiles_x * a.tiles_y + 7) / 8 * 8));
   hipLaunchKernelGGL((fire_fused<T, NTS, NTW, MT>), grid, dim3(256), lds, st, a);
 }
 

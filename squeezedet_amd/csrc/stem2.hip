@@ -78,7 +78,10 @@ __global__ __launch_bounds__(256) void stem_strip(StemArgs a) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
-  int b = blockIdx.x;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (own L2 each); every XCD gets a contiguous band of
+  // tiles so the halos shared by neighbouring tiles are fetched into ONE L2 instead of up to eight.
+  int b = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));   // gridDim.x is a multiple of 8
+  if (b >= a.N * a.tiles_x * a.tiles_y) return;
   const int tx = b % a.tiles_x; b /= a.tiles_x;
   const int ty = b % a.tiles_y;
   const int n = b / a.tiles_y;
@@ -275,7 +278,7 @@ static int launch_strip(StemArgs a, bool aligned4, hipStream_t st) {
   const size_t lds = (size_t)TR * LROW * sizeof(T);
   a.tiles_x = (a.Wp + 4 * ZSP - 1) / (4 * ZSP);
   a.tiles_y = (a.Hp + ZPR - 1) / ZPR;
-  const dim3 grid((unsigned)(a.N * a.tiles_x * a.tiles_y));
+  const dim3 grid((unsigned)((a.N * a.tiles_x * a.tiles_y + 7) / 8 * 8));
   if (aligned4)
     hipLaunchKernelGGL((stem_strip<T, KS, NT, true>), grid, dim3(256), lds, st, a);
   else
