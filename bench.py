@@ -36,6 +36,7 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=1242)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="run decode + NMS on the forward's stream (no side stream)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--layer-table", default="", help="write the per-launch table (json) here")
     return ap.parse_args(argv)
@@ -129,8 +130,13 @@ def main(argv=None):
     layers = plan.layer_table()
 
     def step():
-        boxes, probs, cls = model.detect(x)
-        return model.filter_prediction_batch(boxes, probs, cls)
+        # forward on this stream; interpret_output + filter_prediction of the SAME batch on a side HIP stream behind
+        # an event (two-stage pipeline: the next batch's forward overlaps this batch's decode + NMS).  Every step
+        # does all of its work inside the timed region: the closing torch.cuda.synchronize() is device-wide.
+        if args.no_pipeline:
+            boxes, probs, cls = model.detect(x)
+            return model.filter_prediction_batch(boxes, probs, cls)
+        return model.detect_filter_pipelined(x)
 
     # ---- warm-up (untimed); the first pass also sizes every buffer ----
     for _ in range(max(args.warmup, 1)):

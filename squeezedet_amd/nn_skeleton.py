@@ -396,6 +396,26 @@ class ModelSkeleton:
         return tuple(self.run([self.det_boxes, self.det_probs, self.det_class], {self.image_input: images},
                               use_plan=use_plan))
 
+    def detect_filter_pipelined(self, images):
+        """One step of the serving loop as a two-stage pipeline: the network forward runs on the caller's stream,
+        interpret_output + filter_prediction (a few dozen microseconds of latency-bound work on 32 workgroups)
+        run on a side HIP stream behind an event, so the NEXT batch's forward starts while this batch's boxes
+        are being decoded and suppressed.  Returns filter_prediction_batch's tuple; the tensors are produced on
+        `self.post_stream` -- synchronise with it (or the device) before reading them."""
+        mc = self.mc
+        if getattr(self, "post_stream", None) is None:
+            self.post_stream = torch.cuda.Stream(device=self.device)
+            self._post_event = torch.cuda.Event()
+        (preds,) = self.run([self.preds], {self.image_input: images})
+        self._post_event.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.post_stream):
+            self.post_stream.wait_event(self._post_event)
+            boxes, probs, cls = ops.interpret_output(preds, self.anchors_f32(), mc.CLASSES, mc.ANCHOR_PER_GRID, mc.IMAGE_WIDTH,
+                                                     mc.IMAGE_HEIGHT, mc.EXP_THRESH)[:3]
+            out = self.filter_prediction_batch(boxes, probs, cls)
+            preds.record_stream(self.post_stream)      # the allocator must not hand preds' memory out before the side stream is done
+        return out
+
     # ------------------------------------------------------------------ filter_prediction
     def filter_prediction_batch(self, det_boxes, det_probs, det_class, max_out=None):
         """Batched, device-resident filter_prediction: returns (boxes [B,M,4], probs [B,M], cls [B,M] i32,

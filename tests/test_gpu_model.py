@@ -157,3 +157,23 @@ def test_full_config_properties_batch32_fp16():
     fb, fp, fc, fi = O.filter_prediction(O.squeezeDet_config_for_input(375, 1242), boxes[7].cpu().numpy(),
                                          probs[7].cpu().numpy(), cls[7].cpu().numpy(), return_index=True)
     np.testing.assert_array_equal(oi_[7, :n[7]], np.array(fi, np.int32))
+
+
+def test_pipelined_step_equals_sequential():
+    """detect_filter_pipelined (decode + NMS on a side stream behind an event, as bench.py runs the step) returns
+    exactly what detect -> filter_prediction_batch returns, step after step with different inputs in flight."""
+    m, mc, params, storage = _model("squeezeDet", torch.float16, 4, (375, 1242))
+    xs = [O.synthetic_images(4, 375, 1242, seed=s, storage=storage).to(DEV, torch.float16) for s in (3, 4, 5)]
+    seq = []
+    for x in xs:
+        b, p, c = m.detect(x)
+        seq.append([t.clone() for t in m.filter_prediction_batch(b, p, c)])
+    torch.cuda.synchronize()
+    outs = [m.detect_filter_pipelined(x) for x in xs]          # three steps in flight, no sync in between
+    torch.cuda.synchronize()
+    for got, want in zip(outs, seq):
+        n = want[4].cpu().numpy()
+        assert np.array_equal(got[4].cpu().numpy(), n)
+        for i in range(4):
+            for t in range(4):
+                assert torch.equal(got[t][i, :n[i]], want[t][i, :n[i]])
