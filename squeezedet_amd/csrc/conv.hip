@@ -318,7 +318,7 @@ int conv_algo() {
   return g_conv_algo;
 }
 void set_conv_algo(int v) { g_conv_algo = v; }
-static int g_fire_overlap = 0;  // measured on MI355X: the cross-stream fork/join costs more than the overlap wins (24.9k vs 26.3k img/s)
+static int g_fire_overlap = 0;  // two-stream schedules of the plan: measured slower on MI355X both times (see sqdet.h)
 int fire_overlap() { return g_fire_overlap; }
 
 // Experiment knobs (0 = built-in heuristic): see tune() call sites.

@@ -268,21 +268,26 @@ void* buf_ptr(const sqdet_net* net, int buf, const void* input, void* preds) {
   return net->workspace + net->buf_off[buf];
 }
 
-int run_layer(sqdet_net* net, const Layer& L, const void* input, void* preds, hipStream_t st) {
-  const void* x = buf_ptr(net, L.in_buf, input, preds);
-  void* y = buf_ptr(net, L.out_buf, input, preds);
+// Runs layer L on images [n0, n0 + nb) of the batch (activations are NHWC with the image index outermost, so a
+// sub-batch is a pointer offset).
+int run_layer_part(sqdet_net* net, const Layer& L, const void* input, void* preds, int n0, int nb, hipStream_t st) {
+  const size_t esz = dtype_size(net->dtype);
+  const int in_c = L.type == L_STEM ? 3 : L.cin;
+  const void* x = reinterpret_cast<const char*>(buf_ptr(net, L.in_buf, input, preds)) + (size_t)n0 * L.h * L.w * in_c * esz;
+  void* y = reinterpret_cast<char*>(buf_ptr(net, L.out_buf, input, preds)) +
+            (size_t)n0 * L.ho * L.wo * (L.type == L_POOL ? L.cin : L.y_cstride) * esz;
   if (L.type == L_CONV) {
     const void* wp = net->param_mem + net->params[L.kparam].offset;
     const float* b = reinterpret_cast<const float*>(
         net->param_mem + (L.fold >= 0 ? net->folds[L.fold].fbias_off : net->params[L.bparam].offset));
-    return conv2d_launch_ex(x, wp, b, y, net->batch, L.h, L.w, L.cin, L.cout, L.k, L.stride, L.pad_mode, L.relu,
+    return conv2d_launch_ex(x, wp, b, y, nb, L.h, L.w, L.cin, L.cout, L.k, L.stride, L.pad_mode, L.relu,
                             net->dtype, L.y_cstride, L.y_coffset, L.cin, 0, L.accum, st);
   }
   if (L.type == L_STEM) {
     const void* wp = net->param_mem + net->params[L.kparam].offset;
     const float* b = reinterpret_cast<const float*>(net->param_mem + net->params[L.bparam].offset);
     bool handled = false;
-    const int rc = stem_launch(x, wp, b, y, net->batch, L.h, L.w, L.cout, L.k, L.pad_mode, L.pool_pad_mode, net->dtype,
+    const int rc = stem_launch(x, wp, b, y, nb, L.h, L.w, L.cout, L.k, L.pad_mode, L.pool_pad_mode, net->dtype,
                                L.y_cstride, L.y_coffset, st, &handled);
     if (rc != SQDET_OK) return rc;
     if (!handled) { set_error("net: fused stem no longer eligible (conv_algo changed after net_create?)"); return SQDET_ESTATE; }
@@ -293,12 +298,16 @@ int run_layer(sqdet_net* net, const Layer& L, const void* input, void* preds, hi
     auto pb = [&](int i) { return reinterpret_cast<const float*>(net->param_mem + net->params[i].offset); };
     bool handled = false;
     const int rc = fire_fused_launch(x, pk(L.kp_s), pb(L.bp_s), pk(L.kp_1), pb(L.bp_1), pk(L.kp_3), pb(L.bp_3), y,
-                                     net->batch, L.h, L.w, L.cin, L.fs, L.fe1, L.fe3, net->dtype, st, &handled);
+                                     nb, L.h, L.w, L.cin, L.fs, L.fe1, L.fe3, net->dtype, st, &handled);
     if (rc != SQDET_OK) return rc;
     if (!handled) { set_error("net: fused fire no longer eligible (options changed after net_create?)"); return SQDET_ESTATE; }
     return SQDET_OK;
   }
-  return maxpool_launch(x, y, net->batch, L.h, L.w, L.cin, L.k, L.stride, L.pad_mode, net->dtype, st);
+  return maxpool_launch(x, y, nb, L.h, L.w, L.cin, L.k, L.stride, L.pad_mode, net->dtype, st);
+}
+
+int run_layer(sqdet_net* net, const Layer& L, const void* input, void* preds, hipStream_t st) {
+  return run_layer_part(net, L, input, preds, 0, net->batch, st);
 }
 
 // Re-folds (sqdet_fold_batchnorm) and re-packs every _conv_bn_layer whose parameters changed since
@@ -527,45 +536,57 @@ extern "C" int sqdet_net_forward(sqdet_net_t* net, const void* image_input, void
   const int frc = refresh_folds(net, st);
   if (frc != SQDET_OK) return frc;
   const int nl = (int)net->layers.size();
-  const bool overlap = fire_overlap() != 0;
-  if (overlap && !net->side) SQDET_CHECK_HIP(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking));
-  size_t fires = 0;
-  for (int i = 0; i < nl; ++i) {
-    const Layer& L = net->layers[i];
-    // expand1x1 (layer i) and expand3x3 (layer i+1) of one fire module: same input buffer, same
-    // output buffer, disjoint channel ranges -> i runs on the side stream while i+1 runs on `st`
-    const bool pair = overlap && i + 1 < nl && L.type == L_CONV && net->layers[i + 1].type == L_CONV &&
-                      L.in_buf == BUF_S && net->layers[i + 1].in_buf == BUF_S && L.out_buf == net->layers[i + 1].out_buf &&
-                      L.y_coffset + L.cout <= net->layers[i + 1].y_coffset;
-    hipStream_t ls = st;
-    if (pair) {
-      if (fires >= net->fork_events.size()) {
-        hipEvent_t e1, e2;
-        SQDET_CHECK_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-        SQDET_CHECK_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-        net->fork_events.push_back(e1);
-        net->join_events.push_back(e2);
-      }
-      SQDET_CHECK_HIP(hipEventRecord(net->fork_events[fires], st));
-      SQDET_CHECK_HIP(hipStreamWaitEvent(net->side, net->fork_events[fires], 0));
-      ls = net->side;
-    }
-    const bool probe = i == net->probe_layer && 2 * (net->probe_count + 1) <= (int)net->probe_events.size();
+  // "late_split" (sqdet_set_option): the trailing run of small-map launches (one wave of workgroups each: their
+  // time is one workgroup's critical path, with the matrix pipes idle during its memory phase and vice versa) is
+  // run as two half-batches on two streams SKEWED by one layer -- half 1 of layer k next to half 0 of layer k+1 --
+  // so that one half's memory phase sits beside the other half's MFMA phase.
+  int split = nl;
+  if (fire_overlap() != 0 && net->batch % 2 == 0) {
+    while (split > 0 && (long)net->batch * net->layers[split - 1].h * net->layers[split - 1].w <= 100000 &&
+           net->layers[split - 1].type != L_STEM)
+      --split;
+    if (nl - split < 2) split = nl;
+  }
+  auto one = [&](int i, int n0, int nb, hipStream_t ls) -> int {
+    const bool probe = n0 == 0 && i == net->probe_layer && 2 * (net->probe_count + 1) <= (int)net->probe_events.size();
     if (probe) SQDET_CHECK_HIP(hipEventRecord(net->probe_events[2 * net->probe_count], ls));
-    const int rc = run_layer(net, L, image_input, preds, ls);
+    const int rc = run_layer_part(net, net->layers[i], image_input, preds, n0, nb, ls);
     if (rc != SQDET_OK) return rc;
     if (probe) {
       SQDET_CHECK_HIP(hipEventRecord(net->probe_events[2 * net->probe_count + 1], ls));
       ++net->probe_count;
     }
-    if (pair) {
-      SQDET_CHECK_HIP(hipEventRecord(net->join_events[fires], net->side));
-      const int rc2 = run_layer(net, net->layers[i + 1], image_input, preds, st);
-      if (rc2 != SQDET_OK) return rc2;
-      SQDET_CHECK_HIP(hipStreamWaitEvent(st, net->join_events[fires], 0));
-      ++fires;
-      ++i;
+    return SQDET_OK;
+  };
+  for (int i = 0; i < split; ++i) {
+    const int rc = one(i, 0, net->batch, st);
+    if (rc != SQDET_OK) return rc;
+  }
+  if (split < nl) {
+    if (!net->side) SQDET_CHECK_HIP(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking));
+    if (net->fork_events.empty()) {
+      hipEvent_t e1, e2;
+      SQDET_CHECK_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+      SQDET_CHECK_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+      net->fork_events.push_back(e1);
+      net->join_events.push_back(e2);
     }
+    const int hb = net->batch / 2;
+    // half 0 of the first late layer goes first; the side stream may start once it is done
+    int rc = one(split, 0, hb, st);
+    if (rc != SQDET_OK) return rc;
+    SQDET_CHECK_HIP(hipEventRecord(net->fork_events[0], st));
+    SQDET_CHECK_HIP(hipStreamWaitEvent(net->side, net->fork_events[0], 0));
+    for (int i = split; i < nl; ++i) {
+      rc = one(i, hb, hb, net->side);                       // half 1 of layer i ...
+      if (rc != SQDET_OK) return rc;
+      if (i + 1 < nl) {
+        rc = one(i + 1, 0, hb, st);                          // ... beside half 0 of layer i + 1
+        if (rc != SQDET_OK) return rc;
+      }
+    }
+    SQDET_CHECK_HIP(hipEventRecord(net->join_events[0], net->side));
+    SQDET_CHECK_HIP(hipStreamWaitEvent(st, net->join_events[0], 0));
   }
   return SQDET_OK;
 }
