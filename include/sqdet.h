@@ -124,6 +124,14 @@ int sqdet_fire_fwd(const void* x, const void* w_s, const float* b_s, const void*
                    const void* w_e3, const float* b_e3, void* sq_scratch, void* y,
                    int n, int h, int w, int cin, int s1x1, int e1x1, int e3x3, int dtype, sqdet_stream_t stream);
 
+/* Fire module followed by max_pool 3x3 / stride 2 / SAME (fire3 -> pool3, fire5 -> pool5: nets/squeezeDet.py:49-57)
+ * in one launch where the streaming kernel covers the shape: the pool is taken in registers and only the pooled
+ * tensor y [n, ceil(h/2), ceil(w/2), e1x1+e3x3] is written.  fire_scratch [n,h,w,e1x1+e3x3] and sq_scratch (as in
+ * sqdet_fire_fwd) are only used by the unfused fallback.  Results are bitwise those of fire -> pool. */
+int sqdet_fire_maxpool_fwd(const void* x, const void* w_s, const float* b_s, const void* w_e1, const float* b_e1,
+                           const void* w_e3, const float* b_e3, void* sq_scratch, void* fire_scratch, void* y,
+                           int n, int h, int w, int cin, int s1x1, int e1x1, int e3x3, int dtype, sqdet_stream_t stream);
+
 /* ---------------------------------------------------- interpret_output --
  * Replaces ModelSkeleton._add_interpretation_graph (nn_skeleton.py:142-283) +
  * util.safe_exp / bbox_transform / bbox_transform_inv (utils/util.py:167-231).

@@ -16,14 +16,41 @@
 //     One barrier per tile; the input loads have a whole phase B (+ the other workgroup) to land.
 // Accumulation order equals conv3x3_tile / conv1x1 (chunk-major, taps 0..8): results are bitwise
 // those of the unfused kernels.
+//
+// POOL variant (fire3 + pool3, fire5 + pool5 of SqueezeDet, nets/squeezeDet.py:49-57): the 3x3 / stride-2 SAME
+// max-pool that follows the module is taken IN REGISTERS and only the pooled tensor is written -- the
+// module's full-resolution output (the largest write of the net) and the pool kernel's read of it never
+// exist.  A tile is 9 x 16 module outputs -> 4 x 7 pooled pixels (tiles overlap by one row / two columns, like
+// the stem's strips); a wave holds 5 rows: vertical 3-max on plain registers, horizontal 3-max by two DPP row
+// shifts (the C/D layout puts column j in lane j of a 16-lane DPP row), ReLU once on the pooled value,
+// out-of-image positions are -inf (TF SAME pooling never picks padding).
 #include "conv_common.h"
 
 namespace sqdet {
 
-constexpr int SROWS = 8, SCOLS = 16;
-constexpr int SHP = (SROWS + 2) * (SCOLS + 2);   // 180 halo pixels
-constexpr int SBLK = (SHP + 15) / 16;            // 12 pixel blocks of 16
-constexpr int STILE = SHP * 64;                  // bytes of one squeeze tile (one 64-byte chunk per pixel)
+constexpr int SCOLS = 16;                        // module-output columns per tile (one MFMA pixel block per row)
+template <bool POOL> struct Geo {
+  static constexpr int ROWS = POOL ? 9 : 8;      // module-output rows per tile
+  static constexpr int MT = POOL ? 5 : 4;        // rows per wave (row halves [0,MT) and [4,4+MT))
+  static constexpr int HP = (ROWS + 2) * (SCOLS + 2);   // halo pixels of the squeeze tile (198 / 180)
+  static constexpr int BLK = (HP + 15) / 16;     // 16-pixel blocks of the halo
+  static constexpr int TILE = HP * 64;           // bytes of one squeeze tile (one 64-byte chunk per pixel)
+  static constexpr int RSTEP = POOL ? 8 : 8;     // module-output rows between tile origins
+  static constexpr int CSTEP = POOL ? 14 : 16;   // columns between tile origins
+};
+
+// packed max written as the instruction (the generic max canonicalises both inputs first)
+template <typename T> __device__ __forceinline__ unsigned int pmax(unsigned int a, unsigned int b);
+template <> __device__ __forceinline__ unsigned int pmax<f16>(unsigned int a, unsigned int b) {
+  unsigned int r;
+  asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <> __device__ __forceinline__ unsigned int pmax<float>(unsigned int a, unsigned int b) {
+  unsigned int r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 struct FireSArgs {
   const void* x;
@@ -34,14 +61,16 @@ struct FireSArgs {
   int tiles_x, tiles_y, ntiles;
   int x_pieces;                // Cin*sizeof(T)/16
   unsigned x_bytes, y_bytes;   // tensor sizes (< 2^31: 32-bit buffer offsets)
+  int Hp, Wp, ptp, plp;        // POOL: pooled output dims and the SAME pads (top / left) of the 3x3/s2 pool
 };
 
-template <typename T, int NCHX, int NTS, int NWAVES, int PF>
+template <typename T, int NCHX, int NTS, int NWAVES, int PF, bool POOL>
 __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs a) {   // 2 waves per SIMD: 256 VGPRs
   constexpr int KG = Tr<T>::KG;
   constexpr int KC = 4 * KG;
+  constexpr int SHP = Geo<POOL>::HP, SBLK = Geo<POOL>::BLK, STILE = Geo<POOL>::TILE;
   constexpr int MB = (SBLK + NWAVES - 1) / NWAVES;   // halo pixel blocks per wave in phase A
-  constexpr int MT = SROWS / 2;                      // tile rows per wave in phase B
+  constexpr int MT = Geo<POOL>::MT;                  // tile rows per wave in phase B
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* sq = lds;                           // [2][STILE]
   unsigned char* wsl = lds + 2 * STILE;              // squeeze weights [NCHX][NTS][64 lanes][16 B]
@@ -71,7 +100,7 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
     }
   }
   const int cp = wave >> 1, rh = wave & 1;           // cout pair, row half
-  const int m0 = rh * MT;
+  const int m0 = rh * 4;                             // rows [0,MT) / [4,4+MT) (POOL: row 4 is computed by both)
   // This wave's two MFMA tiles t = 0,1 cover the 32 consecutive couts [cp*32, cp*32+32) with
   //   tile row i  <->  cout cp*32 + 8*(i>>2) + 4*t + (i&3),
   // so lane group g ends up with the 8 consecutive couts cp*32 + 8g + [0,8): one 16-byte store per pixel,
@@ -126,7 +155,7 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
     for (int mb = 0; mb < MB; ++mb) {
       const int P = (wave + NWAVES * mb) * 16 + j;
       const int r = P / (SCOLS + 2), c = P - r * (SCOLS + 2);
-      const int iy = ty * SROWS - 1 + r, ix = tx * SCOLS - 1 + c;
+      const int iy = ty * Geo<POOL>::RSTEP - (POOL ? a.ptp : 0) - 1 + r, ix = tx * Geo<POOL>::CSTEP - (POOL ? a.plp : 0) - 1 + c;
       inimg[mb] = tile_ok && P < SHP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
       const unsigned base = (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + g * KG) * (int)sizeof(T));
 #pragma unroll
@@ -182,29 +211,74 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
     issue_loads(tile + PF * nl, tile + PF * nl < band_end, xq, inimg);
     __syncthreads();
     // ---------------- phase B: expand3x3, then expand1x1, on rows [m0, m0 + MT) ----------------
-    const int ox = tx * SCOLS + j;
-    const unsigned ybase = (unsigned)(((((n * a.H + ty * SROWS + m0) * a.W + ox) * ctot) + cb) * (int)sizeof(T));
-    const unsigned yrow = (unsigned)(a.W * ctot * (int)sizeof(T));
-    auto epilogue = [&](f32x4 (&acc)[MT][2], const float* bias_lds, unsigned off0) {
+    const int oy0 = ty * Geo<POOL>::RSTEP - (POOL ? a.ptp : 0), ox0 = tx * Geo<POOL>::CSTEP - (POOL ? a.plp : 0);
+    const int ox = ox0 + j;
+    auto epilogue = [&](f32x4 (&acc)[MT][2], const float* bias_lds, int coff) {
       f32x4 bias[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const f32x4*>(bias_lds + cb + t * 4);
+      if constexpr (!POOL) {
+        const unsigned off0 = (unsigned)(((((n * a.H + oy0 + m0) * a.W + ox) * ctot) + coff + cb) * (int)sizeof(T));
+        const unsigned yrow = (unsigned)(a.W * ctot * (int)sizeof(T));
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const unsigned off = (ox < a.W && ty * SROWS + m0 + m < a.H) ? off0 + m * yrow : OOB;   // OOB stores are dropped
-        f32x4 v[2];
+        for (int m = 0; m < MT; ++m) {
+          const unsigned off = (ox < a.W && oy0 + m0 + m < a.H) ? off0 + m * yrow : OOB;   // OOB stores are dropped
+          f32x4 v[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          v[t] = acc[m][t] + bias[t];
+          for (int t = 0; t < 2; ++t) {
+            v[t] = acc[m][t] + bias[t];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[t][e] = fmaxf(v[t][e], 0.f);
+            for (int e = 0; e < 4; ++e) v[t][e] = fmaxf(v[t][e], 0.f);
+          }
+          if constexpr (sizeof(T) == 2) {
+            const f16x8 h = {(f16)v[0][0], (f16)v[0][1], (f16)v[0][2], (f16)v[0][3], (f16)v[1][0], (f16)v[1][1], (f16)v[1][2], (f16)v[1][3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, h), ry, off, 0, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v[0]), ry, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v[1]), ry, off == OOB ? OOB : off + 16, 0, 0);
+          }
         }
-        if constexpr (sizeof(T) == 2) {
-          const f16x8 h = {(f16)v[0][0], (f16)v[0][1], (f16)v[0][2], (f16)v[0][3], (f16)v[1][0], (f16)v[1][1], (f16)v[1][2], (f16)v[1][3]};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, h), ry, off, 0, 0);
-        } else {
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v[0]), ry, off, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v[1]), ry, off == OOB ? OOB : off + 16, 0, 0);
+      } else {
+        constexpr int NR = sizeof(T) == 2 ? 4 : 8;        // 32-bit registers holding this lane's 8 couts of one pixel
+        const unsigned NEG = sizeof(T) == 2 ? 0xfc00fc00u : 0xff800000u;   // -inf (packed)
+        unsigned int val[MT][NR];
+        const bool col_ok = ox >= 0 && ox < a.W;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int oy = oy0 + m0 + m;
+          const bool ok = col_ok && oy >= 0 && oy < a.H;
+          const f32x4 v0 = acc[m][0] + bias[0], v1 = acc[m][1] + bias[1];
+          if constexpr (sizeof(T) == 2) {
+            const f16x8 h = {(f16)v0[0], (f16)v0[1], (f16)v0[2], (f16)v0[3], (f16)v1[0], (f16)v1[1], (f16)v1[2], (f16)v1[3]};
+            const i32x4 hi = __builtin_bit_cast(i32x4, h);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) val[m][r] = ok ? (unsigned)hi[r] : NEG;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              val[m][r] = ok ? __float_as_uint(v0[r]) : NEG;
+              val[m][4 + r] = ok ? __float_as_uint(v1[r]) : NEG;
+            }
+          }
+        }
+        const int pc = tx * 7 + (j >> 1);                 // pooled column of the even lanes j = 0, 2, .., 12
+        const bool lane_ok = (j & 1) == 0 && j <= 12 && pc < a.Wp;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                     // this wave's two pooled rows
+          const int pr = ty * 4 + rh * 2 + q;
+          unsigned int o[NR];
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const unsigned int vm = pmax<T>(val[2 * q][r], pmax<T>(val[2 * q + 1][r], val[2 * q + 2][r]));
+            const unsigned int s1 = (unsigned int)__builtin_amdgcn_update_dpp((int)NEG, (int)vm, 0x101, 0xf, 0xf, false);
+            const unsigned int s2 = (unsigned int)__builtin_amdgcn_update_dpp((int)NEG, (int)vm, 0x102, 0xf, 0xf, false);
+            o[r] = pmax<T>(pmax<T>(vm, pmax<T>(s1, s2)), 0u);        // 0u = +0.0 (packed): the ReLU
+          }
+          const unsigned off = (lane_ok && pr < a.Hp)
+              ? (unsigned)(((((n * a.Hp + pr) * a.Wp + pc) * ctot) + coff + cb) * (int)sizeof(T)) : OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)o[0], (int)o[1], (int)o[2], (int)o[3]}, ry, off, 0, 0);
+          if constexpr (sizeof(T) == 4)
+            __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)o[4], (int)o[5], (int)o[6], (int)o[7]}, ry, off == OOB ? OOB : off + 16, 0, 0);
         }
       }
     };
@@ -229,20 +303,34 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
         for (int m = 0; m < MT; ++m)
           bf[m] = *reinterpret_cast<const i32x4*>(sqb + (P0 + (SCOLS + 2) * (m0 + m)) * 64 + ((go ^ ((h0 + m0 + m) & 3)) << 4));
       };
-      i32x4 bfa[MT], bfb[MT];
-      load_tap(0, bfa);
+      constexpr bool DB = MB * NCHX * PF < 16 || !POOL;   // (the pooled fire3 shape has no registers left for the second buffer)
+      if constexpr (DB) {
+        i32x4 bfa[MT], bfb[MT];
+        load_tap(0, bfa);
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        i32x4 (&cur)[MT] = (tap & 1) ? bfb : bfa;
-        i32x4 (&nxt)[MT] = (tap & 1) ? bfa : bfb;
-        if (tap + 1 < 9) load_tap(tap + 1, nxt);
+        for (int tap = 0; tap < 9; ++tap) {
+          i32x4 (&cur)[MT] = (tap & 1) ? bfb : bfa;
+          i32x4 (&nxt)[MT] = (tap & 1) ? bfa : bfb;
+          if (tap + 1 < 9) load_tap(tap + 1, nxt);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int t = 0; t < 2; ++t) mma16<T>(acc3[m][t], w3r[tap][t], cur[m]);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int t = 0; t < 2; ++t) mma16<T>(acc3[m][t], w3r[tap][t], cur[m]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          i32x4 bf[MT];
+          load_tap(tap, bf);
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) mma16<T>(acc3[m][t], w3r[tap][t], bf[m]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      epilogue(acc3, bl + a.E, ybase + a.E * (int)sizeof(T));   // expand3x3 -> channels [E, 2E)
+      epilogue(acc3, bl + a.E, a.E);                  // expand3x3 -> channels [E, 2E)
     }
     {
       f32x4 acc1[MT][2];
@@ -260,7 +348,7 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
           mma16<T>(acc1[m][t], w1f[t], bf);
         }
       }
-      epilogue(acc1, bl, ybase);                      // expand1x1 -> channels [0, E)
+      epilogue(acc1, bl, 0);                          // expand1x1 -> channels [0, E)
     }
   };
 
@@ -301,26 +389,27 @@ bool fire_stream_eligible(int cin, int s, int e1, int e3, int dtype) {
   return stream_shape(cin, s, e1, e3, dtype, &a, &b, &c);
 }
 
-template <typename T, int NCHX, int NTS, int NWAVES>
+template <typename T, int NCHX, int NTS, int NWAVES, bool POOL>
 static void launch_stream(const FireSArgs& a, hipStream_t st) {
-  const size_t lds = 2 * (size_t)STILE + (size_t)NCHX * NTS * 1024 + (size_t)(NWAVES / 4) * 4 * 1024 + (size_t)(2 * a.E + a.S) * 4;
+  const size_t lds = 2 * (size_t)Geo<POOL>::TILE + (size_t)NCHX * NTS * 1024 + (size_t)(NWAVES / 4) * 4 * 1024 + (size_t)(2 * a.E + a.S) * 4;
   // persistent: 8 waves per CU (the register-resident weights + prefetched input allow 2 per SIMD)
   int grid = 256 * (8 / NWAVES);
   if (grid > (a.ntiles + 7) / 8 * 8) grid = (a.ntiles + 7) / 8 * 8;
   // two tiles of input in flight when their fragments fit the register budget next to the resident weights
-  if constexpr (NCHX <= 4) {   // (compile to <= 252 VGPRs without spills)
+  constexpr int MBH = (Geo<POOL>::BLK + NWAVES - 1) / NWAVES;
+  if constexpr (2 * MBH * NCHX <= 16) {   // (these compile without spills; a spill in the tile loop drains vmcnt)
     if (tune(TUNE_DBG) != 8) {
-      hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 2>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
+      hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 2, POOL>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
       return;
     }
   }
-  hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 1>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
+  hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 1, POOL>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
 }
 
-template <typename T>
+template <typename T, bool POOL>
 static bool dispatch_stream(const FireSArgs& a, int nchx, int nts, int nwaves, hipStream_t st) {
 #define SQDET_FS(NC, NS, NW) \
-  if (nchx == NC && nts == NS && nwaves == NW) { launch_stream<T, NC, NS, NW>(a, st); return true; }
+  if (nchx == NC && nts == NS && nwaves == NW) { launch_stream<T, NC, NS, NW, POOL>(a, st); return true; }
   SQDET_FS(2, 1, 4) SQDET_FS(4, 1, 4) SQDET_FS(2, 2, 4) SQDET_FS(4, 2, 4)
   SQDET_FS(2, 1, 8) SQDET_FS(4, 1, 8) SQDET_FS(2, 2, 8) SQDET_FS(4, 2, 8) SQDET_FS(8, 1, 8) SQDET_FS(8, 2, 8)
 #undef SQDET_FS
@@ -328,25 +417,41 @@ static bool dispatch_stream(const FireSArgs& a, int nchx, int nts, int nwaves, h
 }
 
 // *handled = false: shape not covered (fire_fused_launch / the three separate convs take over).
+int fire_stream_launch_ex(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
+                          const float* b3, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
+                          int pool, hipStream_t st, bool* handled);
+
 int fire_stream_launch(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
                        const float* b3, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
                        hipStream_t st, bool* handled) {
+  return fire_stream_launch_ex(x, ws, bs, w1, b1, w3, b3, y, n, h, w, cin, s, e1, e3, dtype, 0, st, handled);
+}
+
+// pool != 0: the module is followed by max_pool 3x3 / stride 2 / SAME and y is the POOLED tensor [n, ceil(h/2), ceil(w/2), e1+e3]
+int fire_stream_launch_ex(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
+                          const float* b3, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
+                          int pool, hipStream_t st, bool* handled) {
   *handled = false;
   int nchx, nts, nwaves;
   if (!stream_shape(cin, s, e1, e3, dtype, &nchx, &nts, &nwaves)) return SQDET_OK;
   FireSArgs a;
   a.x = x; a.y = y; a.ws = ws; a.w1 = w1; a.w3 = w3; a.bs = bs; a.b1 = b1; a.b3 = b3;
   a.N = n; a.H = h; a.W = w; a.Cin = cin; a.S = s; a.E = e1;
-  a.tiles_x = (w + SCOLS - 1) / SCOLS; a.tiles_y = (h + SROWS - 1) / SROWS;
+  a.Hp = out_size(h, 3, 2, SQDET_PAD_SAME); a.Wp = out_size(w, 3, 2, SQDET_PAD_SAME);
+  a.ptp = pad_before(h, 3, 2, SQDET_PAD_SAME); a.plp = pad_before(w, 3, 2, SQDET_PAD_SAME);
+  if (pool) { a.tiles_x = (a.Wp + 6) / 7; a.tiles_y = (a.Hp + 3) / 4; }
+  else { a.tiles_x = (w + SCOLS - 1) / SCOLS; a.tiles_y = (h + 7) / 8; }
   const long nt = (long)n * a.tiles_x * a.tiles_y;
   if (nt > 0x3fffffffL) return SQDET_OK;
   a.ntiles = (int)nt;
   const int esz = dtype == SQDET_F16 ? 2 : 4;
   a.x_pieces = cin * esz / 16;
-  const long xb = (long)n * h * w * cin * esz, yb = (long)n * h * w * 2 * e1 * esz;
+  const long xb = (long)n * h * w * cin * esz, yb = pool ? (long)n * a.Hp * a.Wp * 2 * e1 * esz : (long)n * h * w * 2 * e1 * esz;
   if (xb >= (1L << 31) || yb >= (1L << 31)) return SQDET_OK;   // 32-bit buffer offsets
   a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb;
-  const bool ok = dtype == SQDET_F16 ? dispatch_stream<f16>(a, nchx, nts, nwaves, st) : dispatch_stream<float>(a, nchx, nts, nwaves, st);
+  bool ok;
+  if (pool) ok = dtype == SQDET_F16 ? dispatch_stream<f16, true>(a, nchx, nts, nwaves, st) : dispatch_stream<float, true>(a, nchx, nts, nwaves, st);
+  else ok = dtype == SQDET_F16 ? dispatch_stream<f16, false>(a, nchx, nts, nwaves, st) : dispatch_stream<float, false>(a, nchx, nts, nwaves, st);
   if (!ok) return SQDET_OK;
   SQDET_CHECK_HIP(hipGetLastError());
   *handled = true;

@@ -28,6 +28,9 @@ int fire_fused_launch(const void* x, const void* ws, const float* bs, const void
                       hipStream_t st, bool* handled);
 bool fire_fused_eligible(int cin, int s, int e1, int e3, int dtype);
 bool fire_stream_eligible(int cin, int s, int e1, int e3, int dtype);
+int fire_stream_launch_ex(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
+                          const float* b3, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
+                          int pool, hipStream_t st, bool* handled);
 int conv_algo();
 int fire_overlap();
 int tune(int which);
@@ -74,6 +77,7 @@ struct Layer {
   // L_FIRE: cin = fire input channels, cout = e1 + e3; the three convs' parameters
   int fs, fe1, fe3;
   int kp_s, bp_s, kp_1, bp_1, kp_3, bp_3;
+  int fire_pool = 0;   // L_FIRE: the 3x3/s2 SAME max-pool that follows is taken inside the kernel (ho, wo = pooled dims)
   double flops, bytes;
 };
 
@@ -297,8 +301,11 @@ int run_layer_part(sqdet_net* net, const Layer& L, const void* input, void* pred
     auto pk = [&](int i) { return (const void*)(net->param_mem + net->params[i].offset); };
     auto pb = [&](int i) { return reinterpret_cast<const float*>(net->param_mem + net->params[i].offset); };
     bool handled = false;
-    const int rc = fire_fused_launch(x, pk(L.kp_s), pb(L.bp_s), pk(L.kp_1), pb(L.bp_1), pk(L.kp_3), pb(L.bp_3), y,
-                                     nb, L.h, L.w, L.cin, L.fs, L.fe1, L.fe3, net->dtype, st, &handled);
+    const int rc = L.fire_pool
+        ? fire_stream_launch_ex(x, pk(L.kp_s), pb(L.bp_s), pk(L.kp_1), pb(L.bp_1), pk(L.kp_3), pb(L.bp_3), y, nb, L.h, L.w,
+                                L.cin, L.fs, L.fe1, L.fe3, net->dtype, 1, st, &handled)
+        : fire_fused_launch(x, pk(L.kp_s), pb(L.bp_s), pk(L.kp_1), pb(L.bp_1), pk(L.kp_3), pb(L.bp_3), y,
+                            nb, L.h, L.w, L.cin, L.fs, L.fe1, L.fe3, net->dtype, st, &handled);
     if (rc != SQDET_OK) return rc;
     if (!handled) { set_error("net: fused fire no longer eligible (options changed after net_create?)"); return SQDET_ESTATE; }
     return SQDET_OK;
@@ -365,6 +372,45 @@ void fuse_fires(sqdet_net* net, size_t esz) {
     i += 2;
   }
   net->layers.swap(out);
+}
+
+// fire module + the 3x3/s2 SAME max-pool behind it -> one launch of the streaming kernel's POOL form (fire3+pool3,
+// fire5+pool5 of SqueezeDet): the module's full-resolution output never reaches HBM.  "fire_fuse" = 4 keeps them apart.
+void fuse_fire_pools(sqdet_net* net, size_t esz) {
+  if (conv_algo() != 0 || tune(3) == 2 || tune(3) == 3 || tune(3) == 4) return;
+  std::vector<Layer> out;
+  std::vector<Layer> in = net->layers;
+  bool fused_any = false;
+  for (size_t i = 0; i < in.size(); ++i) {
+    const bool ok = i + 1 < in.size() && in[i].type == L_FIRE && in[i + 1].type == L_POOL && in[i + 1].k == 3 &&
+                    in[i + 1].stride == 2 && in[i + 1].pad_mode == SQDET_PAD_SAME && in[i + 1].in_buf == in[i].out_buf &&
+                    fire_stream_eligible(in[i].cin, in[i].fs, in[i].fe1, in[i].fe3, net->dtype);
+    if (!ok) { out.push_back(in[i]); continue; }
+    const Layer& p = in[i + 1];
+    Layer f = in[i];
+    f.fire_pool = 1;
+    f.name = in[i].name + "+" + p.name;
+    // The pooled tensor goes where the module's own output would have gone -- NOT into the pool's output buffer:
+    // that is the ping-pong buffer the module READS (other workgroups are still reading it).  One ping-pong step
+    // disappears, so the two buffers swap roles for every later layer.
+    f.ho = p.ho; f.wo = p.wo;
+    for (size_t k = i + 2; k < in.size(); ++k) {
+      auto sw = [](int b) { return b == BUF_A ? BUF_B : (b == BUF_B ? BUF_A : b); };
+      in[k].in_buf = sw(in[k].in_buf);
+      in[k].out_buf = sw(in[k].out_buf);
+    }
+    fused_any = true;
+    // algorithmic bytes: fire input + POOLED output + the three weight sets
+    f.bytes = in[i].bytes - (double)net->batch * in[i].h * in[i].w * in[i].cout * (double)esz +
+              (double)net->batch * p.ho * p.wo * in[i].cout * (double)esz;
+    out.push_back(f);
+    ++i;
+  }
+  net->layers.swap(out);
+  if (fused_any) {   // either buffer may now hold what the other was sized for
+    const size_t m = net->buf_elems[BUF_A] > net->buf_elems[BUF_B] ? net->buf_elems[BUF_A] : net->buf_elems[BUF_B];
+    net->buf_elems[BUF_A] = net->buf_elems[BUF_B] = m;
+  }
 }
 
 // conv1 + pool1 -> one L_STEM launch when the fused kernel applies (decided at plan creation).
@@ -440,6 +486,7 @@ extern "C" int sqdet_net_create(sqdet_net_t** out, int arch, int dtype, int batc
   net->gh = b.h; net->gw = b.w; net->out_ch = nout;
   fuse_stem(net, b.esz);
   fuse_fires(net, b.esz);
+  fuse_fire_pools(net, b.esz);
   net->fold_scratch_off = net->param_bytes;
   net->param_bytes = align_up(net->param_bytes + net->fold_scratch_bytes, 256);
   size_t off = 0;
@@ -672,4 +719,23 @@ extern "C" int sqdet_fire_fwd(const void* x, const void* w_s, const float* b_s, 
   if (rc != SQDET_OK) return rc;
   return conv2d_launch(sq_scratch, w_e3, b_e3, y, n, h, w, s1x1, e3x3, 3, 1, SQDET_PAD_SAME, 1, dtype, e1x1 + e3x3,
                        e1x1, st);
+}
+
+extern "C" int sqdet_fire_maxpool_fwd(const void* x, const void* w_s, const float* b_s, const void* w_e1, const float* b_e1,
+                                      const void* w_e3, const float* b_e3, void* sq_scratch, void* fire_scratch, void* y,
+                                      int n, int h, int w, int cin, int s1x1, int e1x1, int e3x3, int dtype,
+                                      sqdet_stream_t stream) {
+  SQDET_REQUIRE(fire_scratch && y, "fire_maxpool_fwd: null pointer");
+  hipStream_t st = as_stream(stream);
+  const int ff = tune(3);
+  if (ff != 2 && ff != 3 && ff != 4) {   // one launch when the streaming kernel covers the shape (the scratches stay untouched)
+    bool handled = false;
+    const int rc = fire_stream_launch_ex(x, w_s, b_s, w_e1, b_e1, w_e3, b_e3, y, n, h, w, cin, s1x1, e1x1, e3x3, dtype, 1, st,
+                                         &handled);
+    if (rc != SQDET_OK || handled) return rc;
+  }
+  const int rc = sqdet_fire_fwd(x, w_s, b_s, w_e1, b_e1, w_e3, b_e3, sq_scratch, fire_scratch, n, h, w, cin, s1x1, e1x1, e3x3,
+                                dtype, stream);
+  if (rc != SQDET_OK) return rc;
+  return maxpool_launch(fire_scratch, y, n, h, w, e1x1 + e3x3, 3, 2, SQDET_PAD_SAME, dtype, st);
 }

@@ -128,6 +128,22 @@ def fire(x, p_s, b_s, p_e1, b_e1, p_e3, b_e3):
     return y
 
 
+def fire_maxpool(x, p_s, b_s, p_e1, b_e1, p_e3, b_e3):
+    """_fire_layer followed by max_pool 3x3/s2 SAME (nets/squeezeDet.py:49-57) -> the pooled tensor, in one launch
+    where the streaming kernel covers the shape (sqdet_fire_maxpool_fwd)."""
+    n, h, w, cin = [int(v) for v in x.shape]
+    ctot = p_e1.cout + p_e3.cout
+    sq = torch.empty((n, h, w, p_s.cout), dtype=x.dtype, device=x.device)
+    full = torch.empty((n, h, w, ctot), dtype=x.dtype, device=x.device)
+    y = torch.empty((n, -(-h // 2), -(-w // 2), ctot), dtype=x.dtype, device=x.device)
+    check(lib().sqdet_fire_maxpool_fwd(_dev(x, "x"), _dev(p_s.data, "w_s"), _dev(b_s, "b_s", torch.float32),
+                                       _dev(p_e1.data, "w_e1"), _dev(b_e1, "b_e1", torch.float32),
+                                       _dev(p_e3.data, "w_e3"), _dev(b_e3, "b_e3", torch.float32),
+                                       _dev(sq, "sq"), _dev(full, "fire_scratch"), _dev(y, "y"), n, h, w, cin, p_s.cout,
+                                       p_e1.cout, p_e3.cout, dtype_code(x.dtype), stream_ptr()), "sqdet_fire_maxpool_fwd")
+    return y
+
+
 # ---------------------------------------------------------------- post-processing
 def interpret_output(preds, anchors_f32, classes, anchors_per_grid, img_w, img_h, exp_thresh=1.0,
                      with_class_probs=False):

@@ -62,8 +62,9 @@ def test_net_plan_tables_without_gpu(lib):
         assert lib.sqdet_net_layer_info(h, i, nm, 128, None, None) == 0
         names_default.append(nm.value.decode())
     assert names_default[0] == "conv1+pool1" and "fire2" in names_default and "fire11" in names_default
-    assert "fire5" in names_default and "pool5" in names_default
-    assert len(names_default) == 34 - 2 * 10
+    # ... and the two max-pools behind fire3 / fire5 are taken inside those launches
+    assert "fire3+pool3" in names_default and "fire5+pool5" in names_default and "pool3" not in names_default
+    assert len(names_default) == 34 - 2 * 10 - 2
     lib.sqdet_net_destroy(h)
     # the rest of this test inspects the per-conv plan (fire fusion off)
     assert lib.sqdet_set_option(b"fire_fuse", 2) == 0

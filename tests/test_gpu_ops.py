@@ -183,6 +183,37 @@ def test_fused_fire_module_parity(case, dtype):
     np.testing.assert_allclose(y_fused.float().cpu().numpy(), ref, **tol)
 
 
+FIRE_POOL_CASES = [("fire3", 128, 16, 64, 94, 311, 2), ("fire3-odd", 128, 16, 64, 19, 37, 2), ("fire3-even", 128, 16, 64, 20, 28, 1),
+                   ("fire5", 256, 32, 128, 47, 156, 2), ("fire5-small", 256, 32, 128, 9, 15, 3), ("fire2-shape", 64, 16, 64, 33, 30, 1),
+                   ("fire5-many-tiles", 256, 32, 128, 47, 156, 10), ("fire3-many-tiles", 128, 16, 64, 94, 311, 5),
+                   ("fallback", 256, 48, 192, 13, 21, 1)]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("case", FIRE_POOL_CASES, ids=[c[0] for c in FIRE_POOL_CASES])
+def test_fire_plus_maxpool_one_launch(case, dtype):
+    """sqdet_fire_maxpool_fwd (fire3+pool3 / fire5+pool5, nets/squeezeDet.py:49-57: the 3x3/s2 SAME pool taken in
+    registers, only the pooled tensor written) BITWISE against fire -> max-pool, over odd / even sizes (SAME pads
+    (0,1) and (1,1)), image edges inside tiles, and a shape the streaming kernel does not cover (fallback)."""
+    ops = _ops()
+    name, cin, s, e, H, W, N = case
+    tdt = torch.float16 if dtype == "fp16" else torch.float32
+    rs = np.random.RandomState(zlib.crc32(name.encode()) % (2 ** 31))
+    mk = lambda k, ci, co: torch.from_numpy((rs.randn(k, k, ci, co) * (2.0 / (k * k * ci)) ** 0.5).astype(np.float32))
+    ws, w1, w3 = mk(1, cin, s), mk(1, s, e), mk(3, s, e)
+    bs, b1, b3 = [torch.from_numpy(rs.uniform(-0.3, 0.3, c).astype(np.float32)).to(DEV) for c in (s, e, e)]
+    x = torch.from_numpy((rs.randn(N, H, W, cin) - 0.3).astype(np.float32)).to(DEV, tdt).contiguous()   # many negative pre-activations
+    ps, p1, p3 = [ops.pack_conv_weights(w.to(DEV), tdt) for w in (ws, w1, w3)]
+    args = (x, ps, bs, p1, b1, p3, b3)
+    y = ops.fire_maxpool(*args)
+    ops.set_option("fire_fuse", 2)
+    want = ops.maxpool_nhwc(ops.fire(*args), 3, 2, "SAME")
+    ops.set_option("fire_fuse", 0)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (N, -(-H // 2), -(-W // 2), 2 * e)
+    assert torch.equal(y, want), "fire+pool in one launch differs from fire -> pool"
+
+
 POOL_CASES = [(2, 37, 53, 64, 3, 2, "SAME"), (1, 188, 621, 8, 3, 2, "SAME"), (1, 47, 156, 16, 3, 2, "SAME"),
               (1, 94, 311, 8, 3, 2, "SAME"), (1, 41, 57, 96, 3, 2, "VALID"), (1, 12, 14, 8, 2, 2, "SAME"), (1, 3, 3, 8, 3, 2, "SAME")]
 
