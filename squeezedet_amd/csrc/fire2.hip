@@ -31,10 +31,14 @@ namespace sqdet {
 constexpr int SCOLS = 16;                        // module-output columns per tile (one MFMA pixel block per row)
 template <bool POOL> struct Geo {
   static constexpr int ROWS = POOL ? 9 : 8;      // module-output rows per tile
-  static constexpr int MT = POOL ? 5 : 4;        // rows per wave (row halves [0,MT) and [4,4+MT))
   static constexpr int HP = (ROWS + 2) * (SCOLS + 2);   // halo pixels of the squeeze tile (198 / 180)
   static constexpr int BLK = (HP + 15) / 16;     // 16-pixel blocks of the halo
-  static constexpr int TILE = HP * 64;           // bytes of one squeeze tile (one 64-byte chunk per pixel)
+  // LDS row pitch of the squeeze tile: 24 pixels, not 18.  With a pitch that is a multiple of 8 the swizzle term
+  // ((pixel >> 1) & 3) of a fragment read is the same for every tile row, so the MT reads of one tap are ONE address
+  // register + immediate row offsets (with pitch 18 every (tap, row) needed its own address: 180 VALU per tile).
+  static constexpr int LW = 24;
+  static constexpr int LPIX = (ROWS + 2) * LW;   // pixels of the LDS tile (incl. the unused pitch columns)
+  static constexpr int TILE = LPIX * 64;         // bytes of one squeeze tile (one 64-byte chunk per pixel)
   static constexpr int RSTEP = POOL ? 8 : 8;     // module-output rows between tile origins
   static constexpr int CSTEP = POOL ? 14 : 16;   // columns between tile origins
 };
@@ -64,18 +68,23 @@ struct FireSArgs {
   int Hp, Wp, ptp, plp;        // POOL: pooled output dims and the SAME pads (top / left) of the 3x3/s2 pool
 };
 
-template <typename T, int NCHX, int NTS, int NWAVES, int PF, bool POOL>
+// RS = row split: the tile rows are divided among RS waves per cout pair (NWAVES = cout pairs x RS).  POOL: a wave
+// owns 4/RS pooled rows and computes the 2*(4/RS)+1 module rows under them (neighbouring waves both compute the row
+// they share); otherwise 8/RS rows.
+template <typename T, int NCHX, int NTS, int NWAVES, int PF, bool POOL, int RS>
 __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs a) {   // 2 waves per SIMD: 256 VGPRs
   constexpr int KG = Tr<T>::KG;
   constexpr int KC = 4 * KG;
-  constexpr int SHP = Geo<POOL>::HP, SBLK = Geo<POOL>::BLK, STILE = Geo<POOL>::TILE;
+  constexpr int SHP = Geo<POOL>::HP, SBLK = Geo<POOL>::BLK, STILE = Geo<POOL>::TILE, LW = Geo<POOL>::LW;
   constexpr int MB = (SBLK + NWAVES - 1) / NWAVES;   // halo pixel blocks per wave in phase A
-  constexpr int MT = Geo<POOL>::MT;                  // tile rows per wave in phase B
+  constexpr int NQ = 4 / RS;                         // POOL: pooled rows per wave
+  constexpr int MT = POOL ? 2 * NQ + 1 : 8 / RS;     // module rows per wave in phase B
+  constexpr int NG = NWAVES / RS / 2;                // 64-cout groups of each expand conv
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* sq = lds;                           // [2][STILE]
   unsigned char* wsl = lds + 2 * STILE;              // squeeze weights [NCHX][NTS][64 lanes][16 B]
   unsigned char* w1l = wsl + NCHX * NTS * 1024;      // expand1x1 weights [E/16 tiles][64 lanes][16 B]
-  float* bl = reinterpret_cast<float*>(w1l + (NWAVES / 4) * 4 * 1024);   // biases
+  float* bl = reinterpret_cast<float*>(w1l + NG * 4 * 1024);   // biases
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
 
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
     const i32x4* src = reinterpret_cast<const i32x4*>(a.ws);
     for (int i = threadIdx.x; i < NCHX * NTS * 64; i += NWAVES * 64) reinterpret_cast<i32x4*>(wsl)[i] = src[i];
     const i32x4* src1 = reinterpret_cast<const i32x4*>(a.w1);
-    for (int i = threadIdx.x; i < (NWAVES / 4) * 4 * 64; i += NWAVES * 64) reinterpret_cast<i32x4*>(w1l)[i] = src1[i];
+    for (int i = threadIdx.x; i < NG * 4 * 64; i += NWAVES * 64) reinterpret_cast<i32x4*>(w1l)[i] = src1[i];
     // biases -> LDS [b1 (E) | b3 (E) | bs (S)]: read back with ds_read (lgkmcnt).  A global bias load inside
     // the tile loop would sit behind the prefetched input loads and the stores in the in-order vmcnt queue
     // and drain them every time it is waited for.
@@ -93,14 +102,15 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
     // channel padding of the squeeze tile (S*sizeof(T) < 64 bytes) is zero in both buffers, forever
     const int s_pieces = a.S * (int)sizeof(T) / 16;
     const int pad = 4 - s_pieces;
-    for (int idx = threadIdx.x; idx < 2 * SHP * pad; idx += NWAVES * 64) {
-      const int bsel = idx / (SHP * pad), r = idx - bsel * SHP * pad;
+    constexpr int LPIX = Geo<POOL>::LPIX;
+    for (int idx = threadIdx.x; idx < 2 * LPIX * pad; idx += NWAVES * 64) {
+      const int bsel = idx / (LPIX * pad), r = idx - bsel * LPIX * pad;
       const int P = r / pad, q = s_pieces + (r - P * pad);
       *reinterpret_cast<i32x4*>(sq + bsel * STILE + P * 64 + ((q ^ ((P >> 1) & 3)) << 4)) = i32x4{0, 0, 0, 0};
     }
   }
-  const int cp = wave >> 1, rh = wave & 1;           // cout pair, row half
-  const int m0 = rh * 4;                             // rows [0,MT) / [4,4+MT) (POOL: row 4 is computed by both)
+  const int cp = wave / RS, rq = wave % RS;          // cout pair, row part
+  const int m0 = POOL ? rq * 2 * NQ : rq * MT;       // first module row of this wave (POOL: boundary rows are shared)
   // This wave's two MFMA tiles t = 0,1 cover the 32 consecutive couts [cp*32, cp*32+32) with
   //   tile row i  <->  cout cp*32 + 8*(i>>2) + 4*t + (i&3),
   // so lane group g ends up with the 8 consecutive couts cp*32 + 8g + [0,8): one 16-byte store per pixel,
@@ -196,7 +206,9 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
               f32x4 v = acc[mb][t] + biass;
               v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
               if (!inimg[mb]) v = f32x4{0.f, 0.f, 0.f, 0.f};   // SAME padding of the squeeze tensor
-              store4<T>(reinterpret_cast<T*>(sqb + P * 64 + ((q ^ ((P >> 1) & 3)) << 4) + sub), v);
+              const int hr = P / (SCOLS + 2);
+              const int PL = hr * LW + (P - hr * (SCOLS + 2));   // position in the LDS tile (row pitch LW)
+              store4<T>(reinterpret_cast<T*>(sqb + PL * 64 + ((q ^ ((PL >> 1) & 3)) << 4) + sub), v);
             }
           }
         }
@@ -264,8 +276,8 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
         const int pc = tx * 7 + (j >> 1);                 // pooled column of the even lanes j = 0, 2, .., 12
         const bool lane_ok = (j & 1) == 0 && j <= 12 && pc < a.Wp;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {                     // this wave's two pooled rows
-          const int pr = ty * 4 + rh * 2 + q;
+        for (int q = 0; q < NQ; ++q) {                    // this wave's pooled rows
+          const int pr = ty * 4 + rq * NQ + q;
           unsigned int o[NR];
 #pragma unroll
           for (int r = 0; r < NR; ++r) {
@@ -297,11 +309,10 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
       asm volatile("" : "+v"(jo), "+v"(go));
       auto load_tap = [&](int tap, i32x4 (&bf)[MT]) {
         const int dy = tap / 3, dx = tap - dy * 3;
-        const int P0 = dy * (SCOLS + 2) + jo + dx;
-        const int h0 = P0 >> 1;
+        const int P0 = dy * LW + jo + dx;
+        const unsigned char* base = sqb + (P0 + LW * m0) * 64 + ((go ^ ((P0 >> 1) & 3)) << 4);   // LW*(m0+m)/2 = 0 mod 4
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-          bf[m] = *reinterpret_cast<const i32x4*>(sqb + (P0 + (SCOLS + 2) * (m0 + m)) * 64 + ((go ^ ((h0 + m0 + m) & 3)) << 4));
+        for (int m = 0; m < MT; ++m) bf[m] = *reinterpret_cast<const i32x4*>(base + m * (LW * 64));
       };
       constexpr bool DB = MB * NCHX * PF < 16 || !POOL;   // (the pooled fire3 shape has no registers left for the second buffer)
       if constexpr (DB) {
@@ -337,11 +348,11 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
       i32x4 w1f[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) w1f[t] = *reinterpret_cast<const i32x4*>(w1l + (group * 4 * 64 + wsrc[t]) * 16);
-      const int P0 = (SCOLS + 2) + j + 1;             // centre tap
-      const int h0 = P0 >> 1;
+      const int P0 = LW + j + 1;                      // centre tap
+      const unsigned char* base1 = sqb + (P0 + LW * m0) * 64 + ((g ^ ((P0 >> 1) & 3)) << 4);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const i32x4 bf = *reinterpret_cast<const i32x4*>(sqb + (P0 + (SCOLS + 2) * (m0 + m)) * 64 + ((g ^ ((h0 + m0 + m) & 3)) << 4));
+        const i32x4 bf = *reinterpret_cast<const i32x4*>(base1 + m * (LW * 64));
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           acc1[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -389,9 +400,9 @@ bool fire_stream_eligible(int cin, int s, int e1, int e3, int dtype) {
   return stream_shape(cin, s, e1, e3, dtype, &a, &b, &c);
 }
 
-template <typename T, int NCHX, int NTS, int NWAVES, bool POOL>
+template <typename T, int NCHX, int NTS, int NWAVES, bool POOL, int RS>
 static void launch_stream(const FireSArgs& a, hipStream_t st) {
-  const size_t lds = 2 * (size_t)Geo<POOL>::TILE + (size_t)NCHX * NTS * 1024 + (size_t)(NWAVES / 4) * 4 * 1024 + (size_t)(2 * a.E + a.S) * 4;
+  const size_t lds = 2 * (size_t)Geo<POOL>::TILE + (size_t)NCHX * NTS * 1024 + (size_t)(NWAVES / RS / 2) * 4 * 1024 + (size_t)(2 * a.E + a.S) * 4;
   // persistent: 8 waves per CU (the register-resident weights + prefetched input allow 2 per SIMD)
   int grid = 256 * (8 / NWAVES);
   if (grid > (a.ntiles + 7) / 8 * 8) grid = (a.ntiles + 7) / 8 * 8;
@@ -399,20 +410,27 @@ static void launch_stream(const FireSArgs& a, hipStream_t st) {
   constexpr int MBH = (Geo<POOL>::BLK + NWAVES - 1) / NWAVES;
   if constexpr (2 * MBH * NCHX <= 16) {   // (these compile without spills; a spill in the tile loop drains vmcnt)
     if (tune(TUNE_DBG) != 8) {
-      hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 2, POOL>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
+      hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 2, POOL, RS>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
       return;
     }
   }
-  hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 1, POOL>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
+  hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 1, POOL, RS>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
 }
 
 template <typename T, bool POOL>
 static bool dispatch_stream(const FireSArgs& a, int nchx, int nts, int nwaves, hipStream_t st) {
+  // nwaves = 4 per 64-cout group at row split 2.  One group (E = 64) can also run as 8 waves at row split 4 (half the
+  // input fragments per wave, two tiles in flight): measured 5-12 % SLOWER on MI355X, kept behind "dbg" & 64.
+  const bool rs4 = nwaves == 4 && (tune(TUNE_DBG) & 64);
 #define SQDET_FS(NC, NS, NW) \
-  if (nchx == NC && nts == NS && nwaves == NW) { launch_stream<T, NC, NS, NW, POOL>(a, st); return true; }
+  if (nchx == NC && nts == NS && nwaves == NW) { launch_stream<T, NC, NS, NW, POOL, 2>(a, st); return true; }
+#define SQDET_FS4(NC, NS) \
+  if (rs4 && nchx == NC && nts == NS) { launch_stream<T, NC, NS, 8, POOL, 4>(a, st); return true; }
+  SQDET_FS4(2, 1) SQDET_FS4(4, 1) SQDET_FS4(2, 2) SQDET_FS4(4, 2)
   SQDET_FS(2, 1, 4) SQDET_FS(4, 1, 4) SQDET_FS(2, 2, 4) SQDET_FS(4, 2, 4)
   SQDET_FS(2, 1, 8) SQDET_FS(4, 1, 8) SQDET_FS(2, 2, 8) SQDET_FS(4, 2, 8) SQDET_FS(8, 1, 8) SQDET_FS(8, 2, 8)
 #undef SQDET_FS
+#undef SQDET_FS4
   return false;
 }
 
