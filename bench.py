@@ -181,10 +181,10 @@ def main(argv=None):
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
         # HBM bytes per launch from the PMC counters: not measurable inside this process; taken from the
         # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-        # (profiles/r01_f_hbm_traffic_pmc.json: 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), else null
+        # (profiles/r01_g_hbm_traffic_pmc.json: 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), else null
         roof["traffic"] = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_f_hbm_traffic_pmc.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r01_g_hbm_traffic_pmc.json")) as fh:
                 pmc = json.load(fh)["by_layer"]
             if args.dtype == "fp16" and (args.batch, args.height, args.width) == (32, 375, 1242):
                 roof["traffic"] = pmc.get(name)

@@ -26,10 +26,10 @@ def load(path, counter):
 # layer of sqdet_net_forward -> (substring of the kernel symbol, rank among equal symbols by grid size, descending)
 LAYERS = [
     ("conv1+pool1", "stem_strip", 0),
-    ("fire2", "fire_streamIDF16_Li2ELi1ELi4E", 0), ("fire3", "fire_streamIDF16_Li4ELi1ELi4E", 0),
-    ("pool3", "maxpool3_kernel", 0),
-    ("fire4", "fire_streamIDF16_Li4ELi2ELi8E", 0), ("fire5", "fire_streamIDF16_Li8ELi2ELi8E", 0),
-    ("pool5", "maxpool3_kernel", 1),
+    ("fire2", "fire_streamIDF16_Li2ELi1ELi4E", 0), ("fire3+pool3", "fire_streamIDF16_Li4ELi1ELi4E", 0),
+    ("fire3", "fire_streamIDF16_Li4ELi1ELi4E", 0), ("pool3", "maxpool3_kernel", 0),          # (plans without pool fusion)
+    ("fire4", "fire_streamIDF16_Li4ELi2ELi8E", 0), ("fire5+pool5", "fire_streamIDF16_Li8ELi2ELi8E", 0),
+    ("fire5", "fire_streamIDF16_Li8ELi2ELi8E", 0), ("pool5", "maxpool3_kernel", 1),
     ("fire6", "fire_fusedIDF16_Li3ELi3ELi8E", 0), ("fire7", "fire_fusedIDF16_Li3ELi3ELi8E", 0),
     ("fire8", "fire_fusedIDF16_Li4ELi4ELi8E", 0), ("fire9", "fire_fusedIDF16_Li4ELi4ELi8E", 0),
     ("fire10", "fire_fusedIDF16_Li6ELi3ELi8E", 0), ("fire11", "fire_fusedIDF16_Li6ELi3ELi8E", 0),
