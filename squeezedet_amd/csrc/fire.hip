@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused
   // ~1-2k cycles away under load, and one step is only MT*NTW <= 24 MFMAs), and the NEXT item's first
   // fragments are requested before the current item's epilogue, so they land while the stores go out.
   constexpr int RB = FROWS / MT;   // row blocks per cout item
-  constexpr int WD = (MT == 4 && NTW <= 4) ? 2 : (NTW <= 3 ? 4 : 3);
+  constexpr int WD = (MT == 4 && NTW <= 4) ? 2 : (NTW <= 3 ? 4 : 2);   // even: the B-fragment ping-pong below keys on u & 1
   T* y = reinterpret_cast<T*>(a.y);
   const int ox = ox0 + j;
   const int ctot = a.E1 + a.E3;
@@ -225,28 +225,34 @@ __global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // B fragments (activations, from the LDS squeeze tile) are double-buffered one step ahead as well: a step
+    // whose MFMAs had to wait for its own ds_reads left the matrix pipe idle for an LDS latency every 24 MFMAs.
+    auto load_bf = [&](int s, i32x4 (&bf)[MT]) {
+      const int c = it.is3 ? s / 9 : s;
+      const int tap = it.is3 ? s - c * 9 : 4;
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const unsigned char* lchunk = lds + c * FCHUNK;
+      const int P0 = dy * (FCOLS + 2) + j + dx;
+      const int h0 = P0 >> 1;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int slot = g ^ ((h0 + m0 + m) & 3);
+        bf[m] = *reinterpret_cast<const i32x4*>(lchunk + (P0 + (FCOLS + 2) * (m0 + m)) * 64 + (slot << 4));
+      }
+    };
+    i32x4 bfp[2][MT];
+    load_bf(0, bfp[0]);
 #pragma unroll 1
     for (int s0 = 0; s0 < it.steps; s0 += WD) {
 #pragma unroll
       for (int u = 0; u < WD; ++u) {
         const int s = s0 + u;
         if (s >= it.steps) break;
-        const int c = it.is3 ? s / 9 : s;
-        const int tap = it.is3 ? s - c * 9 : 4;
-        const int dy = tap / 3, dx = tap - dy * 3;
-        const unsigned char* lchunk = lds + c * FCHUNK;
-        const int P0 = dy * (FCOLS + 2) + j + dx;
-        const int h0 = P0 >> 1;
-        i32x4 bf[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const int slot = g ^ ((h0 + m0 + m) & 3);
-          bf[m] = *reinterpret_cast<const i32x4*>(lchunk + (P0 + (FCOLS + 2) * (m0 + m)) * 64 + (slot << 4));
-        }
+        if (s + 1 < it.steps) load_bf(s + 1, bfp[(u + 1) & 1]);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], afr[u][t], bf[m]);
+          for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], afr[u][t], bfp[u & 1][m]);
         if (s + WD < it.steps) {
           const i32x4* wp = frag(it, s + WD);
 #pragma unroll
