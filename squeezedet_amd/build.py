@@ -34,6 +34,7 @@ SOURCES = [
     ("postproc.hip", ["-ffp-contract=off"]),
     ("filter_fast.hip", ["-ffp-contract=off"]),
     ("train.hip", ["-ffp-contract=off"]),
+    ("wgrad.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("probe.hip", []),
     ("net.cpp", []),
 ]

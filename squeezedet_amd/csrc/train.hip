@@ -46,99 +46,7 @@ __global__ void pack_bwd_data_kernel(const float* __restrict__ w, T* __restrict_
   }
 }
 
-// ------------------------------------------------------------------ backward-filter (wgrad)
-// dW[tap][ci][co] = sum_p X[p@tap][ci] * dY[p][co]; GEMM M = ci, N = co, K = pixels.
-// Workgroup: one tap x (MW*16 ci) x (NW*16 co) tile; 4 waves 2x2, each (MW/2 x NW/2) MFMA tiles;
-// K walked in 32-pixel stages staged through LDS (coalesced 16-byte loads, TF zero padding by
-// bounds predication); blockIdx.z owns every ksplit-th stage and writes a partial [tap][ci][co]
-// slab; wgrad_reduce sums the slabs in a fixed order (deterministic).
-struct WgArgs {
-  const float* x;
-  const float* dy;
-  float* partial;
-  int N, H, W, Cin, Cout, k, pad;
-  int x_cstride, x_coffset, dy_cstride, dy_coffset;
-  int P, nstages, ksplit, ci_tiles;
-};
-
-template <int MW, int NW>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgArgs a) {
-  constexpr int PS = 32;                 // pixels per stage
-  constexpr int XS = MW * 16 + 16;       // LDS row strides (floats): == 16 mod 32 -> the two k rows a
-  constexpr int DS = NW * 16 + 16;       //   ds_read_b32 half-wave touches hit disjoint bank halves
-  __shared__ float xs[PS * XS];
-  __shared__ float dsm[PS * DS];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
-  const int i = lane & 15, kk = lane >> 4;
-  const int tap = blockIdx.x / a.ci_tiles;
-  const int ci0 = (blockIdx.x - tap * a.ci_tiles) * (MW * 16);
-  const int co0 = blockIdx.y * (NW * 16);
-  const int ty = tap / a.k, tx = tap - ty * a.k;
-
-  f32x4 acc[MW / 2][NW / 2];
-#pragma unroll
-  for (int mi = 0; mi < MW / 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NW / 2; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  for (int st = blockIdx.z; st < a.nstages; st += a.ksplit) {
-    const int p0 = st * PS;
-    // ---- stage X (shifted by the tap) and dY ----
-    for (int idx = threadIdx.x; idx < PS * (MW * 4); idx += 256) {
-      const int pp = idx / (MW * 4), c4 = idx - pp * (MW * 4);
-      const int p = p0 + pp;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      const int ci = ci0 + c4 * 4;
-      if (p < a.P && ci < a.Cin) {
-        const int n = p / (a.H * a.W);
-        const int r = p - n * (a.H * a.W);
-        const int y = r / a.W, xx = r - y * a.W;
-        const int iy = y + ty - a.pad, ix = xx + tx - a.pad;
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-          v = *reinterpret_cast<const f32x4*>(a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.x_cstride + a.x_coffset + ci);
-      }
-      *reinterpret_cast<f32x4*>(&xs[pp * XS + c4 * 4]) = v;
-    }
-    for (int idx = threadIdx.x; idx < PS * (NW * 4); idx += 256) {
-      const int pp = idx / (NW * 4), c4 = idx - pp * (NW * 4);
-      const int p = p0 + pp;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      const int co = co0 + c4 * 4;
-      if (p < a.P && co < a.Cout) v = *reinterpret_cast<const f32x4*>(a.dy + (size_t)p * a.dy_cstride + a.dy_coffset + co);
-      *reinterpret_cast<f32x4*>(&dsm[pp * DS + c4 * 4]) = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < PS / 4; ++ks) {
-      float af[MW / 2], bf[NW / 2];
-#pragma unroll
-      for (int mi = 0; mi < MW / 2; ++mi) af[mi] = xs[(ks * 4 + kk) * XS + (wm * (MW / 2) + mi) * 16 + i];
-#pragma unroll
-      for (int ni = 0; ni < NW / 2; ++ni) bf[ni] = dsm[(ks * 4 + kk) * DS + (wn * (NW / 2) + ni) * 16 + i];
-#pragma unroll
-      for (int mi = 0; mi < MW / 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NW / 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  // D layout: col (co) = lane&15, row (ci) = 4*(lane>>4) + reg
-  float* out = a.partial + (size_t)blockIdx.z * a.k * a.k * a.Cin * a.Cout;
-#pragma unroll
-  for (int mi = 0; mi < MW / 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NW / 2; ++ni) {
-      const int co = co0 + (wn * (NW / 2) + ni) * 16 + i;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ci = ci0 + (wm * (MW / 2) + mi) * 16 + kk * 4 + r;
-        if (ci < a.Cin && co < a.Cout) out[((size_t)tap * a.Cin + ci) * a.Cout + co] = acc[mi][ni][r];
-      }
-    }
-}
-
+// (conv backward-filter lives in wgrad.hip)
 // out[e] = sum_z partial[z][e]  (+ decay * w[e] when w != NULL), z ascending: deterministic.
 __global__ void slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, const float* __restrict__ w,
                                    float decay, size_t count, int nslabs) {
@@ -147,30 +55,6 @@ __global__ void slab_reduce_kernel(const float* __restrict__ partial, float* __r
     for (int z = 0; z < nslabs; ++z) s += partial[(size_t)z * count + e];
     if (w) s += decay * w[e];
     out[e] = s;
-  }
-}
-
-// bias gradient partials: partial[blockIdx.x][co] = sum over this block's pixels of dy[p][co]
-// 256 threads = (256/CW pixel lanes) x (CW channels): every thread streams pixels for one channel of
-// the current CW-channel chunk, lanes are summed through LDS in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dy, float* __restrict__ partial,
-                                                                int P, int cout, int cstride, int coffset, int cw) {
-  __shared__ float red[256];
-  const int tx = threadIdx.x % cw, ty = threadIdx.x / cw;
-  const int lanes = 256 / cw;
-  for (int cb = 0; cb < cout; cb += cw) {
-    const int co = cb + tx;
-    float s = 0.f;
-    if (co < cout)
-      for (int p = blockIdx.x * lanes + ty; p < P; p += gridDim.x * lanes) s += dy[(size_t)p * cstride + coffset + co];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (ty == 0 && co < cout) {
-      float t = 0.f;
-      for (int l = 0; l < lanes; ++l) t += red[l * cw + tx];
-      partial[(size_t)blockIdx.x * cout + co] = t;
-    }
-    __syncthreads();
   }
 }
 
@@ -434,70 +318,6 @@ extern "C" int sqdet_conv2d_nhwc_bwd_data(const void* dy, const void* w_packed_b
   SQDET_REQUIRE(k == 1 || k == 3, "conv2d_bwd_data: k must be 1 or 3 (stride 1, SAME)");
   return conv2d_launch_ex(dy, w_packed_bwd, nullptr, dx, n, h, w, cout, cin, k, 1, SQDET_PAD_SAME, 0, dtype, cin, 0,
                           dy_cstride, dy_coffset, accumulate, as_stream(stream));
-}
-
-extern "C" size_t sqdet_conv2d_bwd_filter_workspace_bytes(int n, int h, int w, int cin, int cout, int k) {
-  // ksplit slabs of the filter + 256 rows of bias partials
-  const long P = (long)n * h * w;
-  long nst = (P + 31) / 32;
-  long ks = nst < 64 ? nst : 64;
-  return (size_t)(ks * (long)k * k * cin * cout + 256L * cout) * sizeof(float);
-}
-
-extern "C" int sqdet_conv2d_nhwc_bwd_filter(const float* x, const float* dy, float* dw_hwio, float* dbias,
-                                            const float* w_hwio_for_decay, float weight_decay, float* workspace, int n,
-                                            int h, int w, int cin, int cout, int k, int x_cstride, int x_coffset,
-                                            int dy_cstride, int dy_coffset, sqdet_stream_t stream) {
-  SQDET_REQUIRE(x && dy && dw_hwio && workspace, "conv2d_bwd_filter: null pointer");
-  SQDET_REQUIRE((k == 1 || k == 3) && n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "conv2d_bwd_filter: bad dims");
-  SQDET_UNSUPPORTED(cin % 4 || cout % 4 || x_cstride % 4 || x_coffset % 4 || dy_cstride % 4 || dy_coffset % 4,
-                    "conv2d_bwd_filter: channel counts / strides must be multiples of 4");
-  hipStream_t st = as_stream(stream);
-  WgArgs a;
-  a.x = x; a.dy = dy; a.partial = workspace;
-  a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout; a.k = k; a.pad = k == 3 ? 1 : 0;
-  a.x_cstride = x_cstride; a.x_coffset = x_coffset; a.dy_cstride = dy_cstride; a.dy_coffset = dy_coffset;
-  const long P = (long)n * h * w;
-  SQDET_UNSUPPORTED(P > (1L << 30), "conv2d_bwd_filter: too many pixels");
-  a.P = (int)P;
-  a.nstages = (int)((P + 31) / 32);
-  const bool big_m = cin > 32, big_n = cout > 32;
-  const int mw = big_m ? 4 : 2, nw = big_n ? 4 : 2;
-  a.ci_tiles = (cin + mw * 16 - 1) / (mw * 16);
-  const int gx = k * k * a.ci_tiles, gy = (cout + nw * 16 - 1) / (nw * 16);
-  // enough workgroups to fill the chip, at most 64 slabs
-  int ks = (2048 + gx * gy - 1) / (gx * gy);
-  if (ks > 64) ks = 64;
-  {  // keep the slab buffer (and the reduction's read traffic) bounded: ks * |dW| <= 16 M floats
-    const long per = (long)k * k * cin * cout;
-    const long cap = (16L << 20) / (per > 0 ? per : 1);
-    if (cap >= 1 && ks > cap) ks = (int)cap;
-  }
-  if (ks > a.nstages) ks = a.nstages;
-  if (ks < 1) ks = 1;
-  a.ksplit = ks;
-  const dim3 grid(gx, gy, ks);
-  if (big_m && big_n) hipLaunchKernelGGL((wgrad_kernel<4, 4>), grid, dim3(256), 0, st, a);
-  else if (big_m) hipLaunchKernelGGL((wgrad_kernel<4, 2>), grid, dim3(256), 0, st, a);
-  else if (big_n) hipLaunchKernelGGL((wgrad_kernel<2, 4>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((wgrad_kernel<2, 2>), grid, dim3(256), 0, st, a);
-  SQDET_CHECK_HIP(hipGetLastError());
-  const size_t count = (size_t)k * k * cin * cout;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(count)), dim3(256), 0, st, workspace, dw_hwio, w_hwio_for_decay,
-                     weight_decay, count, ks);
-  SQDET_CHECK_HIP(hipGetLastError());
-  if (dbias) {
-    float* bpart = workspace + (size_t)ks * count;
-    int rows = (int)(P < 256 ? P : 256);
-    const int cw = cout <= 16 ? 16 : (cout <= 32 ? 32 : 64);
-    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(rows), dim3(256), 0, st, dy, bpart, (int)P, cout, dy_cstride,
-                       dy_coffset, cw);
-    SQDET_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(cout)), dim3(256), 0, st, bpart, dbias, (const float*)nullptr, 0.f,
-                       (size_t)cout, rows);
-    SQDET_CHECK_HIP(hipGetLastError());
-  }
-  return SQDET_OK;
 }
 
 extern "C" int sqdet_relu_bwd(const float* y, float* dy_inout, size_t count, sqdet_stream_t stream) {

@@ -1,0 +1,303 @@
+// Conv backward-filter (+ bias gradient) for gfx950, float32 (the reference's training dtype):
+//   dW[ty][tx][ci][co] = sum_p X[p @ (ty,tx)][ci] * dY[p][co]        (stride-1 SAME convs, k = 1 or 3)
+//   dbias[co]          = sum_p dY[p][co]
+// (the gradients tf.gradients produces for tf.nn.conv2d + tf.nn.bias_add, nn_skeleton.py:539-542, which
+// ModelSkeleton._add_train_graph feeds to the optimizer, nn_skeleton.py:343-349).
+//
+// A GEMM with M = ci, N = co and K = pixels on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32).  One workgroup owns a
+// (ci tile) x (co tile) block of dW for ALL the taps of its tap group (1 tap of a 1x1, one kernel row or all nine taps
+// of a 3x3), so X and dY are read once per tap group instead of once per tap.  K is walked in stages of 4 rows x 16
+// columns of one image: the stage's dY tile and X tile (with the 1-pixel halo the taps need; TF SAME zero padding by
+// out-of-range buffer loads, which return zeros) go global -> registers -> LDS one stage ahead of the MFMAs, and every
+// tap's A fragment is the same LDS image read at a shifted pixel offset.  blockIdx.z owns every ksplit-th stage and
+// writes a partial slab; slab_reduce2 sums the slabs in a fixed order, so the result is deterministic (no atomics).
+// The bias gradient rides along as one more MFMA per k-step with an all-ones A operand (row 0 of the product is the
+// column sum of dY), in the waves that own ci tile 0.
+#include "conv_common.h"
+
+namespace sqdet {
+
+struct WgArgs {
+  const float* x;
+  const float* dy;
+  float* partial;
+  int H, W, Cin, Cout, k;
+  int x_cstride, x_coffset, dy_cstride, dy_coffset;
+  int BY, BX, nstages, ksplit, ci_tiles, do_bias;
+  unsigned x_bytes, dy_bytes;
+  size_t slab_stride;  // floats per slab = k*k*Cin*Cout + Cout
+};
+
+constexpr unsigned kOOB = 0xfffffff0u;
+
+template <int MT, int NT, int WM, int TAPS>
+__global__ __launch_bounds__(256, 2) void wgrad_tile(WgArgs a) {
+  constexpr int WN = 4 / WM;
+  constexpr int MTILE = WM * MT * 16, NTILE = WN * NT * 16;
+  constexpr int M4 = MTILE / 4, N4 = NTILE / 4;
+  constexpr int HR = TAPS == 9 ? 6 : 4, HC = TAPS == 1 ? 16 : 18;
+  // row pitches (floats) that are odd multiples of 16: the four k rows one ds_read_b32 touches land in disjoint banks
+  constexpr int XS = ((MTILE / 16) & 1) ? MTILE : MTILE + 16;
+  constexpr int DS = ((NTILE / 16) & 1) ? NTILE : NTILE + 16;
+  constexpr int XN = HR * HC * M4, DN = 64 * N4;
+  constexpr int NXL = (XN + 255) / 256, NDL = (DN + 255) / 256;
+  constexpr int TY = TAPS == 9 ? 3 : 1, TX = TAPS == 1 ? 1 : 3;
+  __shared__ float xs[HR * HC * XS];
+  __shared__ float dsm[64 * DS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int i = lane & 15, kk = lane >> 4;
+  const int tg = blockIdx.x / a.ci_tiles;           // tap group: the kernel row when TAPS == 3
+  const int ci_tile = blockIdx.x - tg * a.ci_tiles;
+  const int ci0 = ci_tile * MTILE, co0 = blockIdx.y * NTILE;
+  const int py = TAPS == 9 ? 1 : (TAPS == 3 ? 1 - tg : 0), px = TAPS == 1 ? 0 : 1;
+  const bool bias_wave = a.do_bias && ci_tile == 0 && tg == 0 && wm == 0;
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.dy_bytes, 0x00020000);
+
+  f32x4 acc[TAPS][MT][NT], accb[NT];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) acc[t][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) accb[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  i32x4 xr[NXL], dr[NDL];
+  auto issue = [&](int s) {
+    const int n = s / (a.BY * a.BX);
+    const int rem = s - n * (a.BY * a.BX);
+    const int by = rem / a.BX;
+    const int y0 = by * 4, x0 = (rem - by * a.BX) * 16;
+#pragma unroll
+    for (int j = 0; j < NXL; ++j) {
+      const int idx = tid + 256 * j;
+      const int pix = idx / M4, c4 = idx - pix * M4;
+      const int hr = pix / HC, hc = pix - hr * HC;
+      const int iy = y0 + hr - py, ix = x0 + hc - px, ci = ci0 + 4 * c4;
+      const bool ok = idx < XN && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && ci < a.Cin;
+      const unsigned off = ((unsigned)((n * a.H + iy) * a.W + ix) * (unsigned)a.x_cstride + (unsigned)(a.x_coffset + ci)) * 4u;
+      xr[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : kOOB, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NDL; ++j) {
+      const int idx = tid + 256 * j;
+      const int pp = idx / N4, c4 = idx - pp * N4;
+      const int y = y0 + (pp >> 4), xx = x0 + (pp & 15), co = co0 + 4 * c4;
+      const bool ok = idx < DN && y < a.H && xx < a.W && co < a.Cout;
+      const unsigned off = ((unsigned)((n * a.H + y) * a.W + xx) * (unsigned)a.dy_cstride + (unsigned)(a.dy_coffset + co)) * 4u;
+      dr[j] = __builtin_amdgcn_raw_buffer_load_b128(rd, ok ? off : kOOB, 0, 0);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < NXL; ++j) {
+      const int idx = tid + 256 * j;
+      const int pix = idx / M4, c4 = idx - pix * M4;
+      if (XN % 256 == 0 || idx < XN) *reinterpret_cast<i32x4*>(&xs[pix * XS + 4 * c4]) = xr[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NDL; ++j) {
+      const int idx = tid + 256 * j;
+      const int pp = idx / N4, c4 = idx - pp * N4;
+      if (DN % 256 == 0 || idx < DN) *reinterpret_cast<i32x4*>(&dsm[pp * DS + 4 * c4]) = dr[j];
+    }
+  };
+
+  const float* xa = xs + kk * XS + wm * (MT * 16) + i;
+  const float* da = dsm + kk * DS + wn * (NT * 16) + i;
+  int s = blockIdx.z;
+  if (s < a.nstages) {
+    issue(s);
+    commit();
+  }
+  __syncthreads();
+  for (; s < a.nstages; s += a.ksplit) {
+    const bool more = s + a.ksplit < a.nstages;
+    if (more) issue(s + a.ksplit);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int r = ks >> 2, c0 = 4 * (ks & 3);
+      float bf[NT];
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) bf[ni] = da[(ks * 4) * DS + ni * 16];
+      if (bias_wave) {
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) accb[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bf[ni], accb[ni], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ty = 0; ty < TY; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < TX; ++tx) {
+          float af[MT];
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi) af[mi] = xa[((r + ty) * HC + c0 + tx) * XS + mi * 16];
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+              acc[ty * TX + tx][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf[ni], acc[ty * TX + tx][mi][ni], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (more) commit();
+    __syncthreads();
+  }
+
+  // D layout: col (co) = lane & 15, row (ci) = 4 * (lane >> 4) + reg
+  float* out = a.partial + (size_t)blockIdx.z * a.slab_stride;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    const int tap = TAPS == 3 ? tg * 3 + t : t;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) {
+        const int co = co0 + (wn * NT + ni) * 16 + i;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int ci = ci0 + (wm * MT + mi) * 16 + kk * 4 + rr;
+          if (ci < a.Cin && co < a.Cout) out[((size_t)tap * a.Cin + ci) * a.Cout + co] = acc[t][mi][ni][rr];
+        }
+      }
+  }
+  if (bias_wave && kk == 0) {
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      const int co = co0 + (wn * NT + ni) * 16 + i;
+      if (co < a.Cout) out[(size_t)a.k * a.k * a.Cin * a.Cout + co] = accb[ni][0];
+    }
+  }
+}
+
+// dw[e] = sum_z partial[z][e] (+ decay * w[e]), dbias[c] = sum_z partial[z][count + c]; z ascending: deterministic.
+__global__ void slab_reduce2_kernel(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ dbias,
+                                    const float* __restrict__ w, float decay, size_t count, int cout, size_t stride, int nslabs) {
+  const size_t total = count + (dbias ? (size_t)cout : 0);
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 4 <= nslabs; z += 4) {   // four independent loads in flight; the additions stay in slab order
+      const float v0 = partial[(size_t)z * stride + e], v1 = partial[(size_t)(z + 1) * stride + e];
+      const float v2 = partial[(size_t)(z + 2) * stride + e], v3 = partial[(size_t)(z + 3) * stride + e];
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; z < nslabs; ++z) s0 += partial[(size_t)z * stride + e];
+    float s = (s0 + s1) + (s2 + s3);
+    if (e < count) {
+      if (w) s += decay * w[e];
+      dw[e] = s;
+    } else {
+      dbias[e - count] = s;
+    }
+  }
+}
+
+namespace {
+
+struct WgPlan {
+  int variant;   // index into the instantiation table below
+  int taps;      // taps per workgroup: 1 (k = 1), 3 or 9 (k = 3)
+  int mtile, ntile;
+  int ci_tiles, co_tiles, BY, BX, nstages, ksplit;
+  size_t count, slab_stride;
+};
+
+// variants: {MT, NT, WM} -> tile (WM*MT*16) x ((4/WM)*NT*16)
+enum { V_64x16, V_64x32, V_64x48, V_64x80, V_64x64, V_32x64, V_16x64, V_48x64 };
+
+WgPlan wgrad_plan(int n, int h, int w, int cin, int cout, int k) {
+  WgPlan p;
+  const long P = (long)n * h * w;
+  if (cin <= 16) { p.variant = V_16x64; p.mtile = 16; p.ntile = 64; }
+  else if (cin <= 48 && cin > 32) { p.variant = V_48x64; p.mtile = 48; p.ntile = 64; }
+  else if (k == 1 && cout <= 16) { p.variant = V_64x16; p.mtile = 64; p.ntile = 16; }
+  else if (k == 1 && cout <= 32) { p.variant = V_64x32; p.mtile = 64; p.ntile = 32; }
+  else if (k == 1 && (cout <= 48 || cout == 96)) { p.variant = V_64x48; p.mtile = 64; p.ntile = 48; }
+  else if (k == 3 && cout > 64 && cout <= 80) { p.variant = V_64x80; p.mtile = 64; p.ntile = 80; }
+  else if (cin % 64 == 0) { p.variant = V_64x64; p.mtile = 64; p.ntile = 64; }
+  else { p.variant = V_32x64; p.mtile = 32; p.ntile = 64; }
+  // all nine taps in one workgroup where the accumulators fit (the few-channel early maps, where X / dY traffic
+  // matters most); one kernel row per workgroup elsewhere
+  p.taps = k == 1 ? 1 : ((P >= 100000 && (p.variant == V_16x64 || p.variant == V_32x64)) ? 9 : 3);
+  p.ci_tiles = (cin + p.mtile - 1) / p.mtile;
+  p.co_tiles = (cout + p.ntile - 1) / p.ntile;
+  p.BY = (h + 3) / 4;
+  p.BX = (w + 15) / 16;
+  p.nstages = n * p.BY * p.BX;
+  p.count = (size_t)k * k * cin * cout;
+  p.slab_stride = p.count + (size_t)cout;
+  const int tiles = (k * k / p.taps) * p.ci_tiles * p.co_tiles;
+  int ks = (512 + tiles - 1) / tiles;                                 // two resident workgroups per CU
+  if (ks > p.nstages / 4) ks = p.nstages / 4;                         // at least four stages each
+  const long cap = (16L << 20) / (long)p.slab_stride;                 // bound the slab buffer: ks * |dW| <= 16 M floats
+  if (ks > cap) ks = (int)cap;
+  if (ks < 1) ks = 1;
+  p.ksplit = ks;
+  return p;
+}
+
+template <int MT, int NT, int WM, bool NINE>
+void launch_taps(const WgPlan& p, dim3 grid, hipStream_t st, const WgArgs& a) {
+  if (p.taps == 1) hipLaunchKernelGGL((wgrad_tile<MT, NT, WM, 1>), grid, dim3(256), 0, st, a);
+  else if (p.taps == 3) hipLaunchKernelGGL((wgrad_tile<MT, NT, WM, 3>), grid, dim3(256), 0, st, a);
+  else if constexpr (NINE) hipLaunchKernelGGL((wgrad_tile<MT, NT, WM, 9>), grid, dim3(256), 0, st, a);
+}
+
+}  // namespace
+}  // namespace sqdet
+
+using namespace sqdet;
+
+extern "C" size_t sqdet_conv2d_bwd_filter_workspace_bytes(int n, int h, int w, int cin, int cout, int k) {
+  if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || (k != 1 && k != 3)) return 0;
+  const WgPlan p = wgrad_plan(n, h, w, cin, cout, k);
+  return (size_t)p.ksplit * p.slab_stride * sizeof(float);
+}
+
+extern "C" int sqdet_conv2d_nhwc_bwd_filter(const float* x, const float* dy, float* dw_hwio, float* dbias,
+                                            const float* w_hwio_for_decay, float weight_decay, float* workspace, int n,
+                                            int h, int w, int cin, int cout, int k, int x_cstride, int x_coffset,
+                                            int dy_cstride, int dy_coffset, sqdet_stream_t stream) {
+  SQDET_REQUIRE(x && dy && dw_hwio && workspace, "conv2d_bwd_filter: null pointer");
+  SQDET_REQUIRE((k == 1 || k == 3) && n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "conv2d_bwd_filter: bad dims");
+  SQDET_UNSUPPORTED(cin % 4 || cout % 4 || x_cstride % 4 || x_coffset % 4 || dy_cstride % 4 || dy_coffset % 4,
+                    "conv2d_bwd_filter: channel counts / strides must be multiples of 4");
+  const size_t P = (size_t)n * h * w;
+  SQDET_UNSUPPORTED(P * x_cstride * 4 >= 0xfffffff0ull || P * dy_cstride * 4 >= 0xfffffff0ull,
+                    "conv2d_bwd_filter: tensors of 4 GiB or more");
+  hipStream_t st = as_stream(stream);
+  const WgPlan p = wgrad_plan(n, h, w, cin, cout, k);
+  WgArgs a;
+  a.x = x; a.dy = dy; a.partial = workspace;
+  a.H = h; a.W = w; a.Cin = cin; a.Cout = cout; a.k = k;
+  a.x_cstride = x_cstride; a.x_coffset = x_coffset; a.dy_cstride = dy_cstride; a.dy_coffset = dy_coffset;
+  a.BY = p.BY; a.BX = p.BX; a.nstages = p.nstages; a.ksplit = p.ksplit; a.ci_tiles = p.ci_tiles;
+  a.do_bias = dbias != nullptr;
+  a.x_bytes = (unsigned)(P * x_cstride * 4);
+  a.dy_bytes = (unsigned)(P * dy_cstride * 4);
+  a.slab_stride = p.slab_stride;
+  const dim3 grid((k * k / p.taps) * p.ci_tiles, p.co_tiles, p.ksplit);
+  switch (p.variant) {
+    case V_64x16: hipLaunchKernelGGL((wgrad_tile<1, 1, 4, 1>), grid, dim3(256), 0, st, a); break;
+    case V_64x32: hipLaunchKernelGGL((wgrad_tile<1, 2, 4, 1>), grid, dim3(256), 0, st, a); break;
+    case V_64x48: hipLaunchKernelGGL((wgrad_tile<1, 3, 4, 1>), grid, dim3(256), 0, st, a); break;
+    case V_64x80: hipLaunchKernelGGL((wgrad_tile<1, 5, 4, 3>), grid, dim3(256), 0, st, a); break;
+    case V_64x64: launch_taps<2, 2, 2, false>(p, grid, st, a); break;
+    case V_32x64: launch_taps<1, 2, 2, true>(p, grid, st, a); break;
+    case V_16x64: launch_taps<1, 1, 1, true>(p, grid, st, a); break;
+    default: launch_taps<3, 1, 1, false>(p, grid, st, a); break;
+  }
+  SQDET_CHECK_HIP(hipGetLastError());
+  const size_t total = p.count + (dbias ? (size_t)cout : 0);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(slab_reduce2_kernel, dim3(blocks), dim3(256), 0, st, workspace, dw_hwio, dbias, w_hwio_for_decay,
+                     weight_decay, p.count, cout, p.slab_stride, p.ksplit);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}

@@ -38,7 +38,14 @@ def _conv_ref(x, w, stride=1):
 
 BWD_CASES = [("e1_16_64", 2, 23, 31, 16, 64, 1), ("e3_16_64", 2, 23, 31, 16, 64, 3), ("sq_128_32", 1, 12, 39, 128, 32, 1),
              ("e3_48_192", 1, 12, 20, 48, 192, 3), ("sq_768_96", 1, 9, 14, 768, 96, 1), ("e3_96_384", 1, 9, 14, 96, 384, 3),
-             ("convdet_768_72", 2, 7, 13, 768, 72, 3), ("e1_32_128_large", 2, 47, 63, 32, 128, 1)]
+             ("convdet_768_72", 2, 7, 13, 768, 72, 3), ("e1_32_128_large", 2, 47, 63, 32, 128, 1),
+             # backward-filter tile variants: 9 taps per workgroup (>= 100k pixels, Cin 16 / 32), Cout 16 / 48 / 96
+             # squeezes, Cin 48 / 64 / 96 expands, ResNet-style 64->64 3x3 and 256->64 1x1, ragged Cin / Cout tails
+             ("e3_16_64_9tap", 2, 190, 270, 16, 64, 3), ("e3_32_128_9tap", 1, 250, 401, 32, 128, 3),
+             ("sq_96_16", 1, 21, 37, 96, 16, 1), ("sq_256_48", 1, 12, 39, 256, 48, 1), ("sq_512_96", 1, 9, 17, 512, 96, 1),
+             ("e1_48_192", 1, 12, 20, 48, 192, 1), ("e3_64_256", 1, 11, 19, 64, 256, 3), ("e1_96_384", 1, 9, 14, 96, 384, 1),
+             ("res_64_64", 1, 17, 33, 64, 64, 3), ("res_256_64", 1, 17, 33, 256, 64, 1), ("ragged_20_36", 1, 6, 18, 20, 36, 3),
+             ("ragged_40_24", 2, 5, 16, 40, 24, 1)]
 
 
 @pytest.mark.parametrize("case", BWD_CASES, ids=[c[0] for c in BWD_CASES])
