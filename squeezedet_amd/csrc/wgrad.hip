@@ -13,6 +13,8 @@
 // writes a partial slab; slab_reduce2 sums the slabs in a fixed order, so the result is deterministic (no atomics).
 // The bias gradient rides along as one more MFMA per k-step with an all-ones A operand (row 0 of the product is the
 // column sum of dY), in the waves that own ci tile 0.
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace sqdet {
@@ -116,33 +118,47 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile(WgArgs a) {
     commit();
   }
   __syncthreads();
+  // one k-step's operands: the dY fragment of every co tile and the X fragment of every (tap, ci tile); fetched from
+  // LDS one k-step ahead of the MFMAs that use them (the scheduling fences keep the compiler from sinking the reads
+  // back to their first use, where every MFMA group would wait out an LDS round trip)
+  float bfr[2][NT], afr[2][TAPS][MT];
+  auto fetch = [&](int ks, int slot) {
+    const int r = ks >> 2, c0 = 4 * (ks & 3);
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) bfr[slot][ni] = da[(ks * 4) * DS + ni * 16];
+#pragma unroll
+    for (int ty = 0; ty < TY; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < TX; ++tx)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) afr[slot][ty * TX + tx][mi] = xa[((r + ty) * HC + c0 + tx) * XS + mi * 16];
+  };
+  auto compute = [&](auto with_bias) {
+    fetch(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int cur = ks & 1;
+      if (ks + 1 < 16) fetch(ks + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (decltype(with_bias)::value) {
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) accb[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bfr[cur][ni], accb[ni], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni)
+            acc[t][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[cur][t][mi], bfr[cur][ni], acc[t][mi][ni], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   for (; s < a.nstages; s += a.ksplit) {
     const bool more = s + a.ksplit < a.nstages;
     if (more) issue(s + a.ksplit);
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const int r = ks >> 2, c0 = 4 * (ks & 3);
-      float bf[NT];
-#pragma unroll
-      for (int ni = 0; ni < NT; ++ni) bf[ni] = da[(ks * 4) * DS + ni * 16];
-      if (bias_wave) {
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni) accb[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bf[ni], accb[ni], 0, 0, 0);
-      }
-#pragma unroll
-      for (int ty = 0; ty < TY; ++ty)
-#pragma unroll
-        for (int tx = 0; tx < TX; ++tx) {
-          float af[MT];
-#pragma unroll
-          for (int mi = 0; mi < MT; ++mi) af[mi] = xa[((r + ty) * HC + c0 + tx) * XS + mi * 16];
-#pragma unroll
-          for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni)
-              acc[ty * TX + tx][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf[ni], acc[ty * TX + tx][mi][ni], 0, 0, 0);
-        }
-    }
+    if (bias_wave) compute(std::true_type{});
+    else compute(std::false_type{});
     __syncthreads();
     if (more) commit();
     __syncthreads();
@@ -232,7 +248,7 @@ WgPlan wgrad_plan(int n, int h, int w, int cin, int cout, int k) {
   p.count = (size_t)k * k * cin * cout;
   p.slab_stride = p.count + (size_t)cout;
   const int tiles = (k * k / p.taps) * p.ci_tiles * p.co_tiles;
-  int ks = (512 + tiles - 1) / tiles;                                 // two resident workgroups per CU
+  int ks = 512 / tiles;                                               // one round of two resident workgroups per CU
   if (ks > p.nstages / 4) ks = p.nstages / 4;                         // at least four stages each
   const long cap = (16L << 20) / (long)p.slab_stride;                 // bound the slab buffer: ks * |dW| <= 16 M floats
   if (ks > cap) ks = (int)cap;
