@@ -170,7 +170,9 @@ int sqdet_filter_prediction(const float* boxes, const float* probs, const int64_
  * SAME: every conv but the frozen conv1, nets/squeezeDet.py:40-42), the loss graph
  * (ModelSkeleton._add_loss_graph, nn_skeleton.py:285-327, on top of _add_interpretation_graph
  * :142-283) and the train graph (ModelSkeleton._add_train_graph, nn_skeleton.py:329-361).
- * float32 storage (SQDET_F32), the reference's training dtype.
+ * float32 storage (SQDET_F32) is the reference's training dtype; the activation-side kernels also take
+ * SQDET_F16 (mixed precision: float16 activations / activation gradients with loss scaling, float32
+ * master weights, weight gradients and optimizer -- BASELINE.json configs[4] "fp16 training").
  */
 
 /* Backward-data: dx = conv(dy, rot180(W)^T).  pack: float32 HWIO [k,k,cin,cout] -> fragment order
@@ -183,24 +185,31 @@ int sqdet_conv2d_nhwc_bwd_data(const void* dy, const void* w_packed_bwd, void* d
                                int cout, int k, int dtype, int dy_cstride, int dy_coffset, int accumulate,
                                sqdet_stream_t stream);
 
-/* Backward-filter (+ bias): dW[kh,kw,ci,co] = sum_pixels x@tap[ci]*dy[co] (+ weight_decay*W when
- * w_hwio_for_decay != NULL: the gradient of wd*l2_loss(W), nn_skeleton.py:66-69), dbias[co] =
- * sum dy (dbias may be NULL).  x / dy may be channel slices.  workspace: device scratch of
- * sqdet_conv2d_bwd_filter_workspace_bytes(...).  Deterministic (two-pass slab reduction). */
+/* Backward-filter (+ bias): dW[kh,kw,ci,co] = grad_scale * sum_pixels x@tap[ci]*dy[co] (+ weight_decay*W
+ * when w_hwio_for_decay != NULL: the gradient of wd*l2_loss(W), nn_skeleton.py:66-69), dbias[co] =
+ * grad_scale * sum dy (dbias may be NULL).  x / dy (dtype SQDET_F32 or SQDET_F16) may be channel slices;
+ * dW / dbias are float32 either way; grad_scale = 1, or 1/loss_scale in mixed-precision training.
+ * workspace: device scratch of sqdet_conv2d_bwd_filter_workspace_bytes(...).  Deterministic (two-pass
+ * slab reduction, no atomics). */
 size_t sqdet_conv2d_bwd_filter_workspace_bytes(int n, int h, int w, int cin, int cout, int k);
-int sqdet_conv2d_nhwc_bwd_filter(const float* x, const float* dy, float* dw_hwio, float* dbias,
-                                 const float* w_hwio_for_decay, float weight_decay, float* workspace, int n, int h,
-                                 int w, int cin, int cout, int k, int x_cstride, int x_coffset, int dy_cstride,
-                                 int dy_coffset, sqdet_stream_t stream);
+int sqdet_conv2d_nhwc_bwd_filter(const void* x, const void* dy, float* dw_hwio, float* dbias,
+                                 const float* w_hwio_for_decay, float weight_decay, float grad_scale, float* workspace,
+                                 int n, int h, int w, int cin, int cout, int k, int x_cstride, int x_coffset,
+                                 int dy_cstride, int dy_coffset, int dtype, sqdet_stream_t stream);
 
-/* dy *= (y > 0)  (tf.nn.relu gradient; count floats, multiple of 4). */
-int sqdet_relu_bwd(const float* y, float* dy_inout, size_t count, sqdet_stream_t stream);
+/* dy *= (y > 0)  (tf.nn.relu gradient; count elements, a multiple of 16 bytes). */
+int sqdet_relu_bwd(const void* y, void* dy_inout, size_t count, int dtype, sqdet_stream_t stream);
 /* y = x * mask * scale: tf.nn.dropout forward (mask = floor(keep_prob + U) in {0,1}, scale =
- * 1/keep_prob; nets/squeezeDet.py:74) and its backward. */
-int sqdet_scale_mask(const float* x, const float* mask, float* y, float scale, size_t count, sqdet_stream_t stream);
+ * 1/keep_prob; nets/squeezeDet.py:74) and its backward.  x, mask, y share dtype. */
+int sqdet_scale_mask(const void* x, const void* mask, void* y, float scale, size_t count, int dtype,
+                     sqdet_stream_t stream);
+/* dst[i] = (dst_dtype)(src[i] * scale): the float16 <-> float32 hand-offs of mixed-precision training (float16
+ * preds -> the float32 loss kernel; its float32 dpreds * loss_scale -> float16).  count a multiple of 4. */
+int sqdet_convert_scale(const void* src, int src_dtype, void* dst, int dst_dtype, float scale, size_t count,
+                        sqdet_stream_t stream);
 /* tf.nn.max_pool gradient: dx[cell] = sum of dy over the windows whose first maximum the cell is. */
-int sqdet_maxpool_nhwc_bwd(const float* x, const float* dy, float* dx, int n, int h, int w, int c, int k, int stride,
-                           int pad_mode, sqdet_stream_t stream);
+int sqdet_maxpool_nhwc_bwd(const void* x, const void* dy, void* dx, int n, int h, int w, int c, int k, int stride,
+                           int pad_mode, int dtype, sqdet_stream_t stream);
 
 /* Loss forward + backward.  Inputs as the reference's placeholders (nn_skeleton.py:86-97):
  * input_mask [B,A], box_delta_input [B,A,4], box_input [B,A,4] (cx,cy,w,h), labels [B,A,C];
@@ -218,14 +227,17 @@ int sqdet_loss_fwd_bwd(const float* preds, const float* anchors, const float* in
  * Variable v = elements [offsets[v], +counts[v]); decays[v] = weight decay added to its gradient
  * BEFORE clipping (0 for biases).  step: g = g*grad_scale (1/world_size after a SUM all-reduce) + decay*w; g *= max_norm/max(||g||,max_norm);
  * accum = momentum*accum + g; w -= lr*accum.  Deterministic (fixed-order norm reduction), so
- * data-parallel replicas stay bit-identical. */
+ * data-parallel replicas stay bit-identical.  found_inf (device int32, may be NULL): set to 1 when any
+ * variable's gradient norm is inf / NaN -- the step is then skipped entirely (params and accum untouched;
+ * the overflow case of loss-scaled float16 training) -- else 0. */
 typedef struct sqdet_optimizer sqdet_optimizer_t;
 int sqdet_optimizer_create(sqdet_optimizer_t** out, const long* offsets, const long* counts, const float* decays,
                            int nvars);
 void sqdet_optimizer_destroy(sqdet_optimizer_t* opt);
 size_t sqdet_optimizer_workspace_bytes(const sqdet_optimizer_t* opt);
 int sqdet_optimizer_step(sqdet_optimizer_t* opt, float* params, float* grads, float* accum, void* workspace, float lr,
-                         float momentum, float max_grad_norm, float grad_scale, sqdet_stream_t stream);
+                         float momentum, float max_grad_norm, float grad_scale, int32_t* found_inf,
+                         sqdet_stream_t stream);
 
 /* ------------------------------------------------------------- network --
  * Replaces SqueezeDet.__init__/_add_forward_graph (nets/squeezeDet.py:19-79,

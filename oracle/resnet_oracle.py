@@ -159,17 +159,38 @@ def trainable_names(params):
     return out
 
 
-def forward_train(params, x, dropout_mask, keep_prob=0.5):
+def forward_train(params, x, dropout_mask, keep_prob=0.5, storage="fp32", override=None):
+    """storage="fp16" restates the device's mixed-precision step (train_oracle._q): the batch norm is folded into
+    the kernel in float32, the FOLDED kernel and every stored activation are rounded to float16, the folded bias,
+    the accumulation and the residual add stay float32 (the add is the conv's epilogue on the device)."""
     from . import train_oracle as TO
+    q = lambda t: TO._q(t, storage)
 
-    def cbn(t, name, stride, relu, with_bias):
+    def ov(name, t):
+        """override (train_oracle.forward_train): pin the forward value of a stored activation -- names: the
+        _conv_bn_layer's parameter prefix, "res<block>" (a block's output), "drop4", "conv5"."""
+        if override is not None and name in override:
+            v = override[name].to(torch.float32)
+            assert v.shape == t.shape, name
+            return t + (v - t).detach()
+        return t
+
+    def cbn(t, name, stride, relu, with_bias, rounded=True):
+        return ov(name, cbn_(t, name, stride, relu, with_bias, rounded)) if rounded else cbn_(t, name, stride, relu, with_bias, rounded)
+
+    def cbn_(t, name, stride, relu, with_bias, rounded=True):
         P = params
-        y = TO._conv(t, P[name + "/kernels"], P[name + "/biases"] if with_bias else torch.zeros_like(P[name + "/mean"]), stride, "SAME", False)
         inv = torch.rsqrt(P[name + "/var"] + BN_EPS) * P[name + "/gamma"]
+        if storage == "fp16":
+            bias = P[name + "/beta"] - P[name + "/mean"] * inv + (P[name + "/biases"] * inv if with_bias else 0.0)
+            y = TO._conv(t, P[name + "/kernels"] * inv.view(1, 1, 1, -1), bias, stride, "SAME", False, storage if rounded else "fp16w")
+            y = torch.relu(y) if relu else y
+            return q(y) if rounded else y
+        y = TO._conv(t, P[name + "/kernels"], P[name + "/biases"] if with_bias else torch.zeros_like(P[name + "/mean"]), stride, "SAME", False)
         y = y * inv + (P[name + "/beta"] - P[name + "/mean"] * inv)
         return torch.relu(y) if relu else y
 
-    t = cbn(x, "conv1", 2, True, True)
+    t = cbn(q(x), "conv1", 2, True, True)
     t = so.pooling_layer(t, 3, 2, "VALID")
     for scope, blocks, in_f, out_f in STAGES:
         for i, n in enumerate(blocks):
@@ -179,18 +200,18 @@ def forward_train(params, x, dropout_mask, keep_prob=0.5):
             b2 = blk + "res%s_branch2/res%s" % (n, n)
             u = cbn(t, b2 + "_branch2a", stride, True, False)
             u = cbn(u, b2 + "_branch2b", 1, True, False)
-            u = cbn(u, b2 + "_branch2c", 1, False, False)
-            t = torch.relu(shortcut + u)
-    t = t * dropout_mask / keep_prob                       # drop4 (resnet50_convDet.py:126)
-    return TO._conv(t, params["conv5/kernels"], params["conv5/biases"], 1, "SAME", False)
+            u = cbn(u, b2 + "_branch2c", 1, False, False, rounded=False)
+            t = ov("res" + n, q(torch.relu(shortcut + u)))
+    t = ov("drop4", q(t * dropout_mask / keep_prob))       # drop4 (resnet50_convDet.py:126)
+    return ov("conv5", TO._conv(t, params["conv5/kernels"], params["conv5/biases"], 1, "SAME", False, storage))
 
 
-def loss_and_grads(mc, params, x, dropout_mask, input_mask, box_delta_input, box_input, labels):
+def loss_and_grads(mc, params, x, dropout_mask, input_mask, box_delta_input, box_input, labels, storage="fp32", override=None):
     """Total loss (incl. weight decay on the trainable kernels) and its gradient w.r.t. every trainable variable."""
     from . import train_oracle as TO
     names = trainable_names(params)
     p = {k: v.clone().requires_grad_(k in names) for k, v in params.items()}
-    preds = forward_train(p, x, dropout_mask, 0.5)
+    preds = forward_train(p, x, dropout_mask, 0.5, storage, override)
     parts = TO.loss_graph(mc, preds, input_mask, box_delta_input, box_input, labels)
     wd = sum(mc.WEIGHT_DECAY * (p[k] ** 2).sum() / 2 for k in names if k.endswith("/kernels"))
     main = parts["class_loss"] + parts["conf_loss"] + parts["bbox_loss"]

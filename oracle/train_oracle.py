@@ -81,7 +81,17 @@ def synthetic_labels(mc, batch, seed=0):
 # --------------------------------------------------------------------------
 # differentiable forward graph (training mode)
 # --------------------------------------------------------------------------
-def _conv(x, w_hwio, b, stride, padding, relu):
+def _q(t, storage):
+    """storage == "fp16": the value rounded to float16 (what a mixed-precision kernel stores), with a straight-through
+    gradient -- so ReLU / max-pool decisions are made on the float16 values the device sees while the weight
+    gradients stay float32, as in the device's mixed-precision step."""
+    if storage != "fp16":
+        return t
+    return t + (t.to(torch.float16).to(torch.float32) - t).detach()
+
+
+def _conv(x, w_hwio, b, stride, padding, relu, storage="fp32"):
+    w_hwio = _q(w_hwio, "fp16" if storage == "fp16w" else storage)   # "fp16w": float16 kernel, float32 result
     k = w_hwio.shape[0]
     H, W = x.shape[1], x.shape[2]
     xn = x.permute(0, 3, 1, 2)
@@ -92,25 +102,37 @@ def _conv(x, w_hwio, b, stride, padding, relu):
     y = F.conv2d(xn, w_hwio.permute(3, 2, 0, 1), None, stride=stride) + b.view(1, -1, 1, 1)
     if relu:
         y = torch.relu(y)
-    return y.permute(0, 2, 3, 1)
+    return _q(y.permute(0, 2, 3, 1), storage)
 
 
-def forward_train(arch, params, x, dropout_mask, keep_prob=0.5):
-    """_add_forward_graph with IS_TRAINING=True: dropout (nets/squeezeDet.py:74) active."""
-    t = x
+def forward_train(arch, params, x, dropout_mask, keep_prob=0.5, storage="fp32", override=None):
+    """_add_forward_graph with IS_TRAINING=True: dropout (nets/squeezeDet.py:74) active.  storage="fp16" restates
+    the device's mixed-precision step: input, kernels and every stored activation rounded to float16 (float32
+    accumulation and biases), see _q.  override: {name: tensor} -- the forward VALUE of that stored activation is
+    replaced by the given tensor (straight-through, like _q), e.g. by the activations a device run kept: every ReLU /
+    max-pool decision of the backward pass is then made on exactly the device's values, which isolates the backward
+    arithmetic from the 1-ulp forward differences that float16 storage amplifies from layer to layer.  Names: conv /
+    pool layer names, "<fire>/squeeze1x1", "<fire>" (the concat), "drop" (conv12's input)."""
+    def ov(name, t):
+        if override is not None and name in override:
+            v = override[name].to(torch.float32)
+            assert v.shape == t.shape, name
+            return t + (v - t).detach()
+        return t
+    t = _q(x, storage)
     specs = O.layer_specs(arch)
     for kind, name, a in specs:
         if name == "conv12":
-            t = t * dropout_mask / keep_prob
+            t = ov("drop", _q(t * dropout_mask / keep_prob, storage))
         if kind == "conv":
-            t = _conv(t, params[name + "/kernels"], params[name + "/biases"], a["stride"], a["padding"], a["relu"])
+            t = ov(name, _conv(t, params[name + "/kernels"], params[name + "/biases"], a["stride"], a["padding"], a["relu"], storage))
         elif kind == "pool":
-            t = O.pooling_layer(t, a["size"], a["stride"], a["padding"])
+            t = ov(name, O.pooling_layer(t, a["size"], a["stride"], a["padding"]))
         else:
-            sq = _conv(t, params[name + "/squeeze1x1/kernels"], params[name + "/squeeze1x1/biases"], 1, "SAME", True)
-            e1 = _conv(sq, params[name + "/expand1x1/kernels"], params[name + "/expand1x1/biases"], 1, "SAME", True)
-            e3 = _conv(sq, params[name + "/expand3x3/kernels"], params[name + "/expand3x3/biases"], 1, "SAME", True)
-            t = torch.cat([e1, e3], dim=3)
+            sq = ov(name + "/squeeze1x1", _conv(t, params[name + "/squeeze1x1/kernels"], params[name + "/squeeze1x1/biases"], 1, "SAME", True, storage))
+            e1 = _conv(sq, params[name + "/expand1x1/kernels"], params[name + "/expand1x1/biases"], 1, "SAME", True, storage)
+            e3 = _conv(sq, params[name + "/expand3x3/kernels"], params[name + "/expand3x3/biases"], 1, "SAME", True, storage)
+            t = ov(name, torch.cat([e1, e3], dim=3))
     return t
 
 
@@ -159,10 +181,11 @@ def trainable_names(arch, params):
     return [n for n in params if not n.startswith("conv1/")]
 
 
-def loss_and_grads(arch, mc, params, x, dropout_mask, input_mask, box_delta_input, box_input, labels):
+def loss_and_grads(arch, mc, params, x, dropout_mask, input_mask, box_delta_input, box_input, labels, storage="fp32",
+                   override=None):
     """Total loss (incl. weight decay) and its gradient w.r.t. every trainable variable."""
     p = {k: v.clone().requires_grad_(k in trainable_names(arch, params)) for k, v in params.items()}
-    preds = forward_train(arch, p, x, dropout_mask, 0.5 if mc.IS_TRAINING else 1.0)
+    preds = forward_train(arch, p, x, dropout_mask, 0.5 if mc.IS_TRAINING else 1.0, storage, override)
     parts = loss_graph(mc, preds, input_mask, box_delta_input, box_input, labels)
     wd = sum(mc.WEIGHT_DECAY * (p[k] ** 2).sum() / 2 for k in trainable_names(arch, params) if k.endswith("/kernels"))
     loss = parts["class_loss"] + parts["conf_loss"] + parts["bbox_loss"] + wd

@@ -37,16 +37,17 @@ SIGNATURES = {
     "sqdet_conv_pack_weights_bwd_data": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "sqdet_conv2d_nhwc_bwd_data": (ci, [vp, vp, vp] + [ci] * 10 + [vp]),
     "sqdet_conv2d_bwd_filter_workspace_bytes": (sz, [ci] * 6),
-    "sqdet_conv2d_nhwc_bwd_filter": (ci, [vp, vp, vp, vp, vp, cf, vp] + [ci] * 10 + [vp]),
-    "sqdet_relu_bwd": (ci, [vp, vp, sz, vp]),
-    "sqdet_scale_mask": (ci, [vp, vp, vp, cf, sz, vp]),
-    "sqdet_maxpool_nhwc_bwd": (ci, [vp, vp, vp] + [ci] * 7 + [vp]),
+    "sqdet_conv2d_nhwc_bwd_filter": (ci, [vp, vp, vp, vp, vp, cf, cf, vp] + [ci] * 11 + [vp]),
+    "sqdet_relu_bwd": (ci, [vp, vp, sz, ci, vp]),
+    "sqdet_convert_scale": (ci, [vp, ci, vp, ci, cf, sz, vp]),
+    "sqdet_scale_mask": (ci, [vp, vp, vp, cf, sz, ci, vp]),
+    "sqdet_maxpool_nhwc_bwd": (ci, [vp, vp, vp] + [ci] * 8 + [vp]),
     "sqdet_loss_workspace_bytes": (sz, []),
     "sqdet_loss_fwd_bwd": (ci, [vp] * 10 + [ci] * 5 + [cf] * 9 + [vp]),
     "sqdet_optimizer_create": (ci, [C.POINTER(vp), C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(cf), ci]),
     "sqdet_optimizer_destroy": (None, [vp]),
     "sqdet_optimizer_workspace_bytes": (sz, [vp]),
-    "sqdet_optimizer_step": (ci, [vp, vp, vp, vp, vp, cf, cf, cf, cf, vp]),
+    "sqdet_optimizer_step": (ci, [vp, vp, vp, vp, vp, cf, cf, cf, cf, vp, vp]),
     "sqdet_net_create": (ci, [C.POINTER(vp), ci, ci, ci, ci, ci, ci, ci]),
     "sqdet_net_destroy": (None, [vp]),
     "sqdet_net_num_params": (ci, [vp]),

@@ -59,71 +59,102 @@ __global__ void slab_reduce_kernel(const float* __restrict__ partial, float* __r
 }
 
 // ------------------------------------------------------------------ elementwise backward ops
-__global__ void relu_bwd_kernel(const float* __restrict__ y, float* __restrict__ dy, size_t n4) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
-    f32x4 g = reinterpret_cast<f32x4*>(dy)[i];
-    g[0] = v[0] > 0.f ? g[0] : 0.f; g[1] = v[1] > 0.f ? g[1] : 0.f;
-    g[2] = v[2] > 0.f ? g[2] : 0.f; g[3] = v[3] > 0.f ? g[3] : 0.f;
-    reinterpret_cast<f32x4*>(dy)[i] = g;
+// (float32, or float16 for mixed-precision training; 16-byte vectors of EV elements)
+template <typename T> struct Vec16 { typedef T type __attribute__((ext_vector_type(16 / sizeof(T)))); };
+
+template <typename T>
+__global__ void relu_bwd_kernel(const T* __restrict__ y, T* __restrict__ dy, size_t nv) {
+  typedef typename Vec16<T>::type V;
+  constexpr int EV = 16 / sizeof(T);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+    const V v = reinterpret_cast<const V*>(y)[i];
+    V g = reinterpret_cast<V*>(dy)[i];
+#pragma unroll
+    for (int e = 0; e < EV; ++e) g[e] = v[e] > (T)0 ? g[e] : (T)0;
+    reinterpret_cast<V*>(dy)[i] = g;
   }
 }
 
 // y = x * mask * scale  (tf.nn.dropout forward with mask = floor(keep_prob + U), scale = 1/keep_prob; and its backward)
-__global__ void scale_mask_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ y,
-                                  float scale, size_t n4) {
+template <typename T>
+__global__ void scale_mask_kernel(const T* __restrict__ x, const T* __restrict__ mask, T* __restrict__ y, float scale, size_t nv) {
+  typedef typename Vec16<T>::type V;
+  constexpr int EV = 16 / sizeof(T);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+    const V v = reinterpret_cast<const V*>(x)[i];
+    const V m = reinterpret_cast<const V*>(mask)[i];
+    V o;
+#pragma unroll
+    for (int e = 0; e < EV; ++e) o[e] = (T)((float)v[e] * (float)m[e] * scale);
+    reinterpret_cast<V*>(y)[i] = o;
+  }
+}
+
+// dst = (D)(src * scale): the float16 <-> float32 hand-offs of mixed-precision training (preds -> loss, dpreds * loss_scale)
+template <typename S, typename D>
+__global__ void convert_scale_kernel(const S* __restrict__ src, D* __restrict__ dst, float scale, size_t n4) {
+  typedef S SV __attribute__((ext_vector_type(4)));
+  typedef D DV __attribute__((ext_vector_type(4)));
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-    const f32x4 m = reinterpret_cast<const f32x4*>(mask)[i];
-    f32x4 o;
-    o[0] = v[0] * m[0] * scale; o[1] = v[1] * m[1] * scale; o[2] = v[2] * m[2] * scale; o[3] = v[3] * m[3] * scale;
-    reinterpret_cast<f32x4*>(y)[i] = o;
+    const SV v = reinterpret_cast<const SV*>(src)[i];
+    DV o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (D)((float)v[e] * scale);
+    reinterpret_cast<DV*>(dst)[i] = o;
   }
 }
 
 // max-pool backward, gather form (deterministic): an input cell receives dy of every window whose
 // FIRST maximum (row-major scan, as tf.nn.max_pool's argmax) it is.
-__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                    int N, int H, int W, int C, int k, int stride, int pt, int pl, int Ho, int Wo) {
-  const int c4n = C / 4;
-  const size_t total = (size_t)N * H * W * c4n;
+  typedef typename Vec16<T>::type V;
+  constexpr int EV = 16 / sizeof(T);
+  const int cvn = C / EV;
+  const size_t total = (size_t)N * H * W * cvn;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int c4 = (int)(idx % c4n);
-    size_t p = idx / c4n;
+    const int cv = (int)(idx % cvn);
+    size_t p = idx / cvn;
     const int ix = (int)(p % W); p /= W;
     const int iy = (int)(p % H);
     const int n = (int)(p / H);
-    const f32x4 me = *reinterpret_cast<const f32x4*>(x + idx * 4);
-    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    float g[EV];
+#pragma unroll
+    for (int e = 0; e < EV; ++e) g[e] = 0.f;
     // windows (oy, ox) containing (iy, ix): oy*stride - pt <= iy <= oy*stride - pt + k - 1
     const int oy_hi = (iy + pt) / stride, ox_hi = (ix + pl) / stride;
     for (int oy = oy_hi; oy >= 0 && oy * stride - pt + k - 1 >= iy; --oy) {
       if (oy >= Ho) continue;
       for (int ox = ox_hi; ox >= 0 && ox * stride - pl + k - 1 >= ix; --ox) {
         if (ox >= Wo) continue;
-        // first argmax of the window, per channel
-        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        int by[4] = {-1, -1, -1, -1}, bx[4] = {-1, -1, -1, -1};
+        // first argmax of the window, per channel: position code yy * W + xx
+        float best[EV];
+        int bpos[EV];
+#pragma unroll
+        for (int e = 0; e < EV; ++e) { best[e] = -INFINITY; bpos[e] = -1; }
         for (int dy_ = 0; dy_ < k; ++dy_) {
           const int yy = oy * stride - pt + dy_;
           if (yy < 0 || yy >= H) continue;
           for (int dx_ = 0; dx_ < k; ++dx_) {
             const int xx = ox * stride - pl + dx_;
             if (xx < 0 || xx >= W) continue;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((((size_t)n * H + yy) * W + xx) * C + c4 * 4));
+            const V v = *reinterpret_cast<const V*>(x + ((((size_t)n * H + yy) * W + xx) * C + cv * EV));
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (v[e] > best[e]) { best[e] = v[e]; by[e] = yy; bx[e] = xx; }
+            for (int e = 0; e < EV; ++e)
+              if ((float)v[e] > best[e]) { best[e] = (float)v[e]; bpos[e] = yy * W + xx; }
           }
         }
-        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + ((((size_t)n * Ho + oy) * Wo + ox) * C + c4 * 4));
+        const V d = *reinterpret_cast<const V*>(dy + ((((size_t)n * Ho + oy) * Wo + ox) * C + cv * EV));
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (by[e] == iy && bx[e] == ix) g[e] += d[e];
+        for (int e = 0; e < EV; ++e)
+          if (bpos[e] == iy * W + ix) g[e] += (float)d[e];
       }
     }
-    (void)me;
-    *reinterpret_cast<f32x4*>(dx + idx * 4) = g;
+    V o;
+#pragma unroll
+    for (int e = 0; e < EV; ++e) o[e] = (T)g[e];
+    *reinterpret_cast<V*>(dx + idx * EV) = o;
   }
 }
 
@@ -257,20 +288,30 @@ __global__ __launch_bounds__(256) void opt_sumsq_kernel(const OptSeg* __restrict
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+// one block: per-variable clip factors + the overflow flag of mixed-precision training (a non-finite gradient norm in
+// ANY variable: flag[0] = 1 and the apply kernel leaves every parameter and momentum untouched)
 __global__ void opt_norm_kernel(const OptSeg* __restrict__ segs, const double* __restrict__ partial, float* __restrict__ scale,
-                                int nvars, float max_norm) {
-  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nvars; v += gridDim.x * blockDim.x) {
+                                int nvars, float max_norm, int* __restrict__ flag, int* __restrict__ found_inf) {
+  int bad = 0;
+  for (int v = threadIdx.x; v < nvars; v += blockDim.x) {
     double s = 0.0;
     for (int b = 0; b < segs[v].nblocks; ++b) s += partial[segs[v].first_block + b];
     const float nrm = (float)sqrt(s);
+    if (!(nrm <= 3.0e38f)) bad = 1;               // inf or NaN
     scale[v] = max_norm / fmaxf(nrm, max_norm);   // tf.clip_by_norm: g * clip / max(||g||, clip)
+  }
+  bad = __syncthreads_or(bad);
+  if (threadIdx.x == 0) {
+    flag[0] = bad;
+    if (found_inf) found_inf[0] = bad;
   }
 }
 
 __global__ __launch_bounds__(256) void opt_apply_kernel(const OptSeg* __restrict__ segs, const int* __restrict__ block_seg,
                                                         float* __restrict__ w, const float* __restrict__ g,
                                                         float* __restrict__ accum, const float* __restrict__ scale,
-                                                        float lr, float momentum) {
+                                                        float lr, float momentum, const int* __restrict__ flag) {
+  if (flag[0]) return;   // overflowed step: skipped
   const int v = block_seg[blockIdx.x];
   const OptSeg s = segs[v];
   const int lb = blockIdx.x - s.first_block;
@@ -320,31 +361,68 @@ extern "C" int sqdet_conv2d_nhwc_bwd_data(const void* dy, const void* w_packed_b
                           dy_cstride, dy_coffset, accumulate, as_stream(stream));
 }
 
-extern "C" int sqdet_relu_bwd(const float* y, float* dy_inout, size_t count, sqdet_stream_t stream) {
-  SQDET_REQUIRE(y && dy_inout && count % 4 == 0, "relu_bwd: bad arguments (count must be a multiple of 4)");
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(count / 4, 8192)), dim3(256), 0, as_stream(stream), y, dy_inout, count / 4);
+extern "C" int sqdet_relu_bwd(const void* y, void* dy_inout, size_t count, int dtype, sqdet_stream_t stream) {
+  SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "relu_bwd: bad dtype");
+  const size_t ev = 16 / dtype_size(dtype);
+  SQDET_REQUIRE(y && dy_inout && count % ev == 0, "relu_bwd: bad arguments (count must be a multiple of 16 bytes)");
+  const dim3 grid(grid_for(count / ev, 8192));
+  if (dtype == SQDET_F16)
+    hipLaunchKernelGGL(relu_bwd_kernel<f16>, grid, dim3(256), 0, as_stream(stream), (const f16*)y, (f16*)dy_inout, count / ev);
+  else
+    hipLaunchKernelGGL(relu_bwd_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)y, (float*)dy_inout, count / ev);
   SQDET_CHECK_HIP(hipGetLastError());
   return SQDET_OK;
 }
 
-extern "C" int sqdet_scale_mask(const float* x, const float* mask, float* y, float scale, size_t count,
+extern "C" int sqdet_scale_mask(const void* x, const void* mask, void* y, float scale, size_t count, int dtype,
                                 sqdet_stream_t stream) {
-  SQDET_REQUIRE(x && mask && y && count % 4 == 0, "scale_mask: bad arguments (count must be a multiple of 4)");
-  hipLaunchKernelGGL(scale_mask_kernel, dim3(grid_for(count / 4, 8192)), dim3(256), 0, as_stream(stream), x, mask, y, scale,
-                     count / 4);
+  SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "scale_mask: bad dtype");
+  const size_t ev = 16 / dtype_size(dtype);
+  SQDET_REQUIRE(x && mask && y && count % ev == 0, "scale_mask: bad arguments (count must be a multiple of 16 bytes)");
+  const dim3 grid(grid_for(count / ev, 8192));
+  if (dtype == SQDET_F16)
+    hipLaunchKernelGGL(scale_mask_kernel<f16>, grid, dim3(256), 0, as_stream(stream), (const f16*)x, (const f16*)mask, (f16*)y, scale, count / ev);
+  else
+    hipLaunchKernelGGL(scale_mask_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)mask, (float*)y, scale, count / ev);
   SQDET_CHECK_HIP(hipGetLastError());
   return SQDET_OK;
 }
 
-extern "C" int sqdet_maxpool_nhwc_bwd(const float* x, const float* dy, float* dx, int n, int h, int w, int c, int k,
-                                      int stride, int pad_mode, sqdet_stream_t stream) {
-  SQDET_REQUIRE(x && dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && k > 0 && stride > 0,
+extern "C" int sqdet_convert_scale(const void* src, int src_dtype, void* dst, int dst_dtype, float scale, size_t count,
+                                   sqdet_stream_t stream) {
+  SQDET_REQUIRE(src && dst && count % 4 == 0, "convert_scale: bad arguments (count must be a multiple of 4)");
+  SQDET_REQUIRE((src_dtype == SQDET_F16 || src_dtype == SQDET_F32) && (dst_dtype == SQDET_F16 || dst_dtype == SQDET_F32),
+                "convert_scale: bad dtype");
+  const dim3 grid(grid_for(count / 4, 8192));
+  hipStream_t st = as_stream(stream);
+  if (src_dtype == SQDET_F16 && dst_dtype == SQDET_F32)
+    hipLaunchKernelGGL((convert_scale_kernel<f16, float>), grid, dim3(256), 0, st, (const f16*)src, (float*)dst, scale, count / 4);
+  else if (src_dtype == SQDET_F32 && dst_dtype == SQDET_F16)
+    hipLaunchKernelGGL((convert_scale_kernel<float, f16>), grid, dim3(256), 0, st, (const float*)src, (f16*)dst, scale, count / 4);
+  else if (src_dtype == SQDET_F32)
+    hipLaunchKernelGGL((convert_scale_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, scale, count / 4);
+  else
+    hipLaunchKernelGGL((convert_scale_kernel<f16, f16>), grid, dim3(256), 0, st, (const f16*)src, (f16*)dst, scale, count / 4);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_maxpool_nhwc_bwd(const void* x, const void* dy, void* dx, int n, int h, int w, int c, int k,
+                                      int stride, int pad_mode, int dtype, sqdet_stream_t stream) {
+  SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "maxpool_bwd: bad dtype");
+  const int ev = 16 / (int)dtype_size(dtype);
+  SQDET_REQUIRE(x && dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && c % ev == 0 && k > 0 && stride > 0,
                 "maxpool_bwd: bad arguments");
   const int Ho = out_size(h, k, stride, pad_mode), Wo = out_size(w, k, stride, pad_mode);
   const int pt = pad_before(h, k, stride, pad_mode), pl = pad_before(w, k, stride, pad_mode);
-  const size_t total = (size_t)n * h * w * (c / 4);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, as_stream(stream), x, dy, dx, n, h, w, c,
-                     k, stride, pt, pl, Ho, Wo);
+  const size_t total = (size_t)n * h * w * (c / ev);
+  const dim3 grid(grid_for(total, 16384));
+  if (dtype == SQDET_F16)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<f16>, grid, dim3(256), 0, as_stream(stream), (const f16*)x, (const f16*)dy, (f16*)dx,
+                       n, h, w, c, k, stride, pt, pl, Ho, Wo);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy,
+                       (float*)dx, n, h, w, c, k, stride, pt, pl, Ho, Wo);
   SQDET_CHECK_HIP(hipGetLastError());
   return SQDET_OK;
 }
@@ -420,7 +498,7 @@ extern "C" size_t sqdet_optimizer_workspace_bytes(const sqdet_optimizer* o) {
 }
 
 extern "C" int sqdet_optimizer_step(sqdet_optimizer* o, float* params, float* grads, float* accum, void* workspace,
-                                    float lr, float momentum, float max_grad_norm, float grad_scale,
+                                    float lr, float momentum, float max_grad_norm, float grad_scale, int32_t* found_inf,
                                     sqdet_stream_t stream) {
   SQDET_REQUIRE(o && params && grads && accum && workspace, "optimizer_step: null pointer");
   hipStream_t st = as_stream(stream);
@@ -437,10 +515,12 @@ extern "C" int sqdet_optimizer_step(sqdet_optimizer* o, float* params, float* gr
   SQDET_CHECK_HIP(hipMemcpyAsync(d_bs, o->block_seg.data(), o->block_seg.size() * sizeof(int), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(opt_sumsq_kernel, dim3(o->nblocks), dim3(256), 0, st, d_segs, d_bs, params, grads, d_part, grad_scale);
   SQDET_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(opt_norm_kernel, dim3(1), dim3(256), 0, st, d_segs, d_part, d_scale, (int)o->segs.size(), max_grad_norm);
+  int* d_flag = reinterpret_cast<int*>(d_scale + o->segs.size());
+  hipLaunchKernelGGL(opt_norm_kernel, dim3(1), dim3(256), 0, st, d_segs, d_part, d_scale, (int)o->segs.size(), max_grad_norm,
+                     d_flag, found_inf);
   SQDET_CHECK_HIP(hipGetLastError());
   hipLaunchKernelGGL(opt_apply_kernel, dim3(o->nblocks), dim3(256), 0, st, d_segs, d_bs, params, grads, accum, d_scale, lr,
-                     momentum);
+                     momentum, d_flag);
   SQDET_CHECK_HIP(hipGetLastError());
   return SQDET_OK;
 }

@@ -1,18 +1,23 @@
-// Conv backward-filter (+ bias gradient) for gfx950, float32 (the reference's training dtype):
+// Conv backward-filter (+ bias gradient) for gfx950:
 //   dW[ty][tx][ci][co] = sum_p X[p @ (ty,tx)][ci] * dY[p][co]        (stride-1 SAME convs, k = 1 or 3)
 //   dbias[co]          = sum_p dY[p][co]
 // (the gradients tf.gradients produces for tf.nn.conv2d + tf.nn.bias_add, nn_skeleton.py:539-542, which
-// ModelSkeleton._add_train_graph feeds to the optimizer, nn_skeleton.py:343-349).
+// ModelSkeleton._add_train_graph feeds to the optimizer, nn_skeleton.py:343-349).  X / dY are float32 (the
+// reference's training dtype; exact-f32 MFMA v_mfma_f32_16x16x4_f32) or float16 (mixed-precision training;
+// v_mfma_f32_16x16x32_f16); dW / dbias are always accumulated and written in float32.
 //
-// A GEMM with M = ci, N = co and K = pixels on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32).  One workgroup owns a
-// (ci tile) x (co tile) block of dW for ALL the taps of its tap group (1 tap of a 1x1, one kernel row or all nine taps
-// of a 3x3), so X and dY are read once per tap group instead of once per tap.  K is walked in stages of 4 rows x 16
-// columns of one image: the stage's dY tile and X tile (with the 1-pixel halo the taps need; TF SAME zero padding by
-// out-of-range buffer loads, which return zeros) go global -> registers -> LDS one stage ahead of the MFMAs, and every
-// tap's A fragment is the same LDS image read at a shifted pixel offset.  blockIdx.z owns every ksplit-th stage and
-// writes a partial slab; slab_reduce2 sums the slabs in a fixed order, so the result is deterministic (no atomics).
-// The bias gradient rides along as one more MFMA per k-step with an all-ones A operand (row 0 of the product is the
-// column sum of dY), in the waves that own ci tile 0.
+// A GEMM with M = ci, N = co and K = pixels.  One workgroup owns a (ci tile) x (co tile) block of dW for ALL the taps
+// of its tap group (1 tap of a 1x1, one kernel row or all nine taps of a 3x3), so X and dY are read once per tap group
+// instead of once per tap.  K is walked in stages of 4 rows x 16 columns of one image: the stage's dY tile and X tile
+// (with the 1-pixel halo the taps need; TF SAME zero padding by out-of-range buffer loads, which return zeros) go
+// global -> registers -> LDS one stage ahead of the MFMAs, and every tap's A fragment is the same LDS image read at a
+// shifted pixel offset.  Both operands are K-major in the MFMA (a lane holds consecutive PIXELS of one channel) while
+// the LDS image is [pixel][channel] as it arrives from HBM: float32 reads one element per lane (ds_read_b32), float16
+// uses the gfx950 transpose read (ds_read_b64_tr_b16: a 16-lane group fetches a [4 pixels][16 channels] block and each
+// lane receives one channel's 4 pixels).  blockIdx.z owns every ksplit-th stage and writes a partial slab;
+// slab_reduce2 sums the slabs in a fixed order, so the result is deterministic (no atomics).  The bias gradient rides
+// along as one more MFMA per k-step with an all-ones A operand (row 0 of the product is the column sum of dY), in the
+// waves that own ci tile 0.
 #include <type_traits>
 
 #include "conv_common.h"
@@ -20,8 +25,8 @@
 namespace sqdet {
 
 struct WgArgs {
-  const float* x;
-  const float* dy;
+  const void* x;
+  const void* dy;
   float* partial;
   int H, W, Cin, Cout, k;
   int x_cstride, x_coffset, dy_cstride, dy_coffset;
@@ -31,21 +36,25 @@ struct WgArgs {
 };
 
 constexpr unsigned kOOB = 0xfffffff0u;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int MT, int NT, int WM, int TAPS>
+template <typename T, int MT, int NT, int WM, int TAPS>
 __global__ __launch_bounds__(256, 2) void wgrad_tile(WgArgs a) {
+  constexpr bool HALF = sizeof(T) == 2;
+  constexpr int EV = 16 / sizeof(T);               // elements per 16-byte load
+  constexpr int KSTEPS = HALF ? 2 : 16;            // MFMA k-steps per 64-pixel stage (K = 32 / 4 pixels)
   constexpr int WN = 4 / WM;
   constexpr int MTILE = WM * MT * 16, NTILE = WN * NT * 16;
-  constexpr int M4 = MTILE / 4, N4 = NTILE / 4;
+  constexpr int MV = MTILE / EV, NV = NTILE / EV;
   constexpr int HR = TAPS == 9 ? 6 : 4, HC = TAPS == 1 ? 16 : 18;
-  // row pitches (floats) that are odd multiples of 16: the four k rows one ds_read_b32 touches land in disjoint banks
+  // row pitches (elements) that are odd multiples of 16: the pixel rows one LDS read touches land in disjoint banks
   constexpr int XS = ((MTILE / 16) & 1) ? MTILE : MTILE + 16;
   constexpr int DS = ((NTILE / 16) & 1) ? NTILE : NTILE + 16;
-  constexpr int XN = HR * HC * M4, DN = 64 * N4;
+  constexpr int XN = HR * HC * MV, DN = 64 * NV;
   constexpr int NXL = (XN + 255) / 256, NDL = (DN + 255) / 256;
   constexpr int TY = TAPS == 9 ? 3 : 1, TX = TAPS == 1 ? 1 : 3;
-  __shared__ float xs[HR * HC * XS];
-  __shared__ float dsm[64 * DS];
+  __shared__ __attribute__((aligned(16))) T xs[HR * HC * XS];
+  __shared__ __attribute__((aligned(16))) T dsm[64 * DS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
@@ -56,8 +65,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile(WgArgs a) {
   const int py = TAPS == 9 ? 1 : (TAPS == 3 ? 1 - tg : 0), px = TAPS == 1 ? 0 : 1;
   const bool bias_wave = a.do_bias && ci_tile == 0 && tg == 0 && wm == 0;
 
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dy_bytes, 0x00020000);
 
   f32x4 acc[TAPS][MT][NT], accb[NT];
 #pragma unroll
@@ -78,20 +87,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile(WgArgs a) {
 #pragma unroll
     for (int j = 0; j < NXL; ++j) {
       const int idx = tid + 256 * j;
-      const int pix = idx / M4, c4 = idx - pix * M4;
+      const int pix = idx / MV, cv = idx - pix * MV;
       const int hr = pix / HC, hc = pix - hr * HC;
-      const int iy = y0 + hr - py, ix = x0 + hc - px, ci = ci0 + 4 * c4;
+      const int iy = y0 + hr - py, ix = x0 + hc - px, ci = ci0 + EV * cv;
       const bool ok = idx < XN && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && ci < a.Cin;
-      const unsigned off = ((unsigned)((n * a.H + iy) * a.W + ix) * (unsigned)a.x_cstride + (unsigned)(a.x_coffset + ci)) * 4u;
+      const unsigned off = ((unsigned)((n * a.H + iy) * a.W + ix) * (unsigned)a.x_cstride + (unsigned)(a.x_coffset + ci)) * (unsigned)sizeof(T);
       xr[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : kOOB, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < NDL; ++j) {
       const int idx = tid + 256 * j;
-      const int pp = idx / N4, c4 = idx - pp * N4;
-      const int y = y0 + (pp >> 4), xx = x0 + (pp & 15), co = co0 + 4 * c4;
+      const int pp = idx / NV, cv = idx - pp * NV;
+      const int y = y0 + (pp >> 4), xx = x0 + (pp & 15), co = co0 + EV * cv;
       const bool ok = idx < DN && y < a.H && xx < a.W && co < a.Cout;
-      const unsigned off = ((unsigned)((n * a.H + y) * a.W + xx) * (unsigned)a.dy_cstride + (unsigned)(a.dy_coffset + co)) * 4u;
+      const unsigned off = ((unsigned)((n * a.H + y) * a.W + xx) * (unsigned)a.dy_cstride + (unsigned)(a.dy_coffset + co)) * (unsigned)sizeof(T);
       dr[j] = __builtin_amdgcn_raw_buffer_load_b128(rd, ok ? off : kOOB, 0, 0);
     }
   };
@@ -99,61 +108,94 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile(WgArgs a) {
 #pragma unroll
     for (int j = 0; j < NXL; ++j) {
       const int idx = tid + 256 * j;
-      const int pix = idx / M4, c4 = idx - pix * M4;
-      if (XN % 256 == 0 || idx < XN) *reinterpret_cast<i32x4*>(&xs[pix * XS + 4 * c4]) = xr[j];
+      const int pix = idx / MV, cv = idx - pix * MV;
+      if (XN % 256 == 0 || idx < XN) *reinterpret_cast<i32x4*>(&xs[pix * XS + EV * cv]) = xr[j];
     }
 #pragma unroll
     for (int j = 0; j < NDL; ++j) {
       const int idx = tid + 256 * j;
-      const int pp = idx / N4, c4 = idx - pp * N4;
-      if (DN % 256 == 0 || idx < DN) *reinterpret_cast<i32x4*>(&dsm[pp * DS + 4 * c4]) = dr[j];
+      const int pp = idx / NV, cv = idx - pp * NV;
+      if (DN % 256 == 0 || idx < DN) *reinterpret_cast<i32x4*>(&dsm[pp * DS + EV * cv]) = dr[j];
     }
   };
 
-  const float* xa = xs + kk * XS + wm * (MT * 16) + i;
-  const float* da = dsm + kk * DS + wn * (NT * 16) + i;
-  int s = blockIdx.z;
-  if (s < a.nstages) {
-    issue(s);
-    commit();
-  }
-  __syncthreads();
+  // Per-lane LDS bases.  float32: lane (i, kk) reads channel i of pixel 4*ks + kk.  float16: k = 8*kk + e of a k-step
+  // is stage pixel 32*ks + 8*kk + e = (row 2*ks + (kk >> 1), column 8*(kk & 1) + e); a transpose read serves 4 of
+  // them, the lane addressing pixel (i >> 2) of the four and channels 4*(i & 3).. of its 16-channel tile.
+  const T* xa = HALF ? xs + ((kk >> 1) * HC + 8 * (kk & 1) + (i >> 2)) * XS + wm * (MT * 16) + 4 * (i & 3)
+                     : xs + kk * XS + wm * (MT * 16) + i;
+  const T* da = HALF ? dsm + (8 * kk + (i >> 2)) * DS + wn * (NT * 16) + 4 * (i & 3) : dsm + kk * DS + wn * (NT * 16) + i;
+
   // one k-step's operands: the dY fragment of every co tile and the X fragment of every (tap, ci tile); fetched from
   // LDS one k-step ahead of the MFMAs that use them (the scheduling fences keep the compiler from sinking the reads
   // back to their first use, where every MFMA group would wait out an LDS round trip)
-  float bfr[2][NT], afr[2][TAPS][MT];
-  auto fetch = [&](int ks, int slot) {
-    const int r = ks >> 2, c0 = 4 * (ks & 3);
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) bfr[slot][ni] = da[(ks * 4) * DS + ni * 16];
-#pragma unroll
-    for (int ty = 0; ty < TY; ++ty)
-#pragma unroll
-      for (int tx = 0; tx < TX; ++tx)
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) afr[slot][ty * TX + tx][mi] = xa[((r + ty) * HC + c0 + tx) * XS + mi * 16];
+  using Frag = typename std::conditional<HALF, f16x8, float>::type;
+  Frag bfr[2][NT], afr[2][TAPS][MT];
+  auto tr8 = [&](const T* p0, const T* p1) {   // two transpose reads -> the 8 consecutive-k halves of one lane
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(f16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
   };
+  auto fetch = [&](int ks, int slot) {
+    if constexpr (HALF) {
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) bfr[slot][ni] = tr8(da + (32 * ks) * DS + ni * 16, da + (32 * ks + 4) * DS + ni * 16);
+#pragma unroll
+      for (int ty = 0; ty < TY; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < TX; ++tx)
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi) {
+            const T* p = xa + ((2 * ks + ty) * HC + tx) * XS + mi * 16;
+            afr[slot][ty * TX + tx][mi] = tr8(p, p + 4 * XS);
+          }
+    } else {
+      const int r = ks >> 2, c0 = 4 * (ks & 3);
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) bfr[slot][ni] = da[(ks * 4) * DS + ni * 16];
+#pragma unroll
+      for (int ty = 0; ty < TY; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < TX; ++tx)
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi) afr[slot][ty * TX + tx][mi] = xa[((r + ty) * HC + c0 + tx) * XS + mi * 16];
+    }
+  };
+  auto mma = [&](Frag av, Frag bv, f32x4 c) {
+    if constexpr (HALF) return __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, c, 0, 0, 0);
+  };
+  Frag ones;
+  if constexpr (HALF) ones = f16x8{(f16)1, (f16)1, (f16)1, (f16)1, (f16)1, (f16)1, (f16)1, (f16)1};
+  else ones = 1.0f;
   auto compute = [&](auto with_bias) {
     fetch(0, 0);
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
+    for (int ks = 0; ks < KSTEPS; ++ks) {
       const int cur = ks & 1;
-      if (ks + 1 < 16) fetch(ks + 1, cur ^ 1);
+      if (ks + 1 < KSTEPS) fetch(ks + 1, cur ^ 1);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (decltype(with_bias)::value) {
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni) accb[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bfr[cur][ni], accb[ni], 0, 0, 0);
+        for (int ni = 0; ni < NT; ++ni) accb[ni] = mma(ones, bfr[cur][ni], accb[ni]);
       }
 #pragma unroll
       for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < NT; ++ni)
-            acc[t][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[cur][t][mi], bfr[cur][ni], acc[t][mi][ni], 0, 0, 0);
+          for (int ni = 0; ni < NT; ++ni) acc[t][mi][ni] = mma(afr[cur][t][mi], bfr[cur][ni], acc[t][mi][ni]);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+
+  int s = blockIdx.z;
+  if (s < a.nstages) {
+    issue(s);
+    commit();
+  }
+  __syncthreads();
   for (; s < a.nstages; s += a.ksplit) {
     const bool more = s + a.ksplit < a.nstages;
     if (more) issue(s + a.ksplit);
@@ -190,9 +232,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile(WgArgs a) {
   }
 }
 
-// dw[e] = sum_z partial[z][e] (+ decay * w[e]), dbias[c] = sum_z partial[z][count + c]; z ascending: deterministic.
+// dw[e] = scale * sum_z partial[z][e] (+ decay * w[e]), dbias[c] = scale * sum_z partial[z][count + c]; z ascending:
+// deterministic.  scale undoes the loss scaling of mixed-precision training (1 otherwise).
 __global__ void slab_reduce2_kernel(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ dbias,
-                                    const float* __restrict__ w, float decay, size_t count, int cout, size_t stride, int nslabs) {
+                                    const float* __restrict__ w, float decay, float scale, size_t count, int cout,
+                                    size_t stride, int nslabs) {
   const size_t total = count + (dbias ? (size_t)cout : 0);
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -203,7 +247,7 @@ __global__ void slab_reduce2_kernel(const float* __restrict__ partial, float* __
       s0 += v0; s1 += v1; s2 += v2; s3 += v3;
     }
     for (; z < nslabs; ++z) s0 += partial[(size_t)z * stride + e];
-    float s = (s0 + s1) + (s2 + s3);
+    float s = ((s0 + s1) + (s2 + s3)) * scale;
     if (e < count) {
       if (w) s += decay * w[e];
       dw[e] = s;
@@ -257,11 +301,25 @@ WgPlan wgrad_plan(int n, int h, int w, int cin, int cout, int k) {
   return p;
 }
 
-template <int MT, int NT, int WM, bool NINE>
+template <typename T, int MT, int NT, int WM, bool NINE>
 void launch_taps(const WgPlan& p, dim3 grid, hipStream_t st, const WgArgs& a) {
-  if (p.taps == 1) hipLaunchKernelGGL((wgrad_tile<MT, NT, WM, 1>), grid, dim3(256), 0, st, a);
-  else if (p.taps == 3) hipLaunchKernelGGL((wgrad_tile<MT, NT, WM, 3>), grid, dim3(256), 0, st, a);
-  else if constexpr (NINE) hipLaunchKernelGGL((wgrad_tile<MT, NT, WM, 9>), grid, dim3(256), 0, st, a);
+  if (p.taps == 1) hipLaunchKernelGGL((wgrad_tile<T, MT, NT, WM, 1>), grid, dim3(256), 0, st, a);
+  else if (p.taps == 3) hipLaunchKernelGGL((wgrad_tile<T, MT, NT, WM, 3>), grid, dim3(256), 0, st, a);
+  else if constexpr (NINE) hipLaunchKernelGGL((wgrad_tile<T, MT, NT, WM, 9>), grid, dim3(256), 0, st, a);
+}
+
+template <typename T>
+void launch_variant(const WgPlan& p, dim3 grid, hipStream_t st, const WgArgs& a) {
+  switch (p.variant) {
+    case V_64x16: hipLaunchKernelGGL((wgrad_tile<T, 1, 1, 4, 1>), grid, dim3(256), 0, st, a); break;
+    case V_64x32: hipLaunchKernelGGL((wgrad_tile<T, 1, 2, 4, 1>), grid, dim3(256), 0, st, a); break;
+    case V_64x48: hipLaunchKernelGGL((wgrad_tile<T, 1, 3, 4, 1>), grid, dim3(256), 0, st, a); break;
+    case V_64x80: hipLaunchKernelGGL((wgrad_tile<T, 1, 5, 4, 3>), grid, dim3(256), 0, st, a); break;
+    case V_64x64: launch_taps<T, 2, 2, 2, false>(p, grid, st, a); break;
+    case V_32x64: launch_taps<T, 1, 2, 2, true>(p, grid, st, a); break;
+    case V_16x64: launch_taps<T, 1, 1, 1, true>(p, grid, st, a); break;
+    default: launch_taps<T, 3, 1, 1, false>(p, grid, st, a); break;
+  }
 }
 
 }  // namespace
@@ -275,16 +333,18 @@ extern "C" size_t sqdet_conv2d_bwd_filter_workspace_bytes(int n, int h, int w, i
   return (size_t)p.ksplit * p.slab_stride * sizeof(float);
 }
 
-extern "C" int sqdet_conv2d_nhwc_bwd_filter(const float* x, const float* dy, float* dw_hwio, float* dbias,
-                                            const float* w_hwio_for_decay, float weight_decay, float* workspace, int n,
-                                            int h, int w, int cin, int cout, int k, int x_cstride, int x_coffset,
-                                            int dy_cstride, int dy_coffset, sqdet_stream_t stream) {
+extern "C" int sqdet_conv2d_nhwc_bwd_filter(const void* x, const void* dy, float* dw_hwio, float* dbias,
+                                            const float* w_hwio_for_decay, float weight_decay, float grad_scale,
+                                            float* workspace, int n, int h, int w, int cin, int cout, int k, int x_cstride,
+                                            int x_coffset, int dy_cstride, int dy_coffset, int dtype, sqdet_stream_t stream) {
   SQDET_REQUIRE(x && dy && dw_hwio && workspace, "conv2d_bwd_filter: null pointer");
   SQDET_REQUIRE((k == 1 || k == 3) && n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "conv2d_bwd_filter: bad dims");
-  SQDET_UNSUPPORTED(cin % 4 || cout % 4 || x_cstride % 4 || x_coffset % 4 || dy_cstride % 4 || dy_coffset % 4,
-                    "conv2d_bwd_filter: channel counts / strides must be multiples of 4");
-  const size_t P = (size_t)n * h * w;
-  SQDET_UNSUPPORTED(P * x_cstride * 4 >= 0xfffffff0ull || P * dy_cstride * 4 >= 0xfffffff0ull,
+  SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "conv2d_bwd_filter: bad dtype");
+  const int ev = dtype == SQDET_F16 ? 8 : 4;
+  SQDET_UNSUPPORTED(cin % ev || cout % ev || x_cstride % ev || x_coffset % ev || dy_cstride % ev || dy_coffset % ev,
+                    "conv2d_bwd_filter: channel counts / strides must be multiples of 16 bytes");
+  const size_t P = (size_t)n * h * w, es = dtype_size(dtype);
+  SQDET_UNSUPPORTED(P * x_cstride * es >= 0xfffffff0ull || P * dy_cstride * es >= 0xfffffff0ull,
                     "conv2d_bwd_filter: tensors of 4 GiB or more");
   hipStream_t st = as_stream(stream);
   const WgPlan p = wgrad_plan(n, h, w, cin, cout, k);
@@ -294,26 +354,18 @@ extern "C" int sqdet_conv2d_nhwc_bwd_filter(const float* x, const float* dy, flo
   a.x_cstride = x_cstride; a.x_coffset = x_coffset; a.dy_cstride = dy_cstride; a.dy_coffset = dy_coffset;
   a.BY = p.BY; a.BX = p.BX; a.nstages = p.nstages; a.ksplit = p.ksplit; a.ci_tiles = p.ci_tiles;
   a.do_bias = dbias != nullptr;
-  a.x_bytes = (unsigned)(P * x_cstride * 4);
-  a.dy_bytes = (unsigned)(P * dy_cstride * 4);
+  a.x_bytes = (unsigned)(P * x_cstride * es);
+  a.dy_bytes = (unsigned)(P * dy_cstride * es);
   a.slab_stride = p.slab_stride;
   const dim3 grid((k * k / p.taps) * p.ci_tiles, p.co_tiles, p.ksplit);
-  switch (p.variant) {
-    case V_64x16: hipLaunchKernelGGL((wgrad_tile<1, 1, 4, 1>), grid, dim3(256), 0, st, a); break;
-    case V_64x32: hipLaunchKernelGGL((wgrad_tile<1, 2, 4, 1>), grid, dim3(256), 0, st, a); break;
-    case V_64x48: hipLaunchKernelGGL((wgrad_tile<1, 3, 4, 1>), grid, dim3(256), 0, st, a); break;
-    case V_64x80: hipLaunchKernelGGL((wgrad_tile<1, 5, 4, 3>), grid, dim3(256), 0, st, a); break;
-    case V_64x64: launch_taps<2, 2, 2, false>(p, grid, st, a); break;
-    case V_32x64: launch_taps<1, 2, 2, true>(p, grid, st, a); break;
-    case V_16x64: launch_taps<1, 1, 1, true>(p, grid, st, a); break;
-    default: launch_taps<3, 1, 1, false>(p, grid, st, a); break;
-  }
+  if (dtype == SQDET_F16) launch_variant<f16>(p, grid, st, a);
+  else launch_variant<float>(p, grid, st, a);
   SQDET_CHECK_HIP(hipGetLastError());
   const size_t total = p.count + (dbias ? (size_t)cout : 0);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(slab_reduce2_kernel, dim3(blocks), dim3(256), 0, st, workspace, dw_hwio, dbias, w_hwio_for_decay,
-                     weight_decay, p.count, cout, p.slab_stride, p.ksplit);
+                     weight_decay, grad_scale, p.count, cout, p.slab_stride, p.ksplit);
   SQDET_CHECK_HIP(hipGetLastError());
   return SQDET_OK;
 }

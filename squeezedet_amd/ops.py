@@ -224,22 +224,26 @@ def conv2d_bwd_data(dy, packed_bwd, dx=None, dy_coffset=0, accumulate=False):
 
 
 def conv2d_bwd_filter(x, dy, k, cin, cout, w_for_decay=None, weight_decay=0.0, x_coffset=0, dy_coffset=0, want_bias=True,
-                      dw=None, db=None):
-    """dW [k,k,cin,cout] float32 HWIO (+ weight_decay*W), dbias [cout].  x [N,H,W,Cx], dy [N,H,W,Cy] float32;
-    the conv's input / output are the channel slices [x_coffset,+cin) / [dy_coffset,+cout)."""
+                      dw=None, db=None, grad_scale=1.0):
+    """dW [k,k,cin,cout] float32 HWIO = grad_scale * sum x*dy (+ weight_decay*W), dbias [cout] float32.
+    x [N,H,W,Cx], dy [N,H,W,Cy] float32 or float16 (same dtype); the conv's input / output are the channel slices
+    [x_coffset,+cin) / [dy_coffset,+cout)."""
     n, h, w, cx = [int(v) for v in x.shape]
     cy = int(dy.shape[3])
     dev = x.device
+    if x.dtype != dy.dtype:
+        raise _lib.SqdetError("conv2d_bwd_filter: x and dy must share a dtype")
     if dw is None:
         dw = torch.empty((k, k, cin, cout), dtype=torch.float32, device=dev)
     if db is None and want_bias:
         db = torch.empty((cout,), dtype=torch.float32, device=dev)
     ws = torch.empty(int(lib().sqdet_conv2d_bwd_filter_workspace_bytes(n, h, w, cin, cout, k)) // 4 + 64, dtype=torch.float32, device=dev)
-    check(lib().sqdet_conv2d_nhwc_bwd_filter(_dev(x, "x", torch.float32), _dev(dy, "dy", torch.float32), _dev(dw, "dw"),
-                                             _dev(db, "db") if db is not None else None,
+    check(lib().sqdet_conv2d_nhwc_bwd_filter(_dev(x, "x"), _dev(dy, "dy"), _dev(dw, "dw", torch.float32),
+                                             _dev(db, "db", torch.float32) if db is not None else None,
                                              _dev(w_for_decay, "w", torch.float32) if w_for_decay is not None else None,
-                                             float(weight_decay), _dev(ws, "ws"), n, h, w, int(cin), int(cout), int(k), cx,
-                                             int(x_coffset), cy, int(dy_coffset), stream_ptr()), "sqdet_conv2d_nhwc_bwd_filter")
+                                             float(weight_decay), float(grad_scale), _dev(ws, "ws"), n, h, w, int(cin), int(cout),
+                                             int(k), cx, int(x_coffset), cy, int(dy_coffset), dtype_code(x.dtype), stream_ptr()),
+          "sqdet_conv2d_nhwc_bwd_filter")
     return dw, db
 
 
@@ -271,23 +275,31 @@ def subsample_nhwc(x, stride):
 
 
 def relu_bwd(y, dy):
-    """In place: dy *= (y > 0)."""
-    check(lib().sqdet_relu_bwd(_dev(y, "y", torch.float32), _dev(dy, "dy", torch.float32), y.numel(), stream_ptr()), "sqdet_relu_bwd")
+    """In place: dy *= (y > 0).  float32 or float16."""
+    check(lib().sqdet_relu_bwd(_dev(y, "y", dy.dtype), _dev(dy, "dy"), y.numel(), dtype_code(dy.dtype), stream_ptr()), "sqdet_relu_bwd")
     return dy
 
 
 def scale_mask(x, mask, scale):
     y = torch.empty_like(x)
-    check(lib().sqdet_scale_mask(_dev(x, "x", torch.float32), _dev(mask, "mask", torch.float32), _dev(y, "y"), float(scale),
-                                 x.numel(), stream_ptr()), "sqdet_scale_mask")
+    check(lib().sqdet_scale_mask(_dev(x, "x"), _dev(mask, "mask", x.dtype), _dev(y, "y"), float(scale), x.numel(),
+                                 dtype_code(x.dtype), stream_ptr()), "sqdet_scale_mask")
+    return y
+
+
+def convert_scale(x, dtype, scale=1.0):
+    """(dtype)(x * scale) on the device: float16 <-> float32 (sqdet_convert_scale)."""
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(lib().sqdet_convert_scale(_dev(x, "x"), dtype_code(x.dtype), _dev(y, "y"), dtype_code(dtype), float(scale), x.numel(),
+                                    stream_ptr()), "sqdet_convert_scale")
     return y
 
 
 def maxpool_bwd(x, dy, size, stride, padding="SAME"):
     n, h, w, c = [int(v) for v in x.shape]
     dx = torch.empty_like(x)
-    check(lib().sqdet_maxpool_nhwc_bwd(_dev(x, "x", torch.float32), _dev(dy, "dy", torch.float32), _dev(dx, "dx"), n, h, w, c,
-                                       int(size), int(stride), pad_code(padding), stream_ptr()), "sqdet_maxpool_nhwc_bwd")
+    check(lib().sqdet_maxpool_nhwc_bwd(_dev(x, "x"), _dev(dy, "dy", x.dtype), _dev(dx, "dx"), n, h, w, c, int(size), int(stride),
+                                       pad_code(padding), dtype_code(x.dtype), stream_ptr()), "sqdet_maxpool_nhwc_bwd")
     return dx
 
 
@@ -324,10 +336,13 @@ class MomentumOptimizer:
         check(lib().sqdet_optimizer_create(C.byref(self._h), off, cnt, dec, nv), "sqdet_optimizer_create")
         self.ws = torch.empty(int(lib().sqdet_optimizer_workspace_bytes(self._h)) + 256, dtype=torch.uint8, device=device)
 
-    def step(self, params, grads, accum, lr, momentum, max_grad_norm, grad_scale=1.0):
+    def step(self, params, grads, accum, lr, momentum, max_grad_norm, grad_scale=1.0, found_inf=None):
+        """found_inf: optional int32 device tensor [1]; set to 1 (and the step skipped) when a gradient norm is inf / NaN."""
         check(lib().sqdet_optimizer_step(self._h, _dev(params, "params", torch.float32), _dev(grads, "grads", torch.float32),
                                          _dev(accum, "accum", torch.float32), _dev(self.ws, "ws"), float(lr), float(momentum),
-                                         float(max_grad_norm), float(grad_scale), stream_ptr()), "sqdet_optimizer_step")
+                                         float(max_grad_norm), float(grad_scale),
+                                         _dev(found_inf, "found_inf", torch.int32) if found_inf is not None else None,
+                                         stream_ptr()), "sqdet_optimizer_step")
 
     def __del__(self):
         try:

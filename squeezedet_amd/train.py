@@ -31,11 +31,22 @@ def allreduce_gradients(flat_grads, world, group=None):
 
 class _TrainerBase:
     """Flat float32 parameter / gradient / momentum buffers over the trainable variables of a model built with
-    mc.IS_TRAINING = True and dtype float32, the gradient all-reduce and the optimizer step."""
+    mc.IS_TRAINING = True, the gradient all-reduce and the optimizer step.
 
-    def __init__(self, model, process_group=None):
-        if model.dtype != torch.float32:
-            raise SqdetError("training runs in float32 (the reference's training dtype)")
+    model.dtype float32 is the reference's training dtype.  model.dtype float16 is mixed-precision training
+    (BASELINE.json configs[4]): activations and activation gradients are float16, the master weights, weight / bias
+    gradients, momentum and the loss stay float32; d(loss)/d(preds) is multiplied by `loss_scale` before it is cast to
+    float16 and the backward-filter kernels divide it out again, so the flat gradients are true-scale.  A step whose
+    gradients overflowed (inf / NaN norm in any variable, on any rank -- the SUM all-reduce spreads it) is skipped by
+    the optimizer kernel and halves the scale; `growth_interval` clean steps double it."""
+
+    def __init__(self, model, process_group=None, loss_scale=1024.0, growth_interval=200):
+        if model.dtype not in (torch.float32, torch.float16):
+            raise SqdetError("training runs in float32 (the reference's training dtype) or float16 (mixed precision)")
+        self.adt = model.dtype                       # activation dtype
+        self.half = model.dtype == torch.float16
+        self.loss_scale = float(loss_scale) if self.half else 1.0
+        self.growth_interval, self._clean_steps, self.skipped_steps = int(growth_interval), 0, 0
         if not model.has_device:
             raise SqdetError("squeezedet_amd needs a HIP device: there is no CPU path")
         self.model, self.mc, self.dev = model, model.mc, model.device
@@ -67,6 +78,7 @@ class _TrainerBase:
         model._packed.clear()
         model._plan_stale = True
         self.opt = ops.MomentumOptimizer(offs, cnts, decs, self.dev)
+        self.found_inf = torch.zeros(1, dtype=torch.int32, device=self.dev)
 
     def learning_rate(self):
         mc = self.mc
@@ -77,12 +89,30 @@ class _TrainerBase:
         mask = t(input_mask).reshape(B, -1)
         return t, mask, t(box_delta_input), t(box_input), t(labels), float(mask.sum().item())
 
+    def _loss(self, preds, mask, delta, box, lab, num_objects):
+        """Loss forward + backward in float32; returns (gradient w.r.t. preds in the activation dtype -- times
+        loss_scale in float16 mode --, float32 dpreds, ious, losses)."""
+        p32 = ops.convert_scale(preds, torch.float32) if self.half else preds
+        dpreds, ious, losses = ops.loss_fwd_bwd(p32, self.model.anchors_f32(), mask, delta, box, lab, self.mc, num_objects)
+        g = ops.convert_scale(dpreds, torch.float16, self.loss_scale) if self.half else dpreds
+        return g, dpreds, ious, losses
+
     def _finish_step(self, apply_update):
         """Gradient all-reduce (the one collective) + clipped Momentum update on the flat buffers."""
         grad_scale = allreduce_gradients(self.flat_grads, self.world, self.pg)
         if apply_update:
             self.opt.step(self.flat_params, self.flat_grads, self.flat_accum, self.learning_rate(), self.mc.MOMENTUM,
-                          self.mc.MAX_GRAD_NORM, grad_scale)
+                          self.mc.MAX_GRAD_NORM, grad_scale, found_inf=self.found_inf if self.half else None)
+            if self.half and int(self.found_inf.item()):
+                # overflow: the kernel left weights and momentum untouched; retry the next batch at half the scale
+                self.loss_scale = max(self.loss_scale / 2.0, 2.0 ** -14)
+                self._clean_steps = 0
+                self.skipped_steps += 1
+                return
+            if self.half:
+                self._clean_steps += 1
+                if self._clean_steps >= self.growth_interval:
+                    self.loss_scale, self._clean_steps = min(self.loss_scale * 2.0, 65536.0), 0
             self.global_step += 1
             self.model._packed.clear()
             self.model._plan_stale = True
@@ -99,8 +129,8 @@ class _TrainerBase:
 class SqueezeDetTrainer(_TrainerBase):
     """model: a squeezedet_amd.nets.SqueezeDet built with mc.IS_TRAINING = True and dtype float32."""
 
-    def __init__(self, model, process_group=None):
-        _TrainerBase.__init__(self, model, process_group)
+    def __init__(self, model, process_group=None, **kw):
+        _TrainerBase.__init__(self, model, process_group, **kw)
         self.layers = self._layer_list()
 
     # ---- the forward graph as a list (nets/squeezeDet.py:30-79) ----
@@ -126,13 +156,17 @@ class SqueezeDetTrainer(_TrainerBase):
         return seq
 
     def _pack(self, name):
-        return ops.pack_conv_weights(self.model.params[name + "/kernels"], torch.float32)
+        return ops.pack_conv_weights(self.model.params[name + "/kernels"], self.adt)
 
-    def step(self, images, input_mask, box_delta_input, box_input, labels, dropout_mask=None, apply_update=True):
+    def step(self, images, input_mask, box_delta_input, box_input, labels, dropout_mask=None, apply_update=True,
+             keep_activations=False):
         """One training step.  images [B,H,W,3]; input_mask [B,A] or [B,A,1]; box_delta_input / box_input
         [B,A,4]; labels [B,A,C] (the reference's placeholders, nn_skeleton.py:81-97).  Returns a dict
-        with loss, class_loss, conf_loss, bbox_loss (device scalars)."""
+        with loss, class_loss, conf_loss, bbox_loss (device scalars).  keep_activations: also return every stored
+        forward activation as out["activations"] = {name: tensor} (names as oracle/train_oracle.py forward_train's
+        `override`), for parity tests of the backward pass."""
         m, mc, P = self.model, self.mc, self.model.params
+        acts = {}
         x = m._to_input(images)
         B = int(x.shape[0])
         t, mask, delta, box, lab, num_objects = self._labels(B, input_mask, box_delta_input, box_input, labels)
@@ -148,32 +182,36 @@ class SqueezeDetTrainer(_TrainerBase):
                     drop_in = cur
                     if dropout_mask is None:
                         dropout_mask = torch.floor(keep + torch.rand(cur.shape, device=self.dev))   # tf.nn.dropout's mask
-                    dm = t(dropout_mask)
+                    dm = t(dropout_mask).to(self.adt)
                     cur = ops.scale_mask(cur, dm, 1.0 / keep) if keep != 1.0 else cur
+                    acts["drop"] = cur
                 y = ops.conv2d_nhwc(cur, self._pack(node.name), P[node.name + "/biases"], node.attrs["stride"],
                                     node.attrs["padding"], node.attrs["relu"])
                 saved.append(("conv", node, cur, y))
+                acts[node.name] = y
                 cur = y
             elif item[0] == "pool":
                 node = item[2]
                 y = ops.maxpool_nhwc(cur, node.attrs["size"], node.attrs["stride"], node.attrs["padding"])
                 saved.append(("pool", node, cur, y))
+                acts[node.name] = y
                 cur = y
             else:
                 _, fname, sq, e1, e3 = item
                 s = ops.conv2d_nhwc(cur, self._pack(sq.name), P[sq.name + "/biases"], 1, "SAME", True)
-                y = torch.empty((B, int(s.shape[1]), int(s.shape[2]), e1.shape[3] + e3.shape[3]), dtype=torch.float32, device=self.dev)
+                y = torch.empty((B, int(s.shape[1]), int(s.shape[2]), e1.shape[3] + e3.shape[3]), dtype=self.adt, device=self.dev)
                 ops.conv2d_nhwc(s, self._pack(e1.name), P[e1.name + "/biases"], 1, "SAME", True, out=y, out_coffset=0)
                 ops.conv2d_nhwc(s, self._pack(e3.name), P[e3.name + "/biases"], 1, "SAME", True, out=y, out_coffset=e1.shape[3])
                 saved.append(("fire", (sq, e1, e3), cur, s, y))
+                acts[fname + "/squeeze1x1"], acts[fname] = s, y
                 cur = y
         preds = cur
         # ---------------- loss ----------------
-        dpreds, ious, losses = ops.loss_fwd_bwd(preds, m.anchors_f32(), mask, delta, box, lab, mc, num_objects)
+        g, dpreds, ious, losses = self._loss(preds, mask, delta, box, lab, num_objects)
         # ---------------- backward ----------------
-        wd = mc.WEIGHT_DECAY
         self.flat_grads.zero_()
-        g = dpreds                      # gradient w.r.t. the current layer's OUTPUT (pre-activation mask applied below)
+        gs = 1.0 / self.loss_scale      # g: gradient w.r.t. the current layer's OUTPUT (pre-activation mask applied below)
+        bwd = lambda name: ops.PackedConvBwd(P[name + "/kernels"], self.adt)
 
         def has_trainable(rec):
             if rec[0] == "conv":
@@ -190,11 +228,11 @@ class SqueezeDetTrainer(_TrainerBase):
                     ops.relu_bwd(y, g)
                 k = node.attrs["size"]
                 cin, cout = int(xin.shape[3]), int(y.shape[3])
-                ops.conv2d_bwd_filter(xin, g, k, cin, cout, dw=self.gview[name + "/kernels"], db=self.gview[name + "/biases"])
+                ops.conv2d_bwd_filter(xin, g, k, cin, cout, dw=self.gview[name + "/kernels"], db=self.gview[name + "/biases"], grad_scale=gs)
                 if need_dx:
-                    g = ops.conv2d_bwd_data(g, ops.PackedConvBwd(P[name + "/kernels"]))
+                    g = ops.conv2d_bwd_data(g, bwd(name))
                     if name == "conv12" and keep != 1.0:
-                        g = ops.scale_mask(g, t(dropout_mask), 1.0 / keep)
+                        g = ops.scale_mask(g, dm, 1.0 / keep)
             elif rec[0] == "pool":
                 _, node, xin, y = rec
                 g = ops.maxpool_bwd(xin, g, node.attrs["size"], node.attrs["stride"], node.attrs["padding"])
@@ -202,18 +240,20 @@ class SqueezeDetTrainer(_TrainerBase):
                 _, (sq, e1, e3), xin, s, y = rec
                 ne1, ne3, ns = e1.shape[3], e3.shape[3], sq.shape[3]
                 ops.relu_bwd(y, g)      # both expand convs end in ReLU
-                ops.conv2d_bwd_filter(s, g, 1, ns, ne1, dy_coffset=0, dw=self.gview[e1.name + "/kernels"], db=self.gview[e1.name + "/biases"])
-                ops.conv2d_bwd_filter(s, g, 3, ns, ne3, dy_coffset=ne1, dw=self.gview[e3.name + "/kernels"], db=self.gview[e3.name + "/biases"])
-                ds = ops.conv2d_bwd_data(g, ops.PackedConvBwd(P[e1.name + "/kernels"]), dy_coffset=0)
-                ops.conv2d_bwd_data(g, ops.PackedConvBwd(P[e3.name + "/kernels"]), dx=ds, dy_coffset=ne1, accumulate=True)
+                ops.conv2d_bwd_filter(s, g, 1, ns, ne1, dy_coffset=0, dw=self.gview[e1.name + "/kernels"], db=self.gview[e1.name + "/biases"], grad_scale=gs)
+                ops.conv2d_bwd_filter(s, g, 3, ns, ne3, dy_coffset=ne1, dw=self.gview[e3.name + "/kernels"], db=self.gview[e3.name + "/biases"], grad_scale=gs)
+                ds = ops.conv2d_bwd_data(g, bwd(e1.name), dy_coffset=0)
+                ops.conv2d_bwd_data(g, bwd(e3.name), dx=ds, dy_coffset=ne1, accumulate=True)
                 ops.relu_bwd(s, ds)
-                ops.conv2d_bwd_filter(xin, ds, 1, int(xin.shape[3]), ns, dw=self.gview[sq.name + "/kernels"], db=self.gview[sq.name + "/biases"])
+                ops.conv2d_bwd_filter(xin, ds, 1, int(xin.shape[3]), ns, dw=self.gview[sq.name + "/kernels"], db=self.gview[sq.name + "/biases"], grad_scale=gs)
                 if need_dx:
-                    g = ops.conv2d_bwd_data(ds, ops.PackedConvBwd(P[sq.name + "/kernels"]))
+                    g = ops.conv2d_bwd_data(ds, bwd(sq.name))
         # ---------------- gradient all-reduce + update ----------------
         self._finish_step(apply_update)
         out = collections.OrderedDict(class_loss=losses[0], conf_loss=losses[1], bbox_loss=losses[2], ious=ious, preds=preds,
                                       dpreds=dpreds, num_objects=num_objects)
+        if keep_activations:
+            out["activations"] = acts
         return out
 
 
@@ -224,8 +264,8 @@ class ResNet50ConvDetTrainer(_TrainerBase):
     it affine): forward = sqdet_fold_batchnorm + conv, backward = the conv backward kernels on the folded
     kernel + sqdet_fold_batchnorm_bwd for d(kernels), d(gamma), d(beta).  float32, like the reference."""
 
-    def __init__(self, model, process_group=None):
-        _TrainerBase.__init__(self, model, process_group)
+    def __init__(self, model, process_group=None, **kw):
+        _TrainerBase.__init__(self, model, process_group, **kw)
         m = model
         order, seen = [], set()
 
@@ -251,7 +291,8 @@ class ResNet50ConvDetTrainer(_TrainerBase):
             if n.op in ("conv", "conv_bn") and not has_tr(n):
                 raise SqdetError("frozen conv %s above the first trainable one is not supported" % n.name)
 
-    def step(self, images, input_mask, box_delta_input, box_input, labels, dropout_mask=None, apply_update=True):
+    def step(self, images, input_mask, box_delta_input, box_input, labels, dropout_mask=None, apply_update=True,
+             keep_activations=False):
         m, mc, P = self.model, self.mc, self.model.params
         eps = mc.BATCH_NORM_EPSILON
         (xb,) = m.run([self.boundary], {m.image_input: images}, use_plan=False)
@@ -268,7 +309,7 @@ class ResNet50ConvDetTrainer(_TrainerBase):
                 fused_add = len(n.readers) == 1 and n.readers[0].op == "add_relu" and n.readers[0].inputs[1] is n and not n.attrs["relu"]
                 if fused_add:
                     continue        # evaluated by its add_relu reader (residual epilogue)
-                val[n] = ops.conv2d_nhwc(x, ops.pack_conv_weights(wf, torch.float32), bf, n.attrs["stride"], n.attrs["padding"], n.attrs["relu"])
+                val[n] = ops.conv2d_nhwc(x, ops.pack_conv_weights(wf, self.adt), bf, n.attrs["stride"], n.attrs["padding"], n.attrs["relu"])
             elif n.op == "add_relu":
                 sc, br = n.inputs
                 if br in val:
@@ -276,26 +317,27 @@ class ResNet50ConvDetTrainer(_TrainerBase):
                 else:
                     wf, bf = aux[br], aux[(br, "bf")]
                     out = val[sc].clone()         # the shortcut is branch2a's input: its value is needed by the backward
-                    val[n] = ops.conv2d_nhwc(val[br.inputs[0]], ops.pack_conv_weights(wf, torch.float32), bf, br.attrs["stride"],
+                    val[n] = ops.conv2d_nhwc(val[br.inputs[0]], ops.pack_conv_weights(wf, self.adt), bf, br.attrs["stride"],
                                              br.attrs["padding"], True, out=out, accumulate=True)
             elif n.op == "dropout":
                 x = val[n.inputs[0]]
                 keep = n.attrs["keep_prob"]
                 if dropout_mask is None:
                     dropout_mask = torch.floor(keep + torch.rand(x.shape, device=self.dev))
-                aux[n] = t(dropout_mask)
+                aux[n] = t(dropout_mask).to(self.adt)
                 val[n] = ops.scale_mask(x, aux[n], 1.0 / keep)
             elif n.op == "conv":
                 x = val[n.inputs[0]]
-                val[n] = ops.conv2d_nhwc(x, ops.pack_conv_weights(P[n.name + "/kernels"], torch.float32), P[n.name + "/biases"],
+                val[n] = ops.conv2d_nhwc(x, ops.pack_conv_weights(P[n.name + "/kernels"], self.adt), P[n.name + "/biases"],
                                          n.attrs["stride"], n.attrs["padding"], n.attrs["relu"])
             else:
                 raise SqdetError("ResNet50ConvDetTrainer: unsupported op %s in the trainable region" % n.op)
         preds = val[m.preds]
-        dpreds, ious, losses = ops.loss_fwd_bwd(preds, m.anchors_f32(), mask, delta, box, lab, mc, num_objects)
+        g0, dpreds, ious, losses = self._loss(preds, mask, delta, box, lab, num_objects)
         # ---------------- backward ----------------
         self.flat_grads.zero_()
-        g = {m.preds: dpreds}
+        g = {m.preds: g0}
+        gs = 1.0 / self.loss_scale
 
         def give(node, dy, packed_bwd):
             """d(input) of a stride-1 conv into g[node] (accumulating when the node already has a gradient)."""
@@ -313,8 +355,8 @@ class ResNet50ConvDetTrainer(_TrainerBase):
                 if n.attrs["relu"]:
                     ops.relu_bwd(val[n], gy)
                 k, cin, cout = n.attrs["size"], int(x.shape[3]), int(n.shape[3])
-                ops.conv2d_bwd_filter(x, gy, k, cin, cout, dw=self.gview[n.name + "/kernels"], db=self.gview[n.name + "/biases"])
-                give(n.inputs[0], gy, ops.PackedConvBwd(P[n.name + "/kernels"]))
+                ops.conv2d_bwd_filter(x, gy, k, cin, cout, dw=self.gview[n.name + "/kernels"], db=self.gview[n.name + "/biases"], grad_scale=gs)
+                give(n.inputs[0], gy, ops.PackedConvBwd(P[n.name + "/kernels"], self.adt))
             elif n.op == "dropout":
                 g[n.inputs[0]] = ops.scale_mask(gy, aux[n], 1.0 / n.attrs["keep_prob"])
             elif n.op == "add_relu":
@@ -333,12 +375,15 @@ class ResNet50ConvDetTrainer(_TrainerBase):
                     if k != 1 or n.inputs[0] is not self.boundary:
                         raise SqdetError("ResNet50ConvDetTrainer: strided conv %s needs an input gradient" % n.name)
                     x = ops.subsample_nhwc(x, stride)
-                dwf, dbf = ops.conv2d_bwd_filter(x, gy, k, cin, cout)
+                dwf, dbf = ops.conv2d_bwd_filter(x, gy, k, cin, cout, grad_scale=gs)
                 ops.fold_batchnorm_bwd(P[n.name + "/kernels"], dwf, dbf, None, P[n.name + "/gamma"], P[n.name + "/mean"],
                                        P[n.name + "/var"], eps, dw=self.gview[n.name + "/kernels"],
                                        dgamma=self.gview[n.name + "/gamma"], dbeta=self.gview[n.name + "/beta"])
                 if stride == 1:
-                    give(n.inputs[0], gy, ops.PackedConvBwd(aux[n]))
+                    give(n.inputs[0], gy, ops.PackedConvBwd(aux[n], self.adt))
         self._finish_step(apply_update)
-        return collections.OrderedDict(class_loss=losses[0], conf_loss=losses[1], bbox_loss=losses[2], ious=ious, preds=preds,
-                                       dpreds=dpreds, num_objects=num_objects)
+        out = collections.OrderedDict(class_loss=losses[0], conf_loss=losses[1], bbox_loss=losses[2], ious=ious, preds=preds,
+                                      dpreds=dpreds, num_objects=num_objects)
+        if keep_activations:     # names as oracle/resnet_oracle.py forward_train's `override`
+            out["activations"] = {n.name: v for n, v in val.items()}
+        return out

@@ -110,6 +110,75 @@ def test_relu_dropout_maxpool_backward():
         np.testing.assert_allclose(dx.cpu().numpy(), x.grad.numpy(), rtol=1e-6, atol=1e-6)
 
 
+def test_float16_elementwise_backward_ops():
+    """The activation-side backward kernels on float16 tensors (mixed-precision training): exact against the same
+    arithmetic on the float16-rounded values."""
+    ops = _ops()
+    rs = np.random.RandomState(13)
+    y = torch.from_numpy(np.maximum(rs.randn(2, 9, 11, 16), 0).astype(np.float32)).half()
+    dy = torch.from_numpy(rs.randn(2, 9, 11, 16).astype(np.float32)).half()
+    got = ops.relu_bwd(y.to(DEV), dy.to(DEV).clone())
+    assert got.dtype == torch.float16
+    np.testing.assert_array_equal(got.cpu().numpy(), (dy * (y > 0)).numpy())
+    m = torch.from_numpy((rs.uniform(size=(2, 9, 11, 16)) < 0.5).astype(np.float32)).half()
+    np.testing.assert_array_equal(ops.scale_mask(dy.to(DEV), m.to(DEV), 2.0).cpu().numpy(), (dy.float() * m.float() * 2.0).half().numpy())
+    for (H, W, pad) in ((47, 156, "SAME"), (20, 31, "VALID")):
+        # distinct float16 values per channel so the argmax is unique
+        bits = np.stack([rs.permutation(H * W) for _ in range(8)], -1).reshape(1, H, W, 8) + 0x2000
+        vals = bits.astype(np.uint16).view(np.float16).astype(np.float32)     # consecutive float16 bit patterns: all distinct
+        x = torch.from_numpy(vals).requires_grad_(True)
+        yp = O.pooling_layer(x, 3, 2, pad)
+        g = torch.from_numpy(rs.randn(*yp.shape).astype(np.float32)).half().float()
+        yp.backward(g)
+        dx = ops.maxpool_bwd(x.detach().half().to(DEV), g.half().to(DEV), 3, 2, pad)
+        torch.cuda.synchronize()
+        assert dx.dtype == torch.float16
+        np.testing.assert_allclose(dx.float().cpu().numpy(), x.grad.numpy(), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("case", BWD_CASES, ids=[c[0] for c in BWD_CASES])
+def test_conv_backward_float16(case):
+    """Backward-data and backward-filter on float16 activations / activation gradients (float32 dW, dbias): against
+    float32 autograd on the SAME float16-rounded inputs; the MFMA accumulates in float32, so only the summation
+    order differs (dx additionally rounds to float16)."""
+    ops = _ops()
+    name, N, H, W, cin, cout, k = case
+    if cin % 8 or cout % 8:
+        pytest.skip("float16 rows are 16-byte vectors: channel counts must be multiples of 8")
+    rs = np.random.RandomState(len(name) * 11 + cout)
+    x = torch.from_numpy(rs.randn(N, H, W, cin).astype(np.float32)).half().float().requires_grad_(True)
+    w = torch.from_numpy((rs.randn(k, k, cin, cout) * (2.0 / (k * k * cin)) ** 0.5).astype(np.float32)).half().float().requires_grad_(True)
+    b = torch.zeros(cout, requires_grad=True)
+    dy = torch.from_numpy(rs.randn(N, H, W, cout).astype(np.float32)).half().float()
+    y = _conv_ref(x, w) + b
+    y.backward(dy)
+    dxg = ops.conv2d_bwd_data(dy.half().to(DEV), ops.PackedConvBwd(w.detach().to(DEV), torch.float16))
+    dwg, dbg = ops.conv2d_bwd_filter(x.detach().half().to(DEV), dy.half().to(DEV), k, cin, cout, grad_scale=0.25)
+    torch.cuda.synchronize()
+    assert dxg.dtype == torch.float16 and dwg.dtype == torch.float32 and dbg.dtype == torch.float32
+    _close(dxg, x.grad, rel=2e-3, what=name + " dx (f16)")
+    _close(dwg, 0.25 * w.grad, rel=1e-4, what=name + " dW (f16 in, f32 out)")
+    _close(dbg, 0.25 * b.grad, rel=1e-4, what=name + " dbias (f16 in, f32 out)")
+
+
+def test_optimizer_skips_overflowed_step():
+    """found_inf: a non-finite gradient norm anywhere skips the whole update (loss-scaled float16 training)."""
+    ops = _ops()
+    offs, cnts = [0, 128], [100, 64]
+    opt = ops.MomentumOptimizer(offs, cnts, [1e-4, 0.0], DEV)
+    p = torch.randn(192, device=DEV)
+    g = torch.randn(192, device=DEV)
+    acc = torch.zeros(192, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    p0 = p.clone()
+    g2 = g.clone()
+    g2[130] = float("inf")
+    opt.step(p, g2, acc, 0.01, 0.9, 1.0, 1.0, found_inf=flag)
+    assert int(flag.item()) == 1 and torch.equal(p, p0) and float(acc.abs().sum()) == 0.0
+    opt.step(p, g.clone(), acc, 0.01, 0.9, 1.0, 1.0, found_inf=flag)
+    assert int(flag.item()) == 0 and not torch.equal(p, p0)
+
+
 def test_loss_forward_backward_vs_oracle():
     ops = _ops()
     mc = O.squeezeDet_config_for_input(128, 256)
@@ -132,7 +201,7 @@ def test_loss_forward_backward_vs_oracle():
     _close(dp, dref, rel=5e-5, what="dpreds")
 
 
-def _trainer(img=(128, 256), batch=2, seed=0):
+def _trainer(img=(128, 256), batch=2, seed=0, dtype=torch.float32, **kw):
     import squeezedet_amd as S
     from squeezedet_amd import nets
     from squeezedet_amd.train import SqueezeDetTrainer
@@ -140,10 +209,10 @@ def _trainer(img=(128, 256), batch=2, seed=0):
     mc.LOAD_PRETRAINED_MODEL = False
     mc.IS_TRAINING = True
     mc.BATCH_SIZE = batch
-    m = nets.SqueezeDet(mc, gpu_id="0", dtype=torch.float32)
+    m = nets.SqueezeDet(mc, gpu_id="0", dtype=dtype)
     params = O.init_params("squeezeDet", seed=seed)
     m.load_params(params)
-    return SqueezeDetTrainer(m), mc, params
+    return SqueezeDetTrainer(m, **kw), mc, params
 
 
 def test_full_training_step_vs_oracle():
@@ -182,6 +251,71 @@ def test_full_training_step_vs_oracle():
     for name in ref["grads"]:
         _close(tr.view[name], p_ref[name], rel=2e-5, what=name + " after update")
     _close(tr.model.params["conv1/kernels"], params["conv1/kernels"], rel=0, what="frozen conv1")
+
+
+def test_mixed_precision_training_step_vs_oracle():
+    """float16 activations / activation gradients, float32 master weights and weight gradients, loss scale 256:
+    the same step against the oracle restated with float16 storage (oracle/train_oracle.py _q: losses 0.2 %, every
+    gradient tensor within 2 % of its largest element) and, for direction, against the float32 oracle.  The flat
+    gradients come out true-scale (the loss scale is divided out by the backward-filter kernels)."""
+    tr, mc, params = _trainer(dtype=torch.float16, loss_scale=256.0)
+    omc = O.squeezeDet_config_for_input(128, 256)
+    omc.IS_TRAINING = True
+    B = 2
+    x = O.synthetic_images(B, 128, 256, seed=11)
+    mask, delta, box, labels = TO.synthetic_labels(omc, B, seed=12)
+    gh, gw = O.squeezedet_grid(128, 256)
+    dm = torch.from_numpy((np.random.RandomState(13).uniform(size=(B, gh, gw, 768)) < 0.5).astype(np.float32))
+    ref16 = TO.loss_and_grads("squeezeDet", omc, params, x, dm, mask, delta, box, labels, storage="fp16")
+    ref32 = TO.loss_and_grads("squeezeDet", omc, params, x, dm, mask, delta, box, labels)
+    out = tr.step(x, mask, delta, box, labels, dropout_mask=dm, apply_update=False, keep_activations=True)
+    torch.cuda.synchronize()
+    assert out["preds"].dtype == torch.float16 and tr.flat_grads.dtype == torch.float32
+    # forward: against the oracle restated with float16 storage, and (looser) the float32 oracle
+    for k in ("class_loss", "conf_loss", "bbox_loss"):
+        np.testing.assert_allclose(float(out[k]), ref16[k], rtol=3e-3)
+        np.testing.assert_allclose(float(out[k]), ref32[k], rtol=1e-2)
+    _close(out["preds"], ref16["preds"], rel=3e-3, what="preds (float16 training forward)")
+    # backward: float16 storage turns 1-ulp forward differences into different ReLU / max-pool decisions for ~1e-3 of
+    # the elements, which moves a gradient by ~sqrt(1e-3) however exact the backward kernels are.  So the backward is
+    # checked with the oracle's forward VALUES pinned to the activations the device kept (same decisions, the
+    # oracle's own float32 backward arithmetic): every gradient within 1 % of its largest element ...
+    acts = {k: v.float().cpu() for k, v in out["activations"].items()}
+    ref = TO.loss_and_grads("squeezeDet", omc, params, x, dm, mask, delta, box, labels, storage="fp16", override=acts)
+    for name, gref in ref["grads"].items():
+        wdg = omc.WEIGHT_DECAY * params[name] if name.endswith("/kernels") else 0.0
+        got = tr.gview[name].cpu() + wdg
+        scale = float(gref.abs().max())
+        err = float((got - gref).abs().max())
+        assert err <= 1e-2 * scale + 1e-7, "%s: grad err %g vs scale %g" % (name, err, scale)
+        # ... and against the free-running float32 oracle the direction of every gradient agrees
+        g32 = ref32["grads"][name]
+        cos = float((got * g32).sum() / (got.norm() * g32.norm() + 1e-30))
+        assert cos >= 0.995, "%s: cos %g vs the float32 oracle" % (name, cos)
+    # the master weights stay float32 and the update is the float32 optimizer kernel
+    assert tr.flat_params.dtype == torch.float32 and tr.model.params["conv12/kernels"].dtype == torch.float32
+
+
+def test_mixed_precision_overflow_skips_and_rescales():
+    """A loss scale that overflows float16 gradients: the step is skipped (weights, momentum, global_step untouched),
+    the scale halves until the gradients are finite, and training then proceeds."""
+    tr, mc, params = _trainer(seed=3, dtype=torch.float16, loss_scale=2.0 ** 40, growth_interval=4)
+    omc = O.squeezeDet_config_for_input(128, 256)
+    x = O.synthetic_images(2, 128, 256, seed=21)
+    mask, delta, box, labels = TO.synthetic_labels(omc, 2, seed=22)
+    w0 = tr.flat_params.clone()
+    tr.step(x, mask, delta, box, labels)
+    assert tr.skipped_steps == 1 and tr.global_step == 0 and tr.loss_scale == 2.0 ** 39
+    assert torch.equal(tr.flat_params, w0) and float(tr.flat_accum.abs().sum()) == 0.0
+    hist = []
+    for _ in range(60):
+        o = tr.step(x, mask, delta, box, labels)
+        if tr.global_step:
+            hist.append(float(o["class_loss"]) + float(o["conf_loss"]) + float(o["bbox_loss"]))
+        if tr.global_step >= 12:
+            break
+    assert tr.global_step >= 12 and tr.skipped_steps > 1 and tr.loss_scale <= 65536.0
+    assert np.isfinite(hist).all() and min(hist[-3:]) < hist[0], hist
 
 
 def test_training_reduces_loss_on_fixed_batch():

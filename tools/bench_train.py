@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: 20 squeezeDet, 8 resnet50)")
     ap.add_argument("--arch", default="squeezeDet", choices=["squeezeDet", "resnet50"],
                     help="squeezeDet = BASELINE.json configs[2]; resnet50 = configs[4] (ResNet50+ConvDet, 1242x375, in float32)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
+                    help="f32 = the reference's training dtype; f16 = mixed precision (float16 activations / activation gradients, "
+                         "float32 master weights, weight gradients and optimizer, dynamic loss scale) -- configs[4] is resnet50 + f16")
     args = ap.parse_args()
     if args.batch <= 0:
         args.batch = 20 if args.arch == "squeezeDet" else 8
@@ -57,7 +60,7 @@ def main():
     mc.IS_TRAINING = True
     mc.BATCH_SIZE = args.batch
     cls, trainer = (nets.SqueezeDet, SqueezeDetTrainer) if args.arch == "squeezeDet" else (nets.ResNet50ConvDet, ResNet50ConvDetTrainer)
-    model = cls(mc, gpu_id=str(local_rank), dtype=torch.float32)
+    model = cls(mc, gpu_id=str(local_rank), dtype=torch.float32 if args.dtype == "f32" else torch.float16)
     model.load_params(synthetic.synthetic_params(model, seed=0))      # same weights on every rank
     tr = trainer(model)
     x = synthetic.synthetic_images(args.batch, mc.IMAGE_HEIGHT, mc.IMAGE_WIDTH, seed=100 + rank).to(dev)
@@ -85,11 +88,13 @@ def main():
         el = float(t.item())
     if rank == 0:
         label = "SqueezeDet 1248x384" if args.arch == "squeezeDet" else "ResNet50+ConvDet 1242x375"
-        print(json.dumps({"metric": "images/sec %s fp32 training" % label, "value": round(args.batch * world * args.steps / el, 2),
+        prec = "fp32" if args.dtype == "f32" else "fp16 (mixed precision)"
+        print(json.dumps({"metric": "images/sec %s %s training" % (label, prec), "value": round(args.batch * world * args.steps / el, 2),
                           "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(el / args.steps * 1e3, 3), "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "%s fp32 training, batch=%d per GPU, forward+loss+backward+"
-                                                 "all-reduce+clipped Momentum" % (label, args.batch), "parallelism": "dp%d" % world},
+                          "ms_per_step": round(el / args.steps * 1e3, 3), "dtype": args.dtype, "data": "synthetic",
+                          "config": {"workload": "%s %s training, batch=%d per GPU, forward+loss+backward+"
+                                                 "all-reduce+clipped Momentum" % (label, prec, args.batch), "parallelism": "dp%d" % world},
+                          "skipped_steps": tr.skipped_steps, "loss_scale": tr.loss_scale,
                           "losses": {k: float(out[k]) for k in ("class_loss", "conf_loss", "bbox_loss")}}))
     if world > 1:
         dist.destroy_process_group()
