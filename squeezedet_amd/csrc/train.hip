@@ -104,7 +104,82 @@ __global__ void convert_scale_kernel(const S* __restrict__ src, D* __restrict__ 
   }
 }
 
-// max-pool backward, gather form (deterministic): an input cell receives dy of every window whose
+// max-pool backward for the nets' 3x3 / stride-2 pools, gather form (deterministic, no atomics).  In padded
+// coordinates (u, v) = (iy + pt, ix + pl) window (oy, ox) covers u in [2oy, 2oy+2]; a thread owns the 2x2 cell block
+// u in {2a, 2a+1}, v in {2b, 2b+1}, which only the four windows (a-1..a, b-1..b) touch: it finds each window's FIRST
+// maximum (row-major scan, tf.nn.max_pool's argmax) once and hands dy to whichever of its cells that is -- 36 loads
+// per block instead of the 81 of a per-cell search.  Windows are visited (a,b), (a,b-1), (a-1,b), (a-1,b-1): the
+// summation order of the generic kernel below, so the two agree bitwise.
+template <typename T>
+__global__ void maxpool3s2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                      int N, int H, int W, int C, int pt, int pl, int Ho, int Wo, int BA, int BB) {
+  typedef typename Vec16<T>::type V;
+  constexpr int EV = 16 / sizeof(T);
+  const int cvn = C / EV;
+  const size_t total = (size_t)N * BA * BB * cvn;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(idx % cvn);
+    size_t p = idx / cvn;
+    const int b = (int)(p % BB); p /= BB;
+    const int a = (int)(p % BA);
+    const int n = (int)(p / BA);
+    float g[4][EV];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < EV; ++e) g[q][e] = 0.f;
+#pragma unroll
+    for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+      for (int wx = 0; wx < 2; ++wx) {
+        const int oy = a - wy, ox = b - wx;
+        if (oy < 0 || oy >= Ho || ox < 0 || ox >= Wo) continue;
+        float best[EV];
+        int bpos[EV];   // 3 * (row in window) + (col in window)
+#pragma unroll
+        for (int e = 0; e < EV; ++e) { best[e] = -INFINITY; bpos[e] = -1; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int yy = 2 * oy - pt + r;
+          if (yy < 0 || yy >= H) continue;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const int xx = 2 * ox - pl + c;
+            if (xx < 0 || xx >= W) continue;
+            const V v = *reinterpret_cast<const V*>(x + ((((size_t)n * H + yy) * W + xx) * C + cv * EV));
+#pragma unroll
+            for (int e = 0; e < EV; ++e)
+              if ((float)v[e] > best[e]) { best[e] = (float)v[e]; bpos[e] = 3 * r + c; }
+          }
+        }
+        const V d = *reinterpret_cast<const V*>(dy + ((((size_t)n * Ho + oy) * Wo + ox) * C + cv * EV));
+        // this block's cells inside window (oy, ox): window rows 2*wy + {0,1}, cols 2*wx + {0,1} (those < 3)
+#pragma unroll
+        for (int du = 0; du < 2; ++du)
+#pragma unroll
+          for (int dv = 0; dv < 2; ++dv) {
+            const int r = 2 * wy + du, c = 2 * wx + dv;
+            if (r > 2 || c > 2) continue;
+#pragma unroll
+            for (int e = 0; e < EV; ++e)
+              if (bpos[e] == 3 * r + c) g[du * 2 + dv][e] += (float)d[e];
+          }
+      }
+#pragma unroll
+    for (int du = 0; du < 2; ++du)
+#pragma unroll
+      for (int dv = 0; dv < 2; ++dv) {
+        const int iy = 2 * a + du - pt, ix = 2 * b + dv - pl;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        V o;
+#pragma unroll
+        for (int e = 0; e < EV; ++e) o[e] = (T)g[du * 2 + dv][e];
+        *reinterpret_cast<V*>(dx + ((((size_t)n * H + iy) * W + ix) * C + cv * EV)) = o;
+      }
+  }
+}
+
+// max-pool backward, generic gather form (deterministic): an input cell receives dy of every window whose
 // FIRST maximum (row-major scan, as tf.nn.max_pool's argmax) it is.
 template <typename T>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
@@ -415,6 +490,18 @@ extern "C" int sqdet_maxpool_nhwc_bwd(const void* x, const void* dy, void* dx, i
                 "maxpool_bwd: bad arguments");
   const int Ho = out_size(h, k, stride, pad_mode), Wo = out_size(w, k, stride, pad_mode);
   const int pt = pad_before(h, k, stride, pad_mode), pl = pad_before(w, k, stride, pad_mode);
+  if (k == 3 && stride == 2) {
+    const int BA = (h + pt + 1) / 2, BB = (w + pl + 1) / 2;
+    const dim3 grid2(grid_for((size_t)n * BA * BB * (c / ev), 16384));
+    if (dtype == SQDET_F16)
+      hipLaunchKernelGGL(maxpool3s2_bwd_kernel<f16>, grid2, dim3(256), 0, as_stream(stream), (const f16*)x, (const f16*)dy,
+                         (f16*)dx, n, h, w, c, pt, pl, Ho, Wo, BA, BB);
+    else
+      hipLaunchKernelGGL(maxpool3s2_bwd_kernel<float>, grid2, dim3(256), 0, as_stream(stream), (const float*)x,
+                         (const float*)dy, (float*)dx, n, h, w, c, pt, pl, Ho, Wo, BA, BB);
+    SQDET_CHECK_HIP(hipGetLastError());
+    return SQDET_OK;
+  }
   const size_t total = (size_t)n * h * w * (c / ev);
   const dim3 grid(grid_for(total, 16384));
   if (dtype == SQDET_F16)

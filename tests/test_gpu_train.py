@@ -108,6 +108,15 @@ def test_relu_dropout_maxpool_backward():
         dx = ops.maxpool_bwd(x.detach().to(DEV), g.to(DEV), 3, 2, pad)
         torch.cuda.synchronize()
         np.testing.assert_allclose(dx.cpu().numpy(), x.grad.numpy(), rtol=1e-6, atol=1e-6)
+    # other window shapes run the generic gather kernel
+    for (H, W, size, stride, pad) in ((21, 30, 2, 2, "VALID"), (13, 17, 3, 1, "SAME")):
+        x = torch.from_numpy(rs.randn(2, H, W, 8).astype(np.float32)).requires_grad_(True)
+        yp = O.pooling_layer(x, size, stride, pad)
+        g = torch.from_numpy(rs.randn(*yp.shape).astype(np.float32))
+        yp.backward(g)
+        dx = ops.maxpool_bwd(x.detach().to(DEV), g.to(DEV), size, stride, pad)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(dx.cpu().numpy(), x.grad.numpy(), rtol=1e-6, atol=1e-6)
 
 
 def test_float16_elementwise_backward_ops():
