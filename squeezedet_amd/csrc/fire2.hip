@@ -15,7 +15,12 @@
 //     B  expand3x3 (9 taps) + expand1x1 (centre tap) from LDS, bias + ReLU, stores.
 //     One barrier per tile; the input loads have a whole phase B (+ the other workgroup) to land.
 // Accumulation order equals conv3x3_tile / conv1x1 (chunk-major, taps 0..8): results are bitwise
-// those of the unfused kernels.
+// those of the unfused kernels -- except the float16 S = 16 modules (fire2 / fire3), whose expand3x3 pairs two
+// taps per MFMA (PAIR below): equal up to float32 summation order.
+// Where a tile's time goes was measured per segment with -DSQDET_FIRE_TIMING + tools/fire_timing.py (s_memtime
+// deltas): of ~10 k cycles per tile of fire3+pool3 the largest single item was every wave WAITING TO ISSUE its 16
+// prefetch loads (~2800 cycles: eight waves reach that point together and the CU has one address pipe); the pooled
+// kernels therefore trickle the loads through the expand3x3's K-steps (SPREAD below).
 //
 // POOL variant (fire3 + pool3, fire5 + pool5 of SqueezeDet, nets/squeezeDet.py:49-57): the 3x3 / stride-2 SAME
 // max-pool that follows the module is taken IN REGISTERS and only the pooled tensor is written -- the
@@ -24,6 +29,8 @@
 // the stem's strips); a wave holds 5 rows: vertical 3-max on plain registers, horizontal 3-max by two DPP row
 // shifts (the C/D layout puts column j in lane j of a 16-lane DPP row), ReLU once on the pooled value,
 // out-of-image positions are -inf (TF SAME pooling never picks padding).
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace sqdet {
@@ -56,6 +63,15 @@ template <> __device__ __forceinline__ unsigned int pmax<float>(unsigned int a, 
   return r;
 }
 
+// -DSQDET_FIRE_TIMING (experiments only): per-wave s_memtime totals of the tile loop's segments, read back with
+// sqdet_debug_fire_timing (tools/fire_timing.py).  Compiled out otherwise.
+#ifdef SQDET_FIRE_TIMING
+__device__ unsigned long long g_fire_timing[2048 * 8];
+#define FT_MARK(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ft_acc[k] += now_ - ft_last; ft_last = now_; } while (0)
+#else
+#define FT_MARK(k) do {} while (0)
+#endif
+
 struct FireSArgs {
   const void* x;
   void* y;
@@ -71,9 +87,15 @@ struct FireSArgs {
 // RS = row split: the tile rows are divided among RS waves per cout pair (NWAVES = cout pairs x RS).  POOL: a wave
 // owns 4/RS pooled rows and computes the 2*(4/RS)+1 module rows under them (neighbouring waves both compute the row
 // they share); otherwise 8/RS rows.
-template <typename T, int NCHX, int NTS, int NWAVES, int PF, bool POOL, int RS>
+// PAIR (squeeze depth = half a 64-byte chunk, i.e. S = 16 in float16): two taps of the expand3x3 share one MFMA --
+// lane groups 0,1 carry tap 2p's 16 channels and groups 2,3 tap 2p+1's (the last pair's second half is zero) -- so
+// the 3x3 takes 5 K-steps instead of 9 half-empty ones, 25 instead of 45 B-fragment reads, and its resident weights
+// 40 instead of 72 registers.  (The two taps' products are then summed inside one MFMA instead of two: equal to the
+// three-conv path up to float32 summation order, no longer bitwise.)
+template <typename T, int NCHX, int NTS, int NWAVES, int PF, bool POOL, int RS, bool PAIR = false>
 __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs a) {   // 2 waves per SIMD: 256 VGPRs
   constexpr int KG = Tr<T>::KG;
+  constexpr int NT3 = PAIR ? 5 : 9;                  // K-steps of the expand3x3
   constexpr int KC = 4 * KG;
   constexpr int SHP = Geo<POOL>::HP, SBLK = Geo<POOL>::BLK, STILE = Geo<POOL>::TILE, LW = Geo<POOL>::LW;
   constexpr int MB = (SBLK + NWAVES - 1) / NWAVES;   // halo pixel blocks per wave in phase A
@@ -85,7 +107,8 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
   unsigned char* wsl = lds + 2 * STILE;              // squeeze weights [NCHX][NTS][64 lanes][16 B]
   unsigned char* w1l = wsl + NCHX * NTS * 1024;      // expand1x1 weights [E/16 tiles][64 lanes][16 B]
   float* bl = reinterpret_cast<float*>(w1l + NG * 4 * 1024);   // biases
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // in an SGPR: what follows from it is wave-uniform
   const int j = lane & 15, g = lane >> 4;
 
   // ---- one-time set-up ------------------------------------------------------------------------
@@ -125,13 +148,21 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
     wsrc[t] = ((c & 15) >> 2) * 64 + (4 * (c >> 4) + (c & 3)) + 16 * g;
   }
   const int group = cp >> 1;
-  i32x4 w3r[9][2];
+  i32x4 w3r[NT3][2];
   {
     const i32x4* p3 = reinterpret_cast<const i32x4*>(a.w3) + (size_t)group * 9 * 4 * 64;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      w3r[tap][0] = p3[tap * 4 * 64 + wsrc[0]];
-      w3r[tap][1] = p3[tap * 4 * 64 + wsrc[1]];
+    for (int p = 0; p < NT3; ++p) {
+      if constexpr (PAIR) {
+        // k-group g of the paired fragment = k-group (g & 1) of tap 2p + (g >> 1); tap 9 does not exist: zeros
+        const int tap = 2 * p + (g >> 1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          w3r[p][t] = tap < 9 ? p3[tap * 4 * 64 + wsrc[t] - 16 * g + 16 * (g & 1)] : i32x4{0, 0, 0, 0};
+      } else {
+        w3r[p][0] = p3[p * 4 * 64 + wsrc[0]];
+        w3r[p][1] = p3[p * 4 * 64 + wsrc[1]];
+      }
     }
   }
   const int cb = cp * 32 + g * 8;                     // this lane's 8 consecutive couts (of both expand convs)
@@ -154,27 +185,57 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
   // PF tiles of input are in flight (registers): xr[q] / inimg[q] belong to the tile processed q steps ahead.
   // Loads are issued unconditionally (an invalid tile turns every offset out of range: no traffic, zeros)
   // so the number of memory instructions per step is fixed and the waits stay exact.
+  // The prefetch is split in two: prep_loads computes one byte offset per 16-pixel block (out of range for pixels outside
+  // the image / the halo / a tile past the band: such loads return zeros, exactly the SAME padding, and move no data),
+  // issue_loads sends the block's NCHX 16-byte loads.  SPREAD (the pooled float16 kernels, whose epilogues store
+  // little): inside the tile loop the loads go out a few per K-step of the expand3x3 instead of all at once -- eight
+  // waves pushing 16 loads each through the CU's one address pipe at the same moment made every wave wait ~2800
+  // cycles of a 10 k-cycle tile (measured with -DSQDET_FIRE_TIMING): fire3+pool3 103 -> 97 us, fire5+pool5 68 -> 64 us.
+  // The unpooled kernels (whose phase B already carries 16 stores per wave) were 5 % SLOWER that way: they keep the
+  // loads in one batch ahead of the barrier; so do the float32 forms (no registers for the offsets).
+  constexpr bool SPREAD = POOL && sizeof(T) == 2;
+  constexpr unsigned OOBL = 0x80000000u;            // (+ c2 * 64 stays out of range: tensors are < 2 GiB)
+  constexpr int NLOADS = MB * NCHX, LPP = (NLOADS + NT3 - 1) / NT3;   // loads per K-step of the expand3x3
   i32x4 xr[PF][MB][NCHX];
   bool inimgs[PF][MB];
-  auto issue_loads = [&](int tl, bool tile_ok, i32x4 (&xq)[MB][NCHX], bool (&inimg)[MB]) {
+  unsigned offs[MB];
+  auto prep_loads = [&](int tl, bool tile_ok, bool (&inimg)[MB]) {
     int b = tl;
     const int tx = b % a.tiles_x; b /= a.tiles_x;
     const int ty = b % a.tiles_y;
     const int n = b / a.tiles_y;
+    const int hy0 = ty * Geo<POOL>::RSTEP - (POOL ? a.ptp : 0) - 1, hx0 = tx * Geo<POOL>::CSTEP - (POOL ? a.plp : 0) - 1;
+    // common case (wave-uniform): a real tile whose halo lies inside the image -- no per-pixel bounds tests
+    const bool allin = tile_ok && hy0 >= 0 && hy0 + Geo<POOL>::ROWS + 2 <= a.H && hx0 >= 0 && hx0 + SCOLS + 2 <= a.W;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       const int P = (wave + NWAVES * mb) * 16 + j;
       const int r = P / (SCOLS + 2), c = P - r * (SCOLS + 2);
-      const int iy = ty * Geo<POOL>::RSTEP - (POOL ? a.ptp : 0) - 1 + r, ix = tx * Geo<POOL>::CSTEP - (POOL ? a.plp : 0) - 1 + c;
-      inimg[mb] = tile_ok && P < SHP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const int iy = hy0 + r, ix = hx0 + c;
+      inimg[mb] = allin || (tile_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W);
       const unsigned base = (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + g * KG) * (int)sizeof(T));
-#pragma unroll
-      for (int c2 = 0; c2 < NCHX; ++c2)
-        xq[mb][c2] = __builtin_amdgcn_raw_buffer_load_b128(rx, (inimg[mb] && c2 * 4 + g < a.x_pieces) ? base + c2 * 64 : OOB, 0, 0);
+      offs[mb] = (inimg[mb] && P < SHP) ? base : OOBL;
     }
   };
+  auto issue_loads = [&](int first, int last, i32x4 (&xq)[MB][NCHX]) {   // (Cin fills whole 64-byte chunks: stream_shape)
+#pragma unroll
+    for (int l = 0; l < NLOADS; ++l)
+      if (l >= first && l < last) xq[l / NCHX][l % NCHX] = __builtin_amdgcn_raw_buffer_load_b128(rx, offs[l / NCHX] + (l % NCHX) * 64, 0, 0);
+  };
 
+#ifdef SQDET_FIRE_TIMING
+  unsigned long long ft_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ft_last = __builtin_amdgcn_s_memtime();
+#endif
   auto step = [&](int tile, i32x4 (&xq)[MB][NCHX], bool (&inimg)[MB], unsigned char* sqb) {
+    FT_MARK(7);
+    // coordinates of THIS tile (all wave-uniform)
+    int b = tile;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y;
+    const int n = b / a.tiles_y;
+    const int oy0 = ty * Geo<POOL>::RSTEP - (POOL ? a.ptp : 0), ox0 = tx * Geo<POOL>::CSTEP - (POOL ? a.plp : 0);
+    // the whole halo inside the image (3 tiles out of 4): no SAME-padding select on the squeeze tile
+    const bool haloin = oy0 >= 1 && oy0 + Geo<POOL>::ROWS + 1 <= a.H && ox0 >= 1 && ox0 + SCOLS + 1 <= a.W;
     // ---------------- phase A: squeeze on the halo, from the prefetched fragments ----------------
     {
       f32x4 acc[MB][NTS];
@@ -192,40 +253,50 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
 #pragma unroll
           for (int t = 0; t < NTS; ++t) mma16<T>(acc[mb][t], af[t], xq[mb][c]);
       }
+      FT_MARK(0);
+      auto store_squeeze = [&](auto pad_t) {
 #pragma unroll
-      for (int t = 0; t < NTS; ++t) {
-        const int ch0 = g * 4 * NTS + 4 * t;
-        if (ch0 < a.S) {
-          const f32x4 biass = *reinterpret_cast<const f32x4*>(bl + 2 * a.E + ch0);
-          const int q = ch0 / KG;
-          const int sub = (ch0 - q * KG) * (int)sizeof(T);
+        for (int t = 0; t < NTS; ++t) {
+          const int ch0 = g * 4 * NTS + 4 * t;
+          if (ch0 < a.S) {
+            const f32x4 biass = *reinterpret_cast<const f32x4*>(bl + 2 * a.E + ch0);
+            const int q = ch0 / KG;
+            const int sub = (ch0 - q * KG) * (int)sizeof(T);
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb) {
-            const int P = (wave + NWAVES * mb) * 16 + j;
-            if (P < SHP) {
-              f32x4 v = acc[mb][t] + biass;
-              v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-              if (!inimg[mb]) v = f32x4{0.f, 0.f, 0.f, 0.f};   // SAME padding of the squeeze tensor
-              const int hr = P / (SCOLS + 2);
-              const int PL = hr * LW + (P - hr * (SCOLS + 2));   // position in the LDS tile (row pitch LW)
-              store4<T>(reinterpret_cast<T*>(sqb + PL * 64 + ((q ^ ((PL >> 1) & 3)) << 4) + sub), v);
+            for (int mb = 0; mb < MB; ++mb) {
+              const int P = (wave + NWAVES * mb) * 16 + j;
+              if (P < SHP) {
+                f32x4 v = acc[mb][t] + biass;
+                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                if constexpr (decltype(pad_t)::value)
+                  if (!inimg[mb]) v = f32x4{0.f, 0.f, 0.f, 0.f};   // SAME padding of the squeeze tensor
+                const int hr = P / (SCOLS + 2);
+                const int PL = hr * LW + (P - hr * (SCOLS + 2));   // position in the LDS tile (row pitch LW)
+                store4<T>(reinterpret_cast<T*>(sqb + PL * 64 + ((q ^ ((PL >> 1) & 3)) << 4) + sub), v);
+              }
             }
           }
         }
-      }
+      };
+      if (haloin) store_squeeze(std::false_type{});
+      else store_squeeze(std::true_type{});
     }
-    // output coordinates of THIS tile (before xr / inimg are reused for the next one)
-    int b = tile;
-    const int tx = b % a.tiles_x; b /= a.tiles_x;
-    const int ty = b % a.tiles_y;
-    const int n = b / a.tiles_y;
     // ---------------- prefetch: the halo of the tile PF steps ahead, into the registers just consumed ----------------
-    issue_loads(tile + PF * nl, tile + PF * nl < band_end, xq, inimg);
+    FT_MARK(1);
+    // ---------------- prefetch: addresses of the halo of the tile PF steps ahead (its loads go out during phase B,
+    // into the registers phase A has just consumed) ----------------
+    prep_loads(tile + PF * nl, tile + PF * nl < band_end, inimg);
+    if constexpr (!SPREAD) issue_loads(0, NLOADS, xq);
+    FT_MARK(2);
     __syncthreads();
+    FT_MARK(3);
     // ---------------- phase B: expand3x3, then expand1x1, on rows [m0, m0 + MT) ----------------
-    const int oy0 = ty * Geo<POOL>::RSTEP - (POOL ? a.ptp : 0), ox0 = tx * Geo<POOL>::CSTEP - (POOL ? a.plp : 0);
     const int ox = ox0 + j;
-    auto epilogue = [&](f32x4 (&acc)[MT][2], const float* bias_lds, int coff) {
+    // INS (wave-uniform): every module row and column this wave produces lies inside the image -- the common case --
+    // so the per-element edge selects (a third of the epilogue's VALU work) are compiled out of that path
+    const bool inside = oy0 + m0 >= 0 && oy0 + m0 + MT <= a.H && ox0 >= 0 && ox0 + SCOLS <= a.W;
+    auto epilogue = [&](f32x4 (&acc)[MT][2], const float* bias_lds, int coff, auto ins_t) {
+      constexpr bool INS = decltype(ins_t)::value;
       f32x4 bias[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) bias[t] = *reinterpret_cast<const f32x4*>(bias_lds + cb + t * 4);
@@ -234,7 +305,7 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
         const unsigned yrow = (unsigned)(a.W * ctot * (int)sizeof(T));
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          const unsigned off = (ox < a.W && oy0 + m0 + m < a.H) ? off0 + m * yrow : OOB;   // OOB stores are dropped
+          const unsigned off = (INS || (ox < a.W && oy0 + m0 + m < a.H)) ? off0 + m * yrow : OOB;   // OOB stores are dropped
           f32x4 v[2];
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
@@ -258,7 +329,7 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           const int oy = oy0 + m0 + m;
-          const bool ok = col_ok && oy >= 0 && oy < a.H;
+          const bool ok = INS || (col_ok && oy >= 0 && oy < a.H);
           const f32x4 v0 = acc[m][0] + bias[0], v1 = acc[m][1] + bias[1];
           if constexpr (sizeof(T) == 2) {
             const f16x8 h = {(f16)v0[0], (f16)v0[1], (f16)v0[2], (f16)v0[3], (f16)v1[0], (f16)v1[1], (f16)v1[2], (f16)v1[3]};
@@ -308,21 +379,34 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
       int jo = j, go = g;
       asm volatile("" : "+v"(jo), "+v"(go));
       auto load_tap = [&](int tap, i32x4 (&bf)[MT]) {
-        const int dy = tap / 3, dx = tap - dy * 3;
-        const int P0 = dy * LW + jo + dx;
-        const unsigned char* base = sqb + (P0 + LW * m0) * 64 + ((go ^ ((P0 >> 1) & 3)) << 4);   // LW*(m0+m)/2 = 0 mod 4
+        int P0, piece;
+        if constexpr (PAIR) {
+          // `tap` is the pair index: lane groups 0,1 read pieces 0,1 of tap 2p's pixel, groups 2,3 those of tap 2p+1's;
+          // past the ninth tap they read the (always zero) padding pieces 2,3 of tap 8's pixel
+          const int ta = 2 * tap, tb = 2 * tap + 1 < 9 ? 2 * tap + 1 : 8;
+          const int ca = (ta / 3) * LW + ta % 3, cbb = (tb / 3) * LW + tb % 3;
+          const bool hi = go >= 2;
+          P0 = jo + (hi ? cbb : ca);
+          piece = (2 * tap + 1 < 9) ? (go & 1) : go;
+        } else {
+          const int dy = tap / 3, dx = tap - dy * 3;
+          P0 = dy * LW + jo + dx;
+          piece = go;
+        }
+        const unsigned char* base = sqb + (P0 + LW * m0) * 64 + ((piece ^ ((P0 >> 1) & 3)) << 4);   // LW*(m0+m)/2 = 0 mod 4
 #pragma unroll
         for (int m = 0; m < MT; ++m) bf[m] = *reinterpret_cast<const i32x4*>(base + m * (LW * 64));
       };
-      constexpr bool DB = MB * NCHX * PF < 16 || !POOL;   // (the pooled fire3 shape has no registers left for the second buffer)
+      constexpr bool DB = PAIR || MB * NCHX * PF < 16 || !POOL;   // (the unpaired pooled fire3 shape has no registers left for the second buffer)
       if constexpr (DB) {
         i32x4 bfa[MT], bfb[MT];
         load_tap(0, bfa);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < NT3; ++tap) {
           i32x4 (&cur)[MT] = (tap & 1) ? bfb : bfa;
           i32x4 (&nxt)[MT] = (tap & 1) ? bfa : bfb;
-          if (tap + 1 < 9) load_tap(tap + 1, nxt);
+          if (tap + 1 < NT3) load_tap(tap + 1, nxt);
+          if constexpr (SPREAD) issue_loads(tap * LPP, (tap + 1) * LPP, xq);
 #pragma unroll
           for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -331,9 +415,10 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
         }
       } else {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < NT3; ++tap) {
           i32x4 bf[MT];
           load_tap(tap, bf);
+          if constexpr (SPREAD) issue_loads(tap * LPP, (tap + 1) * LPP, xq);
 #pragma unroll
           for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -341,7 +426,10 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      epilogue(acc3, bl + a.E, a.E);                  // expand3x3 -> channels [E, 2E)
+      FT_MARK(4);
+      if (inside) epilogue(acc3, bl + a.E, a.E, std::true_type{});   // expand3x3 -> channels [E, 2E)
+      else epilogue(acc3, bl + a.E, a.E, std::false_type{});
+      FT_MARK(5);
     }
     {
       f32x4 acc1[MT][2];
@@ -359,12 +447,18 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
           mma16<T>(acc1[m][t], w1f[t], bf);
         }
       }
-      epilogue(acc1, bl, 0);                          // expand1x1 -> channels [0, E)
+      if (inside) epilogue(acc1, bl, 0, std::true_type{});            // expand1x1 -> channels [0, E)
+      else epilogue(acc1, bl, 0, std::false_type{});
+      FT_MARK(6);
     }
   };
 
-  issue_loads(tile, tile < band_end, xr[0], inimgs[0]);
-  if constexpr (PF == 2) issue_loads(tile + nl, tile + nl < band_end, xr[1], inimgs[1]);
+  prep_loads(tile, tile < band_end, inimgs[0]);
+  issue_loads(0, NLOADS, xr[0]);
+  if constexpr (PF == 2) {
+    prep_loads(tile + nl, tile + nl < band_end, inimgs[1]);
+    issue_loads(0, NLOADS, xr[1]);
+  }
   __syncthreads();                                    // squeeze weights / padding / biases visible
   if constexpr (PF == 1) {
     int buf = 0;
@@ -378,6 +472,10 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
       tile += nl;
     }
   }
+#ifdef SQDET_FIRE_TIMING
+  if (lane == 0 && blockIdx.x * NWAVES + wave < 2048)
+    for (int k = 0; k < 8; ++k) g_fire_timing[(blockIdx.x * NWAVES + wave) * 8 + k] = ft_acc[k];
+#endif
 }
 
 static bool stream_shape(int cin, int s, int e1, int e3, int dtype, int* nchx, int* nts, int* nwaves) {
@@ -390,7 +488,7 @@ static bool stream_shape(int cin, int s, int e1, int e3, int dtype, int* nchx, i
   if (!(gs.nt == 1 || gs.nt == 2)) return false;
   // input fragments stay in registers: 2 or 4 chunks with two tiles in flight, 8 chunks (8-wave form only) with one
   if (!(gs.nchunk == 2 || gs.nchunk == 4 || (gs.nchunk == 8 && g1.ngroups == 2))) return false;
-  if ((cin * esz) % 16 != 0 || (s * esz) % 16 != 0 || s % 4 != 0) return false;
+  if ((cin * esz) % 64 != 0 || (s * esz) % 16 != 0 || s % 4 != 0) return false;   // the input fills whole 64-byte chunks
   *nchx = gs.nchunk; *nts = gs.nt; *nwaves = 4 * g1.ngroups;
   return true;
 }
@@ -408,6 +506,19 @@ static void launch_stream(const FireSArgs& a, hipStream_t st) {
   if (grid > (a.ntiles + 7) / 8 * 8) grid = (a.ntiles + 7) / 8 * 8;
   // two tiles of input in flight when their fragments fit the register budget next to the resident weights
   constexpr int MBH = (Geo<POOL>::BLK + NWAVES - 1) / NWAVES;
+  // squeeze depth of half a chunk (S = 16 in float16): the tap-paired expand3x3 ("dbg" 16 keeps the unpaired form for A/B)
+  if constexpr (sizeof(T) == 2 && NTS == 1 && RS == 2) {
+    if (a.S * (int)sizeof(T) == 32 && tune(TUNE_DBG) != 16) {
+      if constexpr (2 * MBH * NCHX <= 16) {
+        if (tune(TUNE_DBG) != 8) {
+          hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 2, POOL, RS, true>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
+          return;
+        }
+      }
+      hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 1, POOL, RS, true>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
+      return;
+    }
+  }
   if constexpr (2 * MBH * NCHX <= 16) {   // (these compile without spills; a spill in the tile loop drains vmcnt)
     if (tune(TUNE_DBG) != 8) {
       hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 2, POOL, RS>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
@@ -467,6 +578,8 @@ int fire_stream_launch_ex(const void* x, const void* ws, const float* bs, const 
   const long xb = (long)n * h * w * cin * esz, yb = pool ? (long)n * a.Hp * a.Wp * 2 * e1 * esz : (long)n * h * w * 2 * e1 * esz;
   if (xb >= (1L << 31) || yb >= (1L << 31)) return SQDET_OK;   // 32-bit buffer offsets
   a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb;
+  if (tune(TUNE_DBG) == 40) a.x_bytes = 16;   // EXPERIMENT: every input load out of range (no read traffic)
+  if (tune(TUNE_DBG) == 41) a.y_bytes = 16;   // EXPERIMENT: every store dropped (no write traffic)
   bool ok;
   if (pool) ok = dtype == SQDET_F16 ? dispatch_stream<f16, true>(a, nchx, nts, nwaves, st) : dispatch_stream<float, true>(a, nchx, nts, nwaves, st);
   else ok = dtype == SQDET_F16 ? dispatch_stream<f16, false>(a, nchx, nts, nwaves, st) : dispatch_stream<float, false>(a, nchx, nts, nwaves, st);
@@ -477,3 +590,9 @@ int fire_stream_launch_ex(const void* x, const void* ws, const float* bs, const 
 }
 
 }  // namespace sqdet
+
+#ifdef SQDET_FIRE_TIMING
+extern "C" int sqdet_debug_fire_timing(unsigned long long* host, int count) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sqdet::g_fire_timing), sizeof(unsigned long long) * count);
+}
+#endif

@@ -144,6 +144,18 @@ def test_conv2d_concat_offset_and_fire(dtype):
     np.testing.assert_allclose(got, ref, **tol)
 
 
+def _same_as_unfused(got, want, s, dtype, what):
+    """Fused launches are compared BITWISE with the generic kernel path, except the float16 squeeze-depth-16 modules
+    (fire2 / fire3): their streaming kernel sums two taps of the expand3x3 inside one MFMA (fire2.hip, PAIR), which
+    equals the three-conv path up to float32 summation order -- at most one float16 ulp after rounding, and rarely."""
+    if dtype == "fp16" and s == 16:
+        a, b = got.float().cpu().numpy(), want.float().cpu().numpy()
+        np.testing.assert_allclose(a, b, rtol=2 ** -9, atol=2 ** -12, err_msg=what)
+        assert (a != b).mean() < 0.02, what
+    else:
+        assert torch.equal(got, want), what
+
+
 FIRE_CASES = [("fire2", 64, 16, 64, 19, 37), ("fire3", 128, 16, 64, 9, 33), ("fire4", 128, 32, 128, 17, 20),
               ("fire5", 256, 32, 128, 8, 16), ("fire6", 256, 48, 192, 24, 78), ("fire7", 384, 48, 192, 11, 19),
               ("fire8", 384, 64, 256, 10, 17), ("fire9", 512, 64, 256, 9, 31), ("fire10", 512, 96, 384, 24, 78),
@@ -178,7 +190,7 @@ def test_fused_fire_module_parity(case, dtype):
     y_sep = ops.fire(*args)
     ops.set_option("fire_fuse", 0)
     torch.cuda.synchronize()
-    assert torch.equal(y_fused, y_sep), "fused fire differs from squeeze -> expand1x1 / expand3x3"
+    _same_as_unfused(y_fused, y_sep, s, dtype, "fused fire differs from squeeze -> expand1x1 / expand3x3")
     tol = dict(rtol=1e-3, atol=1e-4) if dtype == "fp32" else dict(rtol=2 ** -8, atol=2e-3)
     np.testing.assert_allclose(y_fused.float().cpu().numpy(), ref, **tol)
 
@@ -211,7 +223,7 @@ def test_fire_plus_maxpool_one_launch(case, dtype):
     ops.set_option("fire_fuse", 0)
     torch.cuda.synchronize()
     assert tuple(y.shape) == (N, -(-H // 2), -(-W // 2), 2 * e)
-    assert torch.equal(y, want), "fire+pool in one launch differs from fire -> pool"
+    _same_as_unfused(y, want, s, dtype, "fire+pool in one launch differs from fire -> pool")
 
 
 POOL_CASES = [(2, 37, 53, 64, 3, 2, "SAME"), (1, 188, 621, 8, 3, 2, "SAME"), (1, 47, 156, 16, 3, 2, "SAME"),
