@@ -14,6 +14,10 @@
 //     alternate over the expand3x3 tiles (9 taps) and the expand1x1 tiles (centre tap), weights
 //     prefetched one step ahead; results go to their channel range of the concat tensor.
 // Numerics are identical to the unfused kernels (same chunk order, same MFMA, same roundings).
+// Measured per segment (-DSQDET_FIRE_TIMING + tools/ff_timing.py, fire10 at batch 32): phase A 31 % of a wave's
+// life (12 % waiting for chunk loads / the per-chunk barrier), the expand K loops 52 % (the matrix pipe ~75 % busy
+// inside them), weight refill + epilogue stores 17 %.  Starting the second workgroup of every CU late, so that its
+// phase A would sit under the first one's phase B, was tried and is monotonically SLOWER (+4 us per 16 k cycles).
 #include "conv_common.h"
 
 namespace sqdet {
@@ -42,6 +46,14 @@ struct FireArgs {
 // blocks per cout item -- the small fire modules have only 2-4 cout items, which left waves idle or
 // paired one 9-tap item with one 1-tap item; with MT = 4 every wave gets the same work and the
 // accumulators halve, so 4 workgroups fit on a CU instead of 2).
+// -DSQDET_FIRE_TIMING (experiments only): per-wave s_memtime totals of the kernel's segments (tools/fire_timing.py)
+#ifdef SQDET_FIRE_TIMING
+__device__ unsigned long long g_ff_timing[2048 * 8];
+#define FFT_MARK(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ft_acc[k] += now_ - ft_last; ft_last = now_; } while (0)
+#else
+#define FFT_MARK(k) do {} while (0)
+#endif
+
 template <typename T, int NTS, int NTW, int MT>
 __global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused(FireArgs a) {
   constexpr int KG = Tr<T>::KG;
@@ -49,6 +61,9 @@ __global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
+#ifdef SQDET_FIRE_TIMING
+  unsigned long long ft_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ft_last = __builtin_amdgcn_s_memtime();
+#endif
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (own L2 each); every XCD gets a contiguous band of
   // tiles so the halos shared by neighbouring tiles are fetched into ONE L2 instead of up to eight.
   int b = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));   // gridDim.x is a multiple of 8
@@ -120,6 +135,7 @@ __global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int t = 0; t < NTS; ++t) acc[mb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    FFT_MARK(0);
 #pragma unroll 1
     for (int c0 = 0; c0 < a.nch_x; c0 += PD) {
 #pragma unroll
@@ -133,6 +149,7 @@ __global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused
         else if (later == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | ((1 * PER) & 0xF) | (((1 * PER) >> 4) << 14));
         else __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();                                  // every wave's share of the weights is in the ring
+        FFT_MARK(1);
         const unsigned char* slot = wring + (c % RS) * (NTS * 1024);
         i32x4 af[NTS];
 #pragma unroll
@@ -142,6 +159,7 @@ __global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused
 #pragma unroll
           for (int t = 0; t < NTS; ++t) mma16<T>(acc[mb][t], af[t], xq[u][mb]);
         if (c + PD < a.nch_x) issue(c + PD, xq[u]);
+        FFT_MARK(2);
       }
     }
     // bias + ReLU -> storage type -> LDS squeeze tile; lane = pixel P, channels g*4*NTS + 4t .. +4
@@ -164,8 +182,10 @@ __global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused
         }
       }
     }
+    FFT_MARK(3);
   }
   __syncthreads();
+  FFT_MARK(4);
 
   // ---------------------------------------------------------------- phase B: expand3x3 + expand1x1
   // On the small late maps the whole grid is ONE wave of workgroups: the kernel time is a single workgroup's
@@ -260,6 +280,7 @@ __global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused
         }
       }
     }
+    FFT_MARK(5);
     if (witem + 4 < nw) fill(item_of(witem + 4));   // the ring is empty here: next item's first fragments
     // epilogue: bias + ReLU, 4*NTW consecutive channels per lane into the concat tensor
     const int cout = it.is3 ? a.E3 : a.E1;
@@ -289,7 +310,12 @@ __global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused
         store_couts<T, NTW>(dst, v, nt_valid);
       }
     }
+    FFT_MARK(6);
   }
+#ifdef SQDET_FIRE_TIMING
+  if (lane == 0 && blockIdx.x * 4 + wave < 2048)
+    for (int k = 0; k < 8; ++k) g_ff_timing[(blockIdx.x * 4 + wave) * 8 + k] = ft_acc[k];
+#endif
 }
 
 template <typename T, int NTS, int NTW, int MT>
@@ -394,3 +420,9 @@ int fire_fused_launch(const void* x, const void* ws, const float* bs, const void
 }
 
 }  // namespace sqdet
+
+#ifdef SQDET_FIRE_TIMING
+extern "C" int sqdet_debug_ff_timing(unsigned long long* host, int count) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sqdet::g_ff_timing), sizeof(unsigned long long) * count);
+}
+#endif
