@@ -159,6 +159,7 @@ def main(argv=None):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    t_issued = time.perf_counter() - t0      # host side done enqueueing (diagnostic: host-bound if ~ elapsed)
     torch.cuda.synchronize()
     barrier(world, device)
     elapsed = time.perf_counter() - t0
@@ -183,10 +184,10 @@ def main(argv=None):
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
         # HBM bytes per launch from the PMC counters: not measurable inside this process; taken from the
         # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-        # (profiles/r01_g_hbm_traffic_pmc.json: 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), else null
+        # (profiles/r01_j_hbm_traffic_pmc.json: 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), else null
         roof["traffic"] = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_g_hbm_traffic_pmc.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r01_j_hbm_traffic_pmc.json")) as fh:
                 pmc = json.load(fh)["by_layer"]
             if args.dtype == "fp16" and (args.batch, args.height, args.width) == (32, 375, 1242):
                 roof["traffic"] = pmc.get(name)
@@ -220,6 +221,8 @@ def main(argv=None):
                                    % (args.dtype, args.batch, args.width, args.height),
                        "global_batch": args.batch * world, "parallelism": "dp%d (independent image shards, no collective)" % world},
             "roofline": roof,
+            "host_issue_ms_per_step": round(t_issued / args.steps * 1e3, 4),
+            "forward_launches_ms_sum": round(float(sum(ms0)), 4),
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args, mc, params, args.cpu_baseline_seconds)
