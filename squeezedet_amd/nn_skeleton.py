@@ -9,6 +9,8 @@ executes them on the GPU.  There is no CPU execution path.
 import collections
 import contextlib
 
+import os
+
 import numpy as np
 import torch
 
@@ -401,13 +403,55 @@ class ModelSkeleton:
         interpret_output + filter_prediction (a few dozen microseconds of latency-bound work on 32 workgroups)
         run on a side HIP stream behind an event, so the NEXT batch's forward starts while this batch's boxes
         are being decoded and suppressed.  Returns filter_prediction_batch's tuple; the tensors are produced on
-        `self.post_stream` -- synchronise with it (or the device) before reading them."""
+        `self.post_stream` -- synchronise with it (or the device) before reading them.
+
+        Models with a native plan run it on TWO static sets of buffers (preds, det_*, outputs) used alternately, with
+        explicit events in both directions -- no allocation per step.  (Per-step torch allocations were the first
+        version: preds had to be record_stream'ed for the side stream, so the caching allocator could not reuse a
+        block until its event had completed; a host running a hundred steps ahead then asked for a hundred preds
+        buffers, i.e. hipMalloc inside the serving loop -- the same binary measured 0.77 or 1.0-1.2 ms per step from
+        one run to the next.)  The returned tensors are those of the slot: valid until the second-next call."""
         mc = self.mc
         if getattr(self, "post_stream", None) is None:
-            self.post_stream = torch.cuda.Stream(device=self.device)
+            # high priority: the two small post-processing kernels are dispatched as soon as CUs free up at a kernel
+            # boundary of the forward instead of waiting for its queue to drain
+            self.post_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("SQDET_POST_PRIORITY", "-1")))
             self._post_event = torch.cuda.Event()
+            self._pipe = None
+        cur = torch.cuda.current_stream()
+        if self.NATIVE_ARCH is not None:
+            x = self._to_input(images)
+            B = int(x.shape[0])
+            plan = self._native_plan(B)
+            if self._pipe is None or self._pipe["batch"] != B:
+                A = mc.ANCHORS
+                M = mc.TOP_N_DETECTION if 0 < mc.TOP_N_DETECTION < A else min(A, 1024)
+                f32, dev = torch.float32, self.device
+                mk = lambda: dict(preds=torch.empty((B, plan.gh, plan.gw, plan.out_ch), dtype=self.dtype, device=dev),
+                                  det=(torch.empty((B, A, 4), dtype=f32, device=dev), torch.empty((B, A), dtype=f32, device=dev),
+                                       torch.empty((B, A), dtype=torch.int64, device=dev)),
+                                  out=(torch.empty((B, M, 4), dtype=f32, device=dev), torch.empty((B, M), dtype=f32, device=dev),
+                                       torch.empty((B, M), dtype=torch.int32, device=dev), torch.empty((B, M), dtype=torch.int32, device=dev),
+                                       torch.empty((B,), dtype=torch.int32, device=dev)),
+                                  fwd_done=torch.cuda.Event(), post_done=torch.cuda.Event(), used=False)
+                self._pipe = dict(batch=B, slots=[mk(), mk()], k=0)
+            s = self._pipe["slots"][self._pipe["k"] & 1]
+            self._pipe["k"] += 1
+            if s["used"]:
+                cur.wait_event(s["post_done"])          # the side stream has finished reading this slot's preds
+            plan.forward(x, s["preds"])
+            s["fwd_done"].record(cur)
+            with torch.cuda.stream(self.post_stream):
+                self.post_stream.wait_event(s["fwd_done"])
+                ops.interpret_output(s["preds"], self.anchors_f32(), mc.CLASSES, mc.ANCHOR_PER_GRID, mc.IMAGE_WIDTH,
+                                     mc.IMAGE_HEIGHT, mc.EXP_THRESH, out=s["det"])
+                ops.filter_prediction(s["det"][0], s["det"][1], s["det"][2], mc.CLASSES, mc.TOP_N_DETECTION, mc.NMS_THRESH,
+                                      mc.PROB_THRESH, out=s["out"])
+                s["post_done"].record(self.post_stream)
+            s["used"] = True
+            return s["out"]
         (preds,) = self.run([self.preds], {self.image_input: images})
-        self._post_event.record(torch.cuda.current_stream())
+        self._post_event.record(cur)
         with torch.cuda.stream(self.post_stream):
             self.post_stream.wait_event(self._post_event)
             boxes, probs, cls = ops.interpret_output(preds, self.anchors_f32(), mc.CLASSES, mc.ANCHOR_PER_GRID, mc.IMAGE_WIDTH,

@@ -146,10 +146,11 @@ def fire_maxpool(x, p_s, b_s, p_e1, b_e1, p_e3, b_e3):
 
 # ---------------------------------------------------------------- post-processing
 def interpret_output(preds, anchors_f32, classes, anchors_per_grid, img_w, img_h, exp_thresh=1.0,
-                     with_class_probs=False):
+                     with_class_probs=False, out=None):
     """_add_interpretation_graph (nn_skeleton.py:142-283).  preds [N,gh,gw,K*(C+5)] f16/f32;
     anchors_f32 [A,4] float32 device tensor.  Returns det_boxes [N,A,4] f32, det_probs [N,A] f32,
-    det_class [N,A] int64 (+ pred_class_probs [N,A,C], pred_conf [N,A] when asked)."""
+    det_class [N,A] int64 (+ pred_class_probs [N,A,C], pred_conf [N,A] when asked).  out: optional preallocated
+    (det_boxes, det_probs, det_class) to write into (serving loops: no allocation per step)."""
     n, gh, gw, ch = [int(v) for v in preds.shape]
     if ch != anchors_per_grid * (classes + 5):
         raise _lib.SqdetError("interpret_output: %d channels != %d*(%d+5)" % (ch, anchors_per_grid, classes))
@@ -157,9 +158,14 @@ def interpret_output(preds, anchors_f32, classes, anchors_per_grid, img_w, img_h
     if tuple(anchors_f32.shape) != (A, 4):
         raise _lib.SqdetError("interpret_output: anchors must be [%d,4]" % A)
     dev = preds.device
-    boxes = torch.empty((n, A, 4), dtype=torch.float32, device=dev)
-    probs = torch.empty((n, A), dtype=torch.float32, device=dev)
-    cls = torch.empty((n, A), dtype=torch.int64, device=dev)
+    if out is not None:
+        boxes, probs, cls = out
+        if tuple(boxes.shape) != (n, A, 4) or tuple(probs.shape) != (n, A) or tuple(cls.shape) != (n, A) or cls.dtype != torch.int64:
+            raise _lib.SqdetError("interpret_output: out tensors must be [N,A,4] f32, [N,A] f32, [N,A] int64")
+    else:
+        boxes = torch.empty((n, A, 4), dtype=torch.float32, device=dev)
+        probs = torch.empty((n, A), dtype=torch.float32, device=dev)
+        cls = torch.empty((n, A), dtype=torch.int64, device=dev)
     pcp = torch.empty((n, A, classes), dtype=torch.float32, device=dev) if with_class_probs else None
     pconf = torch.empty((n, A), dtype=torch.float32, device=dev) if with_class_probs else None
     check(lib().sqdet_interpret_output(_dev(preds, "preds"), _dev(anchors_f32, "anchors", torch.float32),
@@ -174,21 +180,26 @@ def interpret_output(preds, anchors_f32, classes, anchors_per_grid, img_w, img_h
     return boxes, probs, cls
 
 
-def filter_prediction(boxes, probs, cls, classes, top_n, nms_thresh, prob_thresh, max_out=None):
+def filter_prediction(boxes, probs, cls, classes, top_n, nms_thresh, prob_thresh, max_out=None, out=None):
     """Batched ModelSkeleton.filter_prediction (nn_skeleton.py:696-734).  boxes [N,A,4] f32,
     probs [N,A] f32, cls [N,A] int64 (device).  Returns device tensors
     (out_boxes [N,M,4], out_probs [N,M], out_cls [N,M] i32, out_index [N,M] i32, out_count [N] i32)
-    with rows [0,count) valid, ordered by class then descending prob."""
+    with rows [0,count) valid, ordered by class then descending prob.  out: optional preallocated tuple of those five."""
     n, A = int(probs.shape[0]), int(probs.shape[1])
     use_topn = 0 < top_n < A
     if max_out is None:
         max_out = top_n if use_topn else min(A, 1024)
     dev = probs.device
-    ob = torch.empty((n, max_out, 4), dtype=torch.float32, device=dev)
-    op = torch.empty((n, max_out), dtype=torch.float32, device=dev)
-    oc = torch.empty((n, max_out), dtype=torch.int32, device=dev)
-    oi = torch.empty((n, max_out), dtype=torch.int32, device=dev)
-    cnt = torch.empty((n,), dtype=torch.int32, device=dev)
+    if out is not None:
+        ob, op, oc, oi, cnt = out
+        if tuple(ob.shape) != (n, max_out, 4) or tuple(op.shape) != (n, max_out) or tuple(cnt.shape) != (n,):
+            raise _lib.SqdetError("filter_prediction: out tensors do not match [N,%d,...]" % max_out)
+    else:
+        ob = torch.empty((n, max_out, 4), dtype=torch.float32, device=dev)
+        op = torch.empty((n, max_out), dtype=torch.float32, device=dev)
+        oc = torch.empty((n, max_out), dtype=torch.int32, device=dev)
+        oi = torch.empty((n, max_out), dtype=torch.int32, device=dev)
+        cnt = torch.empty((n,), dtype=torch.int32, device=dev)
     check(lib().sqdet_filter_prediction(_dev(boxes, "boxes", torch.float32), _dev(probs, "probs", torch.float32),
                                         _dev(cls, "cls", torch.int64), _dev(ob, "ob"), _dev(op, "op"), _dev(oc, "oc"),
                                         _dev(oi, "oi"), _dev(cnt, "cnt"), n, A, int(classes), int(top_n), int(max_out),

@@ -169,8 +169,13 @@ def test_pipelined_step_equals_sequential():
         b, p, c = m.detect(x)
         seq.append([t.clone() for t in m.filter_prediction_batch(b, p, c)])
     torch.cuda.synchronize()
-    outs = [m.detect_filter_pipelined(x) for x in xs]          # three steps in flight, no sync in between
+    outs = []
+    for x in xs + xs:                                           # six steps in flight, no sync in between
+        out = m.detect_filter_pipelined(x)                      # (the slot's tensors: valid until the second-next call)
+        with torch.cuda.stream(m.post_stream):
+            outs.append([t.clone() for t in out])               # snapshot, stream-ordered behind the step's NMS
     torch.cuda.synchronize()
+    seq = seq + seq
     for got, want in zip(outs, seq):
         n = want[4].cpu().numpy()
         assert np.array_equal(got[4].cpu().numpy(), n)
