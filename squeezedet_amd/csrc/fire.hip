@@ -17,7 +17,9 @@
 // Measured per segment (-DSQDET_FIRE_TIMING + tools/ff_timing.py, fire10 at batch 32): phase A 31 % of a wave's
 // life (12 % waiting for chunk loads / the per-chunk barrier), the expand K loops 52 % (the matrix pipe ~75 % busy
 // inside them), weight refill + epilogue stores 17 %.  Starting the second workgroup of every CU late, so that its
-// phase A would sit under the first one's phase B, was tried and is monotonically SLOWER (+4 us per 16 k cycles).
+// phase A would sit under the first one's phase B, was tried and is monotonically SLOWER (+4 us per 16 k cycles; the
+// co-resident pairs are blocks i and i + 256 and start within ~130 cycles of each other: ff_timing.py --placement).
+// Eight instead of four input chunks in flight (decoupled from the weight ring's depth) is 5 % SLOWER as well.
 #include "conv_common.h"
 
 namespace sqdet {
@@ -63,6 +65,9 @@ __global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused
   const int j = lane & 15, g = lane >> 4;
 #ifdef SQDET_FIRE_TIMING
   unsigned long long ft_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ft_last = __builtin_amdgcn_s_memtime();
+  // slot 7: where and when this workgroup started -- HW_ID (cu / sh / se) and XCC_ID above the low 40 bits of the clock
+  ft_acc[7] = (ft_last & 0xFFFFFFFFFFull) | ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFF) << 40) |
+              ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 56);
 #endif
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (own L2 each); every XCD gets a contiguous band of
   // tiles so the halos shared by neighbouring tiles are fetched into ONE L2 instead of up to eight.

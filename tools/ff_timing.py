@@ -47,3 +47,35 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def placement():
+    """Which workgroups share a CU, and when they start (slot 7 of the timing record)."""
+    lib = _lib.lib()
+    n = 2048 * 8
+    buf = (C.c_ulonglong * n)()
+    lib.sqdet_debug_ff_timing.argtypes = [C.c_void_p, C.c_int]
+    assert lib.sqdet_debug_ff_timing(buf, n) == 0
+    t = np.array(buf[:], dtype=np.uint64).reshape(2048, 8)
+    import collections
+    cus = collections.defaultdict(list)
+    for w in range(0, 2048, 4):          # wave 0 of workgroup w / 4
+        v = int(t[w, 7])
+        if v == 0:
+            continue
+        start, hw, xcc = v & 0xFFFFFFFFFF, (v >> 40) & 0xFFFF, (v >> 56) & 0xF
+        cu, sh, se = (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 7
+        cus[(xcc, se, sh, cu)].append((w // 4, start))
+    cnt = collections.Counter(len(v) for v in cus.values())
+    print("CUs used: %d; workgroups per CU histogram: %s" % (len(cus), dict(cnt)))
+    t0 = min(s for v in cus.values() for _, s in v)
+    pairs = [sorted(v, key=lambda e: e[1]) for v in cus.values() if len(v) >= 2]
+    print("first 12 CUs with >= 2 workgroups: (block id, start tick) ...")
+    for v in pairs[:12]:
+        print("   ", [(b, s - t0) for b, s in v])
+    d = [v[1][0] - v[0][0] for v in pairs]
+    print("block-id distance of co-resident pairs: min %d max %d; equal to 256: %d of %d" % (min(d), max(d), sum(1 for x in d if abs(x) == 256), len(d)))
+
+
+if __name__ == "__main__" and "--placement" in sys.argv:
+    placement()
