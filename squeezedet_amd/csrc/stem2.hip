@@ -63,8 +63,22 @@ __device__ __forceinline__ f32x4 mma16_first<float>(const i32x4& a, const i32x4&
   return acc;
 }
 
+// -DSQDET_FIRE_TIMING (experiments only): per-wave s_memtime totals of the kernel's three segments (tools/stem_timing.py).
+// Measured (batch 32, 375x1242): staging the input patch 31 % of a workgroup's life (one memory round trip: 16-byte
+// instead of 4-byte loads changed nothing), barrier 8 %, im2col gather + MFMA + pooling + stores 61 % -- of which the
+// 68 MFMAs are 7 %: the kernel is bound by the VALU / LDS work of the gather and the pooled epilogue.
+#ifdef SQDET_FIRE_TIMING
+__device__ unsigned long long g_stem_timing[2048 * 8];
+#define ST_MARK(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define ST_MARK(k) do {} while (0)
+#endif
+
 template <typename T, int KS, int NT, bool ALIGNED4>
 __global__ __launch_bounds__(256) void stem_strip(StemArgs a) {
+#ifdef SQDET_FIRE_TIMING
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#endif
   constexpr int KG = Tr<T>::KG;
   constexpr int KC = 4 * KG;
   constexpr int TR = 2 * (ZCR - 1) + KS;            // staged input rows
@@ -156,7 +170,9 @@ __global__ __launch_bounds__(256) void stem_strip(StemArgs a) {
       }
     }
   }
+  ST_MARK(0);
   __syncthreads();
+  ST_MARK(1);
 
   // ---- per-lane constants ----
   const int cb = g * 4 * NT;                              // this lane's 4*NT = 16 (or 24) consecutive couts
@@ -269,6 +285,11 @@ __global__ __launch_bounds__(256) void stem_strip(StemArgs a) {
       }
     }
   }
+  ST_MARK(2);
+#ifdef SQDET_FIRE_TIMING
+  if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < 2048)
+    for (int k = 0; k < 8; ++k) g_stem_timing[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + k] = st_acc[k];
+#endif
 }
 
 template <typename T, int KS, int NT>
@@ -303,3 +324,9 @@ int stem_strip_launch(StemArgs a, int k, int dtype, hipStream_t st, bool* handle
 }
 
 }  // namespace sqdet
+
+#ifdef SQDET_FIRE_TIMING
+extern "C" int sqdet_debug_stem_timing(unsigned long long* host, int count) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sqdet::g_stem_timing), sizeof(unsigned long long) * count);
+}
+#endif
