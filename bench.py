@@ -48,9 +48,14 @@ def dist_env():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def _dist_on():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def max_over_ranks(value, world, device):
     """Timing rule of the bench contract: the job's time is the MAX over ranks."""
-    if world == 1:
+    if not _dist_on():
         return value
     import torch.distributed as dist
     t = torch.tensor([value], dtype=torch.float64, device=device)
@@ -59,7 +64,7 @@ def max_over_ranks(value, world, device):
 
 
 def barrier(world, device):
-    if world > 1:
+    if _dist_on():
         import torch.distributed as dist
         if device.type == "cuda":
             dist.barrier(device_ids=[device.index])
@@ -122,7 +127,8 @@ def main(argv=None):
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # (SQDET_FORCE_DIST=1 under torch.distributed.run with one process: exercises the RCCL path on a single-GPU box)
+    if world > 1 or (os.environ.get("SQDET_FORCE_DIST") == "1" and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -227,7 +233,7 @@ def main(argv=None):
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args, mc, params, args.cpu_baseline_seconds)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if _dist_on():
         import torch.distributed as dist
         dist.destroy_process_group()
 
