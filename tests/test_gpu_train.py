@@ -45,7 +45,11 @@ BWD_CASES = [("e1_16_64", 2, 23, 31, 16, 64, 1), ("e3_16_64", 2, 23, 31, 16, 64,
              ("sq_96_16", 1, 21, 37, 96, 16, 1), ("sq_256_48", 1, 12, 39, 256, 48, 1), ("sq_512_96", 1, 9, 17, 512, 96, 1),
              ("e1_48_192", 1, 12, 20, 48, 192, 1), ("e3_64_256", 1, 11, 19, 64, 256, 3), ("e1_96_384", 1, 9, 14, 96, 384, 1),
              ("res_64_64", 1, 17, 33, 64, 64, 3), ("res_256_64", 1, 17, 33, 256, 64, 1), ("ragged_20_36", 1, 6, 18, 20, 36, 3),
-             ("ragged_40_24", 2, 5, 16, 40, 24, 1)]
+             ("ragged_40_24", 2, 5, 16, 40, 24, 1),
+             # SqueezeDet+ late modules (22x76 map, squeeze 384, expand 256) and its 96 / 192 / 288-channel squeezes
+             ("plus_e1_384_256", 1, 22, 76, 384, 256, 1), ("plus_e3_384_256", 1, 22, 76, 384, 256, 3),
+             ("plus_sq_512_384", 1, 22, 76, 512, 384, 1), ("plus_e3_192_128", 1, 23, 39, 192, 128, 3),
+             ("plus_sq_256_288", 1, 23, 39, 256, 288, 1)]
 
 
 @pytest.mark.parametrize("case", BWD_CASES, ids=[c[0] for c in BWD_CASES])
@@ -417,3 +421,44 @@ def test_training_step_from_gpu_built_labels():
     x = O.synthetic_images(2, 128, 256, seed=9)
     out = tr.step(x, mask, delta, box, lab)
     assert out["num_objects"] == 6.0 and np.isfinite(float(out["bbox_loss"]))
+
+
+def test_squeezedet_plus_training_step_vs_oracle():
+    """The same trainer on SqueezeDet+ (nets/squeezeDetPlus.py:30-79: 7x7/s2 VALID conv1 -- frozen --, VALID pools,
+    wider fire modules; train.py --net squeezeDet+) at its full 1242x375 size, batch 1: losses and every gradient
+    against the oracle's autograd."""
+    import squeezedet_amd as S
+    from squeezedet_amd import nets
+    from squeezedet_amd.train import SqueezeDetTrainer
+    mc = S.kitti_squeezeDetPlus_config()
+    mc.LOAD_PRETRAINED_MODEL = False
+    mc.IS_TRAINING = True
+    mc.BATCH_SIZE = 1
+    m = nets.SqueezeDetPlus(mc, gpu_id="0", dtype=torch.float32)
+    params = O.init_params("squeezeDet+", seed=1)
+    m.load_params(params)
+    tr = SqueezeDetTrainer(m)
+    omc = O.kitti_squeezeDetPlus_config()
+    omc.IS_TRAINING = True
+    x = O.synthetic_images(1, mc.IMAGE_HEIGHT, mc.IMAGE_WIDTH, seed=51)
+    mask, delta, box, labels = TO.synthetic_labels(omc, 1, seed=52)
+    dshape = tuple(tr.model.preds.inputs[0].get_shape())        # conv12's input = the dropout's output [1,22,76,512]
+    dm = torch.from_numpy((np.random.RandomState(53).uniform(size=dshape) < 0.5).astype(np.float32))
+    ref = TO.loss_and_grads("squeezeDet+", omc, params, x, dm, mask, delta, box, labels)
+    out = tr.step(x, mask, delta, box, labels, dropout_mask=dm, apply_update=False, keep_activations=True)
+    torch.cuda.synchronize()
+    for k in ("class_loss", "conf_loss", "bbox_loss"):
+        np.testing.assert_allclose(float(out[k]), ref[k], rtol=5e-4)
+    _close(out["preds"], ref["preds"], rel=1e-3, what="preds (SqueezeDet+ training forward)")
+    assert "conv1/kernels" not in tr.gview
+    # gradients: with the oracle's forward values pinned to the device's activations (same ReLU / max-pool decisions;
+    # at this depth and width even float32 summation-order differences flip a few near-zero ReLUs, and ONE flipped
+    # element with a large gradient moved a filter gradient by 3e-3 of its maximum in the free-running comparison)
+    acts = {k: v.float().cpu() for k, v in out["activations"].items()}
+    ref = TO.loss_and_grads("squeezeDet+", omc, params, x, dm, mask, delta, box, labels, override=acts)
+    for name, gref in ref["grads"].items():
+        wdg = omc.WEIGHT_DECAY * params[name] if name.endswith("/kernels") else 0.0
+        got = tr.gview[name].cpu() + wdg
+        scale = float(gref.abs().max())
+        err = float((got - gref).abs().max())
+        assert err <= 1e-3 * scale + 1e-7, "%s: grad err %g vs scale %g" % (name, err, scale)
