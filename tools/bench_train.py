@@ -78,6 +78,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one_step()
+    t_issued = time.perf_counter() - t0          # host done enqueueing (diagnostic: launch-bound if ~ the step time)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier(device_ids=[local_rank])
@@ -91,7 +92,8 @@ def main():
         prec = "fp32" if args.dtype == "f32" else "fp16 (mixed precision)"
         print(json.dumps({"metric": "images/sec %s %s training" % (label, prec), "value": round(args.batch * world * args.steps / el, 2),
                           "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(el / args.steps * 1e3, 3), "dtype": args.dtype, "data": "synthetic",
+                          "ms_per_step": round(el / args.steps * 1e3, 3),
+                          "host_issue_ms_per_step": round(t_issued / args.steps * 1e3, 3), "dtype": args.dtype, "data": "synthetic",
                           "config": {"workload": "%s %s training, batch=%d per GPU, forward+loss+backward+"
                                                  "all-reduce+clipped Momentum" % (label, prec, args.batch), "parallelism": "dp%d" % world},
                           "skipped_steps": tr.skipped_steps, "loss_scale": tr.loss_scale,
