@@ -92,10 +92,13 @@ int sqdet_fold_batchnorm(const float* w_hwio, const float* conv_bias, const floa
  * backward kernels produce the gradients of the FOLDED kernel / bias; this turns them into the
  * gradients of the variables (float32):  dw = dw_folded * gamma/sqrt(var+eps)  (may alias dw_folded),
  *   dgamma = (sum over k,k,cin of dw_folded * w + (conv_bias - mean) * db_folded) / sqrt(var+eps),
- *   dbeta = db_folded.   conv_bias may be NULL.  Deterministic. */
+ *   dbeta = db_folded.   conv_bias may be NULL.  workspace: sqdet_fold_batchnorm_bwd_workspace_bytes(...) of device
+ *   scratch (per-row-block column sums, added in a fixed order: deterministic). */
+size_t sqdet_fold_batchnorm_bwd_workspace_bytes(int k, int cin, int cout);
 int sqdet_fold_batchnorm_bwd(const float* w_hwio, const float* dw_folded, const float* db_folded,
                              const float* conv_bias, const float* gamma, const float* mean, const float* var, float eps,
-                             float* dw, float* dgamma, float* dbeta, int k, int cin, int cout, sqdet_stream_t stream);
+                             float* dw, float* dgamma, float* dbeta, float* workspace, int k, int cin, int cout,
+                             sqdet_stream_t stream);
 
 /* y[n,oy,ox,:] = x[n,oy*stride,ox*stride,:], y: [n,ceil(h/stride),ceil(w/stride),c] -- the pixels a 1x1
  * stride-s SAME conv reads (res3a/res4a branch1 and branch2a), so that their filter gradient can use

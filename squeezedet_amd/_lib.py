@@ -26,7 +26,8 @@ SIGNATURES = {
     "sqdet_conv2d_nhwc_fwd": (ci, [vp, vp, vp, vp] + [ci] * 12 + [vp]),
     "sqdet_conv2d_add_nhwc_fwd": (ci, [vp, vp, vp, vp] + [ci] * 12 + [vp]),
     "sqdet_fold_batchnorm": (ci, [vp] * 6 + [cf, vp, vp, ci, ci, ci, vp]),
-    "sqdet_fold_batchnorm_bwd": (ci, [vp] * 7 + [cf, vp, vp, vp, ci, ci, ci, vp]),
+    "sqdet_fold_batchnorm_bwd_workspace_bytes": (sz, [ci] * 3),
+    "sqdet_fold_batchnorm_bwd": (ci, [vp] * 7 + [cf, vp, vp, vp, vp, ci, ci, ci, vp]),
     "sqdet_subsample_nhwc": (ci, [vp, vp] + [ci] * 6 + [vp]),
     "sqdet_maxpool_nhwc_fwd": (ci, [vp, vp] + [ci] * 8 + [vp]),
     "sqdet_stem_conv_pool_fwd": (ci, [vp, vp, vp, vp] + [ci] * 8 + [vp]),

@@ -266,13 +266,14 @@ def fold_batchnorm_bwd(w_hwio, dw_folded, db_folded, conv_bias, gamma, mean, var
     dw = torch.empty_like(dw_folded) if dw is None else dw
     dgamma = torch.empty(cout, dtype=torch.float32, device=dev) if dgamma is None else dgamma
     dbeta = torch.empty(cout, dtype=torch.float32, device=dev) if dbeta is None else dbeta
+    ws = torch.empty(int(lib().sqdet_fold_batchnorm_bwd_workspace_bytes(k, cin, cout)) // 4 + 16, dtype=torch.float32, device=dev)
     check(lib().sqdet_fold_batchnorm_bwd(_dev(w_hwio, "w", torch.float32), _dev(dw_folded, "dw_folded", torch.float32),
                                          _dev(db_folded, "db_folded", torch.float32),
                                          _dev(conv_bias, "conv_bias", torch.float32) if conv_bias is not None else None,
                                          _dev(gamma, "gamma", torch.float32), _dev(mean, "mean", torch.float32),
                                          _dev(var, "var", torch.float32), float(eps), _dev(dw, "dw", torch.float32),
                                          _dev(dgamma, "dgamma", torch.float32), _dev(dbeta, "dbeta", torch.float32),
-                                         k, cin, cout, stream_ptr()), "sqdet_fold_batchnorm_bwd")
+                                         _dev(ws, "ws"), k, cin, cout, stream_ptr()), "sqdet_fold_batchnorm_bwd")
     return dw, dgamma, dbeta
 
 
