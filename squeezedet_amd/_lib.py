@@ -116,7 +116,16 @@ def pad_code(padding):
     raise SqdetError("padding must be 'SAME' or 'VALID', got %r" % padding)
 
 
+_raw_stream = None
+
+
 def stream_ptr():
-    """The current torch HIP stream as a hipStream_t value."""
+    """The current torch HIP stream as a hipStream_t value.  (torch.cuda.current_stream() builds a Stream object
+    through several Python layers -- 1.6 ms of a 4.7 ms training step's host time; the raw getter is one C call.)"""
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream:
+        return C.c_void_p(_raw_stream(torch._C._cuda_getDevice()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)

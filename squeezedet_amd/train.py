@@ -40,13 +40,18 @@ class _TrainerBase:
     gradients overflowed (inf / NaN norm in any variable, on any rank -- the SUM all-reduce spreads it) is skipped by
     the optimizer kernel and halves the scale; `growth_interval` clean steps double it."""
 
-    def __init__(self, model, process_group=None, loss_scale=1024.0, growth_interval=200):
+    def __init__(self, model, process_group=None, loss_scale=1024.0, growth_interval=200, lazy_overflow_check=False):
         if model.dtype not in (torch.float32, torch.float16):
             raise SqdetError("training runs in float32 (the reference's training dtype) or float16 (mixed precision)")
         self.adt = model.dtype                       # activation dtype
         self.half = model.dtype == torch.float16
         self.loss_scale = float(loss_scale) if self.half else 1.0
         self.growth_interval, self._clean_steps, self.skipped_steps = int(growth_interval), 0, 0
+        # lazy_overflow_check: read a step's overflow flag at the END OF THE NEXT step (asynchronous copy to pinned
+        # memory + event) instead of synchronising with the device every step.  The skipped update itself happens on the
+        # device either way; only the loss-scale / counter bookkeeping lags one step.  flush() settles the last one.
+        self.lazy_overflow_check = bool(lazy_overflow_check)
+        self._pending_flag = None
         if not model.has_device:
             raise SqdetError("squeezedet_amd needs a HIP device: there is no CPU path")
         self.model, self.mc, self.dev = model, model.mc, model.device
@@ -84,10 +89,12 @@ class _TrainerBase:
         mc = self.mc
         return mc.LEARNING_RATE * mc.LR_DECAY_FACTOR ** (self.global_step // mc.DECAY_STEPS)   # staircase decay
 
-    def _labels(self, B, input_mask, box_delta_input, box_input, labels):
+    def _labels(self, B, input_mask, box_delta_input, box_input, labels, num_objects=None):
         t = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))).to(self.dev, torch.float32).contiguous()
         mask = t(input_mask).reshape(B, -1)
-        return t, mask, t(box_delta_input), t(box_input), t(labels), float(mask.sum().item())
+        if num_objects is None:       # sum(input_mask): a device -> host sync; callers that know the count pass it
+            num_objects = float(mask.sum().item())
+        return t, mask, t(box_delta_input), t(box_input), t(labels), float(num_objects)
 
     def _loss(self, preds, mask, delta, box, lab, num_objects):
         """Loss forward + backward in float32; returns (gradient w.r.t. preds in the activation dtype -- times
@@ -103,19 +110,39 @@ class _TrainerBase:
         if apply_update:
             self.opt.step(self.flat_params, self.flat_grads, self.flat_accum, self.learning_rate(), self.mc.MOMENTUM,
                           self.mc.MAX_GRAD_NORM, grad_scale, found_inf=self.found_inf if self.half else None)
-            if self.half and int(self.found_inf.item()):
-                # overflow: the kernel left weights and momentum untouched; retry the next batch at half the scale
-                self.loss_scale = max(self.loss_scale / 2.0, 2.0 ** -14)
-                self._clean_steps = 0
-                self.skipped_steps += 1
-                return
-            if self.half:
-                self._clean_steps += 1
-                if self._clean_steps >= self.growth_interval:
-                    self.loss_scale, self._clean_steps = min(self.loss_scale * 2.0, 65536.0), 0
-            self.global_step += 1
             self.model._packed.clear()
             self.model._plan_stale = True
+            if not self.half:
+                self.global_step += 1
+            elif not self.lazy_overflow_check:
+                self._account(bool(int(self.found_inf.item())))
+            else:
+                self.flush()                                  # the PREVIOUS step's flag (its event completed long ago)
+                if getattr(self, "_flag_host", None) is None:
+                    self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                    self._flag_event = torch.cuda.Event()
+                self._flag_host.copy_(self.found_inf, non_blocking=True)
+                self._flag_event.record(torch.cuda.current_stream())
+                self._pending_flag = True
+
+    def flush(self):
+        """lazy_overflow_check: settle the bookkeeping of the last step (loss scale, skipped / global step counters)."""
+        if self._pending_flag:
+            self._flag_event.synchronize()
+            self._pending_flag = None
+            self._account(bool(int(self._flag_host[0])))
+
+    def _account(self, overflowed):
+        if overflowed:
+            # the kernel left weights and momentum untouched; retry the next batch at half the scale
+            self.loss_scale = max(self.loss_scale / 2.0, 2.0 ** -14)
+            self._clean_steps = 0
+            self.skipped_steps += 1
+            return
+        self._clean_steps += 1
+        if self._clean_steps >= self.growth_interval:
+            self.loss_scale, self._clean_steps = min(self.loss_scale * 2.0, 65536.0), 0
+        self.global_step += 1
 
     def weight_decay_loss(self):
         """sum wd * l2_loss(kernel) over trainable kernels (the 'losses' collection of nn_skeleton.py:66-69)."""
@@ -159,7 +186,7 @@ class SqueezeDetTrainer(_TrainerBase):
         return ops.pack_conv_weights(self.model.params[name + "/kernels"], self.adt)
 
     def step(self, images, input_mask, box_delta_input, box_input, labels, dropout_mask=None, apply_update=True,
-             keep_activations=False):
+             keep_activations=False, num_objects=None):
         """One training step.  images [B,H,W,3]; input_mask [B,A] or [B,A,1]; box_delta_input / box_input
         [B,A,4]; labels [B,A,C] (the reference's placeholders, nn_skeleton.py:81-97).  Returns a dict
         with loss, class_loss, conf_loss, bbox_loss (device scalars).  keep_activations: also return every stored
@@ -169,7 +196,7 @@ class SqueezeDetTrainer(_TrainerBase):
         acts = {}
         x = m._to_input(images)
         B = int(x.shape[0])
-        t, mask, delta, box, lab, num_objects = self._labels(B, input_mask, box_delta_input, box_input, labels)
+        t, mask, delta, box, lab, num_objects = self._labels(B, input_mask, box_delta_input, box_input, labels, num_objects)
         keep = m.keep_prob
         # ---------------- forward, keeping what the backward needs ----------------
         saved = []
@@ -292,12 +319,12 @@ class ResNet50ConvDetTrainer(_TrainerBase):
                 raise SqdetError("frozen conv %s above the first trainable one is not supported" % n.name)
 
     def step(self, images, input_mask, box_delta_input, box_input, labels, dropout_mask=None, apply_update=True,
-             keep_activations=False):
+             keep_activations=False, num_objects=None):
         m, mc, P = self.model, self.mc, self.model.params
         eps = mc.BATCH_NORM_EPSILON
         (xb,) = m.run([self.boundary], {m.image_input: images}, use_plan=False)
         B = int(xb.shape[0])
-        t, mask, delta, box, lab, num_objects = self._labels(B, input_mask, box_delta_input, box_input, labels)
+        t, mask, delta, box, lab, num_objects = self._labels(B, input_mask, box_delta_input, box_input, labels, num_objects)
         # ---------------- forward over the trainable region ----------------
         val, aux = {self.boundary: xb}, {}
         for n in self.region:

@@ -62,14 +62,15 @@ def main():
     cls, trainer = (nets.SqueezeDet, SqueezeDetTrainer) if args.arch == "squeezeDet" else (nets.ResNet50ConvDet, ResNet50ConvDetTrainer)
     model = cls(mc, gpu_id=str(local_rank), dtype=torch.float32 if args.dtype == "f32" else torch.float16)
     model.load_params(synthetic.synthetic_params(model, seed=0))      # same weights on every rank
-    tr = trainer(model)
+    tr = trainer(model, lazy_overflow_check=True)
     x = synthetic.synthetic_images(args.batch, mc.IMAGE_HEIGHT, mc.IMAGE_WIDTH, seed=100 + rank).to(dev)
     # ground truth lives on the device; the anchor assignment + dense label build (imdb.py:195-239,
     # train.py:163-224) runs on the GPU inside every step, like the reference's per-batch _load_data
     from squeezedet_amd import ops
     anchors = torch.from_numpy(np.asarray(mc.ANCHOR_BOX, np.float64)).to(dev)
     gt, gcls, gcnt = [torch.from_numpy(a).to(dev) for a in synthetic_ground_truth(mc, args.batch, seed=200 + rank)]
-    one_step = lambda: tr.step(x, *ops.build_labels(anchors, gt, gcls, gcnt, mc.CLASSES)[:4])
+    nobj = float(gcnt.sum().item())      # known to the host: no per-step device -> host sync for sum(input_mask)
+    one_step = lambda: tr.step(x, *ops.build_labels(anchors, gt, gcls, gcnt, mc.CLASSES)[:4], num_objects=nobj)
     for _ in range(args.warmup):
         out = one_step()
     torch.cuda.synchronize()
@@ -80,6 +81,7 @@ def main():
         out = one_step()
     t_issued = time.perf_counter() - t0          # host done enqueueing (diagnostic: launch-bound if ~ the step time)
     torch.cuda.synchronize()
+    tr.flush()
     if world > 1:
         dist.barrier(device_ids=[local_rank])
     el = time.perf_counter() - t0
