@@ -110,7 +110,11 @@ class _TrainerBase:
         if apply_update:
             self.opt.step(self.flat_params, self.flat_grads, self.flat_accum, self.learning_rate(), self.mc.MOMENTUM,
                           self.mc.MAX_GRAD_NORM, grad_scale, found_inf=self.found_inf if self.half else None)
-            self.model._packed.clear()
+            # packed / BN-folded kernels of the layers whose variables just changed are stale; the frozen layers'
+            # (conv1 of SqueezeDet, conv1 .. res3d of ResNet50 -- re-folded and re-packed every step before) are not
+            tr = self.model.trainable
+            for k in [k for k in self.model._packed if tr.get(k + "/kernels", True)]:
+                del self.model._packed[k]
             self.model._plan_stale = True
             if not self.half:
                 self.global_step += 1
