@@ -158,3 +158,30 @@ def test_graph_builders_and_reference_counters():
             m.run([m.preds], {m.image_input: np.zeros((1, 384, 1248, 3), np.float32)})
         with pytest.raises(_lib.SqdetError):
             m.filter_prediction(np.zeros((10, 4), np.float32), np.zeros(10, np.float32), np.zeros(10, np.int64))
+
+
+def test_loss_scale_bookkeeping_state_machine():
+    """Mixed-precision trainers: the host-side bookkeeping of the dynamic loss scale (the skipped update itself happens
+    inside the optimizer kernel) -- halve on overflow down to 2^-14, double after `growth_interval` clean steps up to
+    65536, global_step counts applied steps only."""
+    from squeezedet_amd.train import _TrainerBase
+    tr = _TrainerBase.__new__(_TrainerBase)          # no device needed for the state machine
+    tr.loss_scale, tr.growth_interval, tr._clean_steps, tr.skipped_steps, tr.global_step = 1024.0, 3, 0, 0, 0
+    tr._account(True)
+    assert (tr.loss_scale, tr.skipped_steps, tr.global_step, tr._clean_steps) == (512.0, 1, 0, 0)
+    for _ in range(2):
+        tr._account(False)
+    assert (tr.loss_scale, tr.global_step, tr._clean_steps) == (512.0, 2, 2)
+    tr._account(False)                               # third clean step: the scale grows, the counter restarts
+    assert (tr.loss_scale, tr.global_step, tr._clean_steps) == (1024.0, 3, 0)
+    tr._account(True)
+    assert tr._clean_steps == 0 and tr.loss_scale == 512.0 and tr.skipped_steps == 2
+    tr.loss_scale = 2.0 ** -14
+    tr._account(True)
+    assert tr.loss_scale == 2.0 ** -14               # floor
+    tr.loss_scale, tr.growth_interval = 65536.0, 1
+    tr._account(False)
+    assert tr.loss_scale == 65536.0                  # ceiling
+    tr._pending_flag = None
+    tr.flush()                                       # nothing pending: a no-op
+    assert tr.global_step == 4
