@@ -123,3 +123,27 @@ def test_forward_shapes_and_storage_modes():
     n_params = sum(int(np.prod(s)) for s in O.param_shapes("squeezeDet").values())
     assert n_params == 2082120  # BASELINE.md derived parameter count
     assert sum(int(np.prod(s)) for s in O.param_shapes("squeezeDet+").values()) == 7021640
+
+
+def test_float16_storage_restatement_rounds_values_not_gradients():
+    """train_oracle._q (the mixed-precision restatement): the forward value is the float16-rounded one, the gradient
+    passes straight through (weight gradients stay float32 on the device as well); an `override` pins the forward
+    value of a stored activation without touching the gradient path."""
+    import torch
+    from oracle import train_oracle as TO
+    t = torch.tensor([0.1, 1.0 + 2.0 ** -12, -3.3333, 70000.0], requires_grad=True)
+    q = TO._q(t, "fp16")
+    assert torch.equal(q.detach(), t.detach().half().float())
+    (q * torch.tensor([1.0, 2.0, 3.0, 0.0])).sum().backward()
+    assert torch.equal(t.grad, torch.tensor([1.0, 2.0, 3.0, 0.0]))
+    assert TO._q(t, "fp32") is t
+    # override: a two-layer toy through forward_train's own helper semantics
+    x = torch.randn(1, 4, 4, 8)
+    w = (torch.randn(1, 1, 8, 8) * 0.3).requires_grad_(True)
+    b = torch.zeros(8)
+    y = TO._conv(x, w, b, 1, "SAME", True, "fp16")
+    pinned = (y.detach() + 0.25) * (y.detach() > 0)                      # some other forward value, same ReLU pattern
+    y2 = y + (pinned - y).detach()
+    (g_free,) = torch.autograd.grad(y.sum(), w, retain_graph=True)
+    (g_pin,) = torch.autograd.grad(y2.sum(), w)
+    assert torch.equal(y2.detach(), pinned) and torch.equal(g_free, g_pin)
