@@ -241,8 +241,12 @@ __global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused
       }
     }
   };
-  if (wave < nw) fill(item_of(wave));
-  for (int witem = wave; witem < nw; witem += 4) {
+  // Work items are dealt round-robin: over the workgroups that share this tile first (gridDim.y > 1 on SMALL batches,
+  // where the tiles alone cannot fill the chip -- batch 1 has 15 of them: every such workgroup repeats the cheap
+  // squeeze phase and takes its share of the expand items), then over the four waves.
+  const int w0 = (int)blockIdx.y + (int)gridDim.y * wave, wstep = 4 * (int)gridDim.y;
+  if (w0 < nw) fill(item_of(w0));
+  for (int witem = w0; witem < nw; witem += wstep) {
     const Item it = item_of(witem);
     const int m0 = it.m0;
     f32x4 acc[MT][NTW];
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused
       }
     }
     FFT_MARK(5);
-    if (witem + 4 < nw) fill(item_of(witem + 4));   // the ring is empty here: next item's first fragments
+    if (witem + wstep < nw) fill(item_of(witem + wstep));   // the ring is empty here: next item's first fragments
     // epilogue: bias + ReLU, 4*NTW consecutive channels per lane into the concat tensor
     const int cout = it.is3 ? a.E3 : a.E1;
     const int coff = it.is3 ? a.E1 : 0;
@@ -331,7 +335,16 @@ static void launch_ff(const FireArgs& a, size_t lds, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     big_lds_ok = true;
   }
-  const dim3 grid((unsigned)((a.N * a.tiles_x * a.tiles_y + 7) / 8 * 8));
+  // few tiles (small batches): split the expand items of a tile over up to items/4 workgroups (one item per wave)
+  const int tiles = a.N * a.tiles_x * a.tiles_y;
+  const int items = (a.e3_tiles / NTW + a.e1_tiles / NTW) * (FROWS / MT);
+  int split = 1;
+  if (tiles < 256 && tune(TUNE_DBG) != 25) {
+    split = 512 / (tiles > 0 ? tiles : 1);
+    if (split > items / 4) split = items / 4;
+    if (split < 1) split = 1;
+  }
+  const dim3 grid((unsigned)((tiles + 7) / 8 * 8), (unsigned)split);
   hipLaunchKernelGGL((fire_fused<T, NTS, NTW, MT>), grid, dim3(256), lds, st, a);
 }
 
