@@ -8,7 +8,6 @@ executes them on the GPU.  There is no CPU execution path.
 """
 import collections
 import contextlib
-
 import os
 
 import numpy as np
