@@ -149,11 +149,19 @@ __global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused
         if (c >= a.nch_x) break;
         // everything up to chunk c has landed when at most the later chunks' instructions are outstanding
         const int later = min(PD - 1, a.nch_x - 1 - c);
-        if (later >= 3) __builtin_amdgcn_s_waitcnt(0x0F70 | ((3 * PER) & 0xF) | (((3 * PER) >> 4) << 14));
-        else if (later == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * PER) & 0xF) | (((2 * PER) >> 4) << 14));
-        else if (later == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | ((1 * PER) & 0xF) | (((1 * PER) >> 4) << 14));
-        else __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();                                  // every wave's share of the weights is in the ring
+        // (0x0070: lgkmcnt(0) too -- this wave's LDS writes / reads are done before it arrives)
+        if (later >= 3) __builtin_amdgcn_s_waitcnt(0x0070 | ((3 * PER) & 0xF) | (((3 * PER) >> 4) << 14));
+        else if (later == 2) __builtin_amdgcn_s_waitcnt(0x0070 | ((2 * PER) & 0xF) | (((2 * PER) >> 4) << 14));
+        else if (later == 1) __builtin_amdgcn_s_waitcnt(0x0070 | ((1 * PER) & 0xF) | (((1 * PER) >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0070);
+        // A bare s_barrier: __syncthreads() carries a workgroup fence, and with LDS-DMA in flight that fence is an
+        // `s_waitcnt vmcnt(0)` -- it drained the PD-deep pipeline at every chunk (fire6-11: 338 -> 320 us).  The
+        // compiler still puts one vmcnt(0) before the first MFMA of every PD chunks (buffer loads and LDS-DMA are
+        // mixed event types to its wait-count pass, which then distrusts the counted waits); hiding the input loads
+        // in inline asm removes that one too and measures the same, so the plain builtins stay.
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // every wave's share of the weights is in the ring
+        asm volatile("" ::: "memory");
         FFT_MARK(1);
         const unsigned char* slot = wring + (c % RS) * (NTS * 1024);
         i32x4 af[NTS];
