@@ -32,6 +32,7 @@ struct TileArgs {
   int total_tiles;  // cout tiles over all groups
   int nchunk;       // 64-byte K chunks per pixel (ceil)
   int pieces;       // 16-byte pieces per pixel actually present = Cin*sizeof(T)/16
+  unsigned x_bytes; // size of the input tensor (split-K mode: 32-bit buffer offsets)
 };
 
 // Stage `nload` K-chunks starting at chunk c0 of the halo tile into LDS.
@@ -102,6 +103,89 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
   const i32x4* wbase = reinterpret_cast<const i32x4*>(a.c.wp) + ((size_t)group * a.c.steps * a.nt_pack + n0) * 64 + lane;
   const int nstages = SPLITK ? (a.nchunk + 3) / 4 : 1;
 
+  if constexpr (SPLITK) {
+    // Wave w walks chunk 4*stage + w of every stage, 9 taps each: one 5-KiB weight step per 40 MFMAs (~0.27 us of
+    // the matrix pipe), and every weight byte is used once per workgroup, so each step's fragments come from L2
+    // (~0.8 us).  With a one-step look-ahead the wave was latency-bound (a workgroup alone on a CU: 65 us, 54 steps).
+    // Here the 9 taps are unrolled over THREE register sets named statically (step s uses set s % 3; 9 % 3 == 0, so
+    // the names line up across the stage loop and nothing is ever copied), two steps are in flight, and the first two
+    // of the next stage are issued before this stage ends -- they cross the staging barriers.
+    // (requires nchunk % 4 == 0: every wave has a chunk in every stage)
+    // That needs ~350 registers: one workgroup per CU (one wave per SIMD, 512 registers each), so nobody else hides
+    // this workgroup's input staging any more -- the NEXT stage's 46 KB are therefore fetched into registers (12 x 16 B
+    // per thread, raw buffer loads: out-of-image / past-the-end offsets have bit 31 set and return the zero padding)
+    // while the current stage computes, and only the LDS stores sit between the two barriers.
+    constexpr int NSV = (HP * 16 + 255) / 256;   // 16-byte pieces per thread per stage = 12 (the last one partial)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.c.x), 0, a.x_bytes, 0x00020000);
+    const int sq = threadIdx.x & 15, sP0 = threadIdx.x >> 4;   // piece of the stage's 16; first halo pixel (then +16 per u)
+    unsigned goff[NSV];
+#pragma unroll
+    for (int u = 0; u < NSV; ++u) {
+      const int P = sP0 + 16 * u;
+      const int r = P / (TCOLS + 2), cc = P - r * (TCOLS + 2);
+      const int iy = oy0 - 1 + r, ix = ox0 - 1 + cc;
+      const bool ok = P < HP && iy >= 0 && iy < a.c.H && ix >= 0 && ix < a.c.W;
+      goff[u] = ok ? (unsigned)(((n * a.c.H + iy) * a.c.W + ix) * (a.pieces * 16) + sq * 16) : 0x80000000u;
+    }
+    // ((P + 16u) >> 1) & 3 == (P >> 1) & 3: the XOR slot is the same for all of a thread's pixels
+    unsigned char* sdst = lds + (sq >> 2) * CHUNK_BYTES + sP0 * 64 + (((sq & 3) ^ ((sP0 >> 1) & 3)) << 4);
+    i32x4 sv[NSV];
+    auto sload = [&](int stage) {
+      const unsigned so = stage < nstages ? (unsigned)stage * 256u : 0x80000000u;
+#pragma unroll
+      for (int u = 0; u < NSV; ++u) sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, goff[u] + so, 0, 0);
+    };
+    sload(0);
+    i32x4 wf[3][NTW];
+    auto wstep = [&](int stage, int t9) {   // weight fragments of (stage, tap) for this wave; clamped past the end
+      const int st = stage < nstages ? stage : nstages - 1;
+      return wbase + (size_t)(t9 * a.nchunk + st * 4 + wave) * a.nt_pack * 64;
+    };
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const i32x4* wp = wstep(0, p);
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) wf[p][t] = wp[t * 64];
+    }
+#pragma unroll 1
+    for (int stage = 0; stage < nstages; ++stage) {
+      if (stage > 0) __syncthreads();   // every wave is done reading the previous stage
+#pragma unroll
+      for (int u = 0; u < NSV; ++u)
+        if (u < NSV - 1 || sP0 + 16 * u < HP) *reinterpret_cast<i32x4*>(sdst + u * 1024) = sv[u];   // sP0 <= 15
+      __syncthreads();
+      sload(stage + 1);
+      const unsigned char* lchunk = lds + wave * CHUNK_BYTES;
+      // B fragments of tap t9 + 1 are read from LDS under the MFMAs of tap t9 (two statically named sets)
+      i32x4 bfs[2][MT];
+      auto bread = [&](int t9, i32x4 (&bf)[MT]) {
+        const int dy = t9 / 3, dx = t9 - dy * 3;
+        const int P0 = dy * (TCOLS + 2) + j + dx;
+        const int h0 = P0 >> 1;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int slot = g ^ ((h0 + m) & 3);
+          bf[m] = *reinterpret_cast<const i32x4*>(lchunk + (P0 + (TCOLS + 2) * m) * 64 + (slot << 4));
+        }
+      };
+      bread(0, bfs[0]);
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        __builtin_amdgcn_sched_barrier(0);   // steps stay in order: no later tap's reads hoisted, no load sunk
+        {
+          const i32x4* wp = t9 + 2 < 9 ? wstep(stage, t9 + 2) : wstep(stage + 1, t9 + 2 - 9);
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) wf[(t9 + 2) % 3][t] = wp[t * 64];
+        }
+        if (t9 + 1 < 9) bread(t9 + 1, bfs[(t9 + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);   // ... and the issues stay AHEAD of this tap's 40 MFMAs
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], wf[t9 % 3][t], bfs[t9 & 1][m]);
+      }
+    }
+  } else
   for (int stage = 0; stage < nstages; ++stage) {
     const int c0 = SPLITK ? stage * 4 : 0;
     const int nload = SPLITK ? (a.nchunk - c0 < 4 ? a.nchunk - c0 : 4) : a.nchunk;
@@ -297,7 +381,9 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
   bool splitk = false;
   size_t lds = 0;
   int grid_y = 1;
-  if (g.nt == 5 && g.ngroups == 1 && g.nchunk >= 8) {
+  const long x_bytes = (long)c.N * c.H * c.W * c.Cin * esz;
+  a.x_bytes = (unsigned)(x_bytes < 0x7fffffffL ? x_bytes : 0);
+  if (g.nt == 5 && g.ngroups == 1 && g.nchunk >= 8 && g.nchunk % 4 == 0 && x_bytes < 0x7fffffffL) {
     // ConvDet-like: few couts, deep K -> split K over the 4 waves, 4 chunks per stage
     splitk = true;
     mt = 8;
