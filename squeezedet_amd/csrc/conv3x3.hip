@@ -68,8 +68,19 @@ __device__ __forceinline__ void stage_tile(const TileArgs& a, unsigned char* lds
   }
 }
 
+// -DSQDET_FIRE_TIMING (experiments only): per-wave s_memtime totals of the split-K kernel's segments (tools/convdet_timing.py)
+#ifdef SQDET_FIRE_TIMING
+__device__ unsigned long long g_cd_timing[2048 * 8];
+#define CT_MARK(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ct_acc[k] += now_ - ct_last; ct_last = now_; } while (0)
+#else
+#define CT_MARK(k) do {} while (0)
+#endif
+
 template <typename T, int MT, int NTW, bool SPLITK>
 __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
+#ifdef SQDET_FIRE_TIMING
+  unsigned long long ct_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ct_last = __builtin_amdgcn_s_memtime();
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int WR = TROWS / MT;   // waves along the tile rows
   constexpr int WC = 4 / WR;       // waves along the cout groups
@@ -149,11 +160,15 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
     }
 #pragma unroll 1
     for (int stage = 0; stage < nstages; ++stage) {
+      CT_MARK(0);
       if (stage > 0) __syncthreads();   // every wave is done reading the previous stage
+      CT_MARK(1);
 #pragma unroll
       for (int u = 0; u < NSV; ++u)
         if (u < NSV - 1 || sP0 + 16 * u < HP) *reinterpret_cast<i32x4*>(sdst + u * 1024) = sv[u];   // sP0 <= 15
+      CT_MARK(2);
       __syncthreads();
+      CT_MARK(3);
       sload(stage + 1);
       const unsigned char* lchunk = lds + wave * CHUNK_BYTES;
       // B fragments of tap t9 + 1 are read from LDS under the MFMAs of tap t9 (two statically named sets)
@@ -169,6 +184,7 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
         }
       };
       bread(0, bfs[0]);
+      CT_MARK(4);
 #pragma unroll
       for (int t9 = 0; t9 < 9; ++t9) {
         __builtin_amdgcn_sched_barrier(0);   // steps stay in order: no later tap's reads hoisted, no load sunk
@@ -184,6 +200,7 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
 #pragma unroll
           for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], wf[t9 % 3][t], bfs[t9 & 1][m]);
       }
+      CT_MARK(5);
     }
   } else
   for (int stage = 0; stage < nstages; ++stage) {
@@ -256,41 +273,45 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
   }
 
   if (SPLITK) {
-    // Deterministic sum of the 4 K-partial accumulators through LDS: wave 0 writes, waves 1..3 add in
-    // turn ((w0+w1)+w2)+w3; the accumulators are only ever READ here.  Then all four waves share the
-    // epilogue, two tile rows each.
-    float* red = reinterpret_cast<float*>(lds);
-    // Every wave passes exactly 5 barriers: 1 + `wu` before its turn, 4-wu after it.
+    // Deterministic sum of the 4 K-partial accumulators, ((w0+w1)+w2)+w3, as a reduce-scatter through LDS: wave o
+    // owns tile rows 2o, 2o+1; every wave writes the 30 accumulators it does not own (slot [owner][source][10 KiB],
+    // 120 KiB), one barrier, and every wave sums its own 10 in ascending source order and stores them.  (Taking
+    // turns on one 40-KiB buffer -- wave 0 writes, 1..3 add -- was 21 % of a workgroup's life: tools/convdet_timing.py.)
+    constexpr int MO = MT / 4;                      // rows per owner
+    constexpr int SLOT = MO * NTW * 1024;           // bytes of one (owner, source) slot
     const int wu = __builtin_amdgcn_readfirstlane(wave);
     __syncthreads();  // all waves are done reading the input tile (the buffer is reused)
-    for (int r = 0; r < wu; ++r) __syncthreads();
-    {
-      const bool first = wu == 0;
+    auto slot_of = [&](int owner, int src) { return lds + ((owner * 3 + (src < owner ? src : src - 1)) * SLOT) + lane * 16; };
+    auto scatter = [&](auto oc) {   // this wave's partials of owner oc's rows
+      constexpr int o = decltype(oc)::value;
+      if (wu == o) return;
+      unsigned char* p = slot_of(o, wu);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
+      for (int mm = 0; mm < MO; ++mm)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-          f32x4* p = reinterpret_cast<f32x4*>(red + ((m * NTW + t) * 64 + lane) * 4);
-          f32x4 v = acc[m][t];
-          if (!first) v += *p;
-          *p = v;
-        }
-        asm volatile("" ::: "memory");  // small batches of accumulator copies
-      }
-    }
-    for (int r = wu; r < 3; ++r) __syncthreads();
+        for (int t = 0; t < NTW; ++t) *reinterpret_cast<f32x4*>(p + (mm * NTW + t) * 1024) = acc[o * MO + mm][t];
+    };
+    scatter(std::integral_constant<int, 0>{});
+    scatter(std::integral_constant<int, 1>{});
+    scatter(std::integral_constant<int, 2>{});
+    scatter(std::integral_constant<int, 3>{});
     __syncthreads();
-    if (ox < a.c.W) {
+    auto gather = [&](auto oc) {
+      constexpr int o = decltype(oc)::value;
+      if (wu != o || ox >= a.c.W) return;
 #pragma unroll
-      for (int mm = 0; mm < MT / 4; ++mm) {
-        const int m = wave * (MT / 4) + mm;
-        const int oy = oy0 + m;
+      for (int mm = 0; mm < MO; ++mm) {
+        const int oy = oy0 + o * MO + mm;
         if (oy >= a.c.H) break;
         T* dst = y + (((size_t)n * a.c.H + oy) * a.c.W + ox) * a.c.y_cstride + a.c.y_coffset + cb;
         f32x4 v[NTW];
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
-          v[t] = *reinterpret_cast<const f32x4*>(red + ((m * NTW + t) * 64 + lane) * 4) + bias[t];
+          f32x4 s = o == 0 ? acc[o * MO + mm][t] : *reinterpret_cast<const f32x4*>(slot_of(o, 0) + (mm * NTW + t) * 1024);
+#pragma unroll
+          for (int src = 1; src < 4; ++src)
+            s += src == o ? acc[o * MO + mm][t] : *reinterpret_cast<const f32x4*>(slot_of(o, src) + (mm * NTW + t) * 1024);
+          v[t] = s + bias[t];
           if (a.c.relu) {
             v[t][0] = fmaxf(v[t][0], 0.f); v[t][1] = fmaxf(v[t][1], 0.f);
             v[t][2] = fmaxf(v[t][2], 0.f); v[t][3] = fmaxf(v[t][3], 0.f);
@@ -298,7 +319,16 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
         }
         store_couts<T, NTW>(dst, v, nt_valid);
       }
-    }
+    };
+    gather(std::integral_constant<int, 0>{});
+    gather(std::integral_constant<int, 1>{});
+    gather(std::integral_constant<int, 2>{});
+    gather(std::integral_constant<int, 3>{});
+    CT_MARK(6);
+#ifdef SQDET_FIRE_TIMING
+    if (lane == 0 && blockIdx.x * 4 + wave < 2048)
+      for (int k = 0; k < 8; ++k) g_cd_timing[(blockIdx.x * 4 + wave) * 8 + k] = ct_acc[k];
+#endif
     return;
   }
   if (!active) return;
@@ -325,6 +355,12 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
 
 template <typename T, int MT, int NTW, bool SPLITK>
 static void launch_tile(const TileArgs& a, int grid_y, size_t lds, hipStream_t st) {
+  static bool big_lds_ok = false;   // > 64 KiB of dynamic LDS has to be allowed once per kernel
+  if (lds > 65536 && !big_lds_ok) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_tile<T, MT, NTW, SPLITK>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    big_lds_ok = true;
+  }
   const dim3 grid((unsigned)((a.c.N * a.tiles_x * a.tiles_y + 7) / 8 * 8), (unsigned)grid_y);
   hipLaunchKernelGGL((conv3x3_tile<T, MT, NTW, SPLITK>), grid, dim3(256), lds, st, a);
 }
@@ -388,7 +424,7 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
     splitk = true;
     mt = 8;
     lds = 4 * (size_t)CHUNK_BYTES;                         // 46080 B
-    const size_t red = (size_t)TROWS * 5 * 64 * 16;        // 40960 B reduction buffer
+    const size_t red = (size_t)12 * (TROWS / 4) * 5 * 1024;   // 122880 B: reduce-scatter slots [owner][source]
     if (red > lds) lds = red;
   } else if (g.nchunk <= 5) {
     // a wave owns one whole packed group; 2 groups per workgroup (waves 2 rows x 2 groups) when
@@ -419,3 +455,9 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
 }
 
 }  // namespace sqdet
+
+#ifdef SQDET_FIRE_TIMING
+extern "C" int sqdet_debug_convdet_timing(unsigned long long* host, int count) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sqdet::g_cd_timing), sizeof(unsigned long long) * count);
+}
+#endif
