@@ -194,11 +194,22 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
           for (int t = 0; t < NTW; ++t) wf[(t9 + 2) % 3][t] = wp[t * 64];
         }
         if (t9 + 1 < 9) bread(t9 + 1, bfs[(t9 + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);   // ... and the issues stay AHEAD of this tap's 40 MFMAs
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], wf[t9 % 3][t], bfs[t9 & 1][m]);
+        // issue order inside the step: one memory instruction, then three MFMAs (the 13 issues + their address
+        // arithmetic cost ~200 cycles per step when they all sat ahead of the 40 MFMAs)
+#pragma unroll
+        for (int k = 0; k < NTW; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // MFMA
+        }
+#pragma unroll
+        for (int k = 0; k < (t9 + 1 < 9 ? MT : 0); ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        }
       }
       CT_MARK(5);
     }
