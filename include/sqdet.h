@@ -135,6 +135,23 @@ int sqdet_fire_maxpool_fwd(const void* x, const void* w_s, const float* b_s, con
                            const void* w_e3, const float* b_e3, void* sq_scratch, void* fire_scratch, void* y,
                            int n, int h, int w, int cin, int s1x1, int e1x1, int e3x3, int dtype, sqdet_stream_t stream);
 
+/* Fire-module CHAIN (float16): the expand half of one fire module and the squeeze of the NEXT module in one launch.
+ * Replaces, for consecutive fire modules on one feature map (fire6 .. fire11, nets/squeezeDet.py:58-69), the pair
+ *   e = concat(relu(conv1x1(sq_in, W_e1) + b_e1), relu(conv3x3(sq_in, W_e3) + b_e3))      (nets/squeezeDet.py:92-106)
+ *   sq_out = relu(conv1x1(e, W_next_s) + b_next_s)                                          (the next module's :86-90)
+ * sq_in: [n,h,w,s1x1] = the module's own squeeze tensor; the concat tensor e [n,h,w,e1x1+e3x3] is written only when
+ * y != NULL; sq_out [n,h,w,next_s1x1] only when next_s1x1 > 0 (at least one of the two).  The three kernels travel as
+ * ONE packed weight stream (sqdet_fire_chain_pack: float32 HWIO in, any of the three may be NULL = that part of the
+ * stream is left as it is); sqdet_fire_chain_stream_bytes returns 0 for shapes the kernel does not cover
+ * (float16 only; s1x1 in 40..96 step 8, e1x1 / e3x3 multiples of 64, next_s1x1 in {0,48,64,96}).  Results are bitwise
+ * those of sqdet_fire_fwd followed by the next module's squeeze conv. */
+size_t sqdet_fire_chain_stream_bytes(int s1x1, int e1x1, int e3x3, int next_s1x1, int dtype);
+int sqdet_fire_chain_pack(const float* w_e1_hwio, const float* w_e3_hwio, const float* w_next_s_hwio, void* stream_buf,
+                          int s1x1, int e1x1, int e3x3, int next_s1x1, int dtype, sqdet_stream_t stream);
+int sqdet_fire_chain_fwd(const void* sq_in, const void* stream_buf, const float* b_e1, const float* b_e3,
+                         const float* b_next_s, void* y, void* sq_out, int n, int h, int w, int s1x1, int e1x1,
+                         int e3x3, int next_s1x1, int dtype, sqdet_stream_t stream);
+
 /* ---------------------------------------------------- interpret_output --
  * Replaces ModelSkeleton._add_interpretation_graph (nn_skeleton.py:142-283) +
  * util.safe_exp / bbox_transform / bbox_transform_inv (utils/util.py:167-231).

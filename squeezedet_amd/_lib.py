@@ -33,6 +33,9 @@ SIGNATURES = {
     "sqdet_stem_conv_pool_fwd": (ci, [vp, vp, vp, vp] + [ci] * 8 + [vp]),
     "sqdet_fire_fwd": (ci, [vp] * 9 + [ci] * 8 + [vp]),
     "sqdet_fire_maxpool_fwd": (ci, [vp] * 10 + [ci] * 8 + [vp]),
+    "sqdet_fire_chain_stream_bytes": (sz, [ci] * 5),
+    "sqdet_fire_chain_pack": (ci, [vp] * 4 + [ci] * 5 + [vp]),
+    "sqdet_fire_chain_fwd": (ci, [vp] * 7 + [ci] * 8 + [vp]),
     "sqdet_interpret_output": (ci, [vp] * 7 + [ci] * 5 + [cf, cf, cf, ci, vp]),
     "sqdet_filter_prediction": (ci, [vp] * 8 + [ci] * 5 + [cd, cf, vp]),
     "sqdet_conv_pack_weights_bwd_data": (ci, [vp, vp, ci, ci, ci, ci, vp]),

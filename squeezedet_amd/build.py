@@ -27,6 +27,7 @@ SOURCES = [
     ("stem2.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("fire.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("fire2.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    ("chain.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("pool.hip", []),
     ("bn.hip", ["-ffp-contract=off"]),
     ("preproc.hip", ["-ffp-contract=off"]),

@@ -144,6 +144,52 @@ def fire_maxpool(x, p_s, b_s, p_e1, b_e1, p_e3, b_e3):
     return y
 
 
+class FireChainStream:
+    """The packed weight stream of sqdet_fire_chain_fwd: expand1x1 + expand3x3 kernels of one fire module and,
+    optionally, the squeeze1x1 kernel of the next one (float32 HWIO in, float16 stream out)."""
+
+    def __init__(self, w_e1_hwio, w_e3_hwio, w_next_s_hwio=None, dtype=torch.float16):
+        w1 = w_e1_hwio.detach().to(torch.float32).contiguous()
+        w3 = w_e3_hwio.detach().to(torch.float32).contiguous()
+        ws = w_next_s_hwio.detach().to(torch.float32).contiguous() if w_next_s_hwio is not None else None
+        self.s, self.e1, self.e3 = int(w1.shape[2]), int(w1.shape[3]), int(w3.shape[3])
+        self.s2 = int(ws.shape[3]) if ws is not None else 0
+        if tuple(w1.shape[:2]) != (1, 1) or tuple(w3.shape[:3]) != (3, 3, self.s) or \
+                (ws is not None and tuple(ws.shape[:3]) != (1, 1, self.e1 + self.e3)):
+            raise _lib.SqdetError("FireChainStream: kernel shapes do not form expand1x1 / expand3x3 / next squeeze1x1")
+        self.dtype = dtype
+        code = dtype_code(dtype)
+        nbytes = lib().sqdet_fire_chain_stream_bytes(self.s, self.e1, self.e3, self.s2, code)
+        if nbytes == 0:
+            raise _lib.SqdetError("fire chain kernel does not cover s=%d e1=%d e3=%d next_s=%d %s"
+                                  % (self.s, self.e1, self.e3, self.s2, dtype))
+        self.data = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
+        check(lib().sqdet_fire_chain_pack(_dev(w1, "w_e1"), _dev(w3, "w_e3"), _dev(ws, "w_next_s") if ws is not None else None,
+                                          _dev(self.data, "stream"), self.s, self.e1, self.e3, self.s2, code, stream_ptr()),
+              "sqdet_fire_chain_pack")
+
+
+def fire_chain_supported(s, e1, e3, next_s, dtype):
+    return lib().sqdet_fire_chain_stream_bytes(int(s), int(e1), int(e3), int(next_s), dtype_code(dtype)) > 0
+
+
+def fire_chain(sq_in, chain, b_e1, b_e3, b_next_s=None, want_y=False):
+    """Expand half of a fire module + the next module's squeeze in one launch (sqdet_fire_chain_fwd).
+    sq_in [N,H,W,S] float16 = the module's squeeze tensor.  Returns (y or None, sq_out or None)."""
+    n, h, w, s = [int(v) for v in sq_in.shape]
+    if s != chain.s or sq_in.dtype != chain.dtype:
+        raise _lib.SqdetError("fire_chain: input does not match the packed stream")
+    y = torch.empty((n, h, w, chain.e1 + chain.e3), dtype=sq_in.dtype, device=sq_in.device) if (want_y or chain.s2 == 0) else None
+    so = torch.empty((n, h, w, chain.s2), dtype=sq_in.dtype, device=sq_in.device) if chain.s2 > 0 else None
+    check(lib().sqdet_fire_chain_fwd(_dev(sq_in, "sq_in"), _dev(chain.data, "stream"), _dev(b_e1, "b_e1", torch.float32),
+                                     _dev(b_e3, "b_e3", torch.float32),
+                                     _dev(b_next_s, "b_next_s", torch.float32) if chain.s2 > 0 else None,
+                                     _dev(y, "y") if y is not None else None, _dev(so, "sq_out") if so is not None else None,
+                                     n, h, w, chain.s, chain.e1, chain.e3, chain.s2, dtype_code(sq_in.dtype), stream_ptr()),
+          "sqdet_fire_chain_fwd")
+    return y, so
+
+
 # ---------------------------------------------------------------- post-processing
 def interpret_output(preds, anchors_f32, classes, anchors_per_grid, img_w, img_h, exp_thresh=1.0,
                      with_class_probs=False, out=None):

@@ -438,3 +438,57 @@ def test_fused_stem_conv_pool_parity(case, dtype):
     assert torch.equal(y, y2), "fused stem differs from conv -> pool"
     tol = dict(rtol=1e-3, atol=1e-4) if dtype == "fp32" else dict(rtol=2 ** -9, atol=1e-3)
     np.testing.assert_allclose(y.float().cpu().numpy(), ref, **tol)
+
+
+# (name, S, E, next_S, H, W, N): SqueezeDet's fire6..fire11 shapes on full and ragged maps; odd batch (the second image
+# of the last workgroup's pair does not exist); next_S = 0: expand only (fire11: the concat tensor is the output)
+CHAIN_CASES = [("fire6-7", 48, 192, 48, 24, 78, 2), ("fire7-8", 48, 192, 64, 11, 19, 3), ("fire8-9", 64, 256, 64, 24, 78, 1),
+               ("fire9-10", 64, 256, 96, 9, 31, 2), ("fire10-11", 96, 384, 96, 24, 78, 3), ("fire11", 96, 384, 0, 24, 78, 2),
+               ("fire11-ragged", 96, 384, 0, 13, 21, 5), ("fire7-only", 48, 192, 0, 8, 16, 1), ("one-pixel", 64, 256, 64, 1, 1, 1)]
+
+
+@pytest.mark.parametrize("want_y", [False, True])
+@pytest.mark.parametrize("case", CHAIN_CASES, ids=[c[0] for c in CHAIN_CASES])
+def test_fire_chain_parity(case, want_y):
+    """sqdet_fire_chain_fwd (expand1x1 || expand3x3 of one fire module + the squeeze1x1 of the next in one launch,
+    nets/squeezeDet.py:58-69,81-106; float16) BITWISE against the separate convs through memory, and against the
+    oracle in float16-storage mode (2 float16 ulps + 2e-3 abs: same tolerance as the fused fire module)."""
+    ops = _ops()
+    name, s, e, s2, H, W, N = case
+    tdt = torch.float16
+    rs = np.random.RandomState(zlib.crc32(("chain" + name).encode()) % (2 ** 31))
+    mk = lambda k, ci, co: torch.from_numpy((rs.randn(k, k, ci, co) * (2.0 / (k * k * ci)) ** 0.5).astype(np.float32)).half().float()
+    w1, w3 = mk(1, s, e), mk(3, s, e)
+    b1 = torch.from_numpy(rs.uniform(-0.3, 0.3, e).astype(np.float32))
+    b3 = torch.from_numpy(rs.uniform(-0.3, 0.3, e).astype(np.float32))
+    ws = mk(1, 2 * e, s2) if s2 else None
+    bs = torch.from_numpy(rs.uniform(-0.3, 0.3, s2).astype(np.float32)) if s2 else None
+    sq = torch.from_numpy(np.maximum(rs.randn(N, H, W, s), 0).astype(np.float32)).half()
+    chain = ops.FireChainStream(w1.to(DEV), w3.to(DEV), ws.to(DEV) if s2 else None, tdt)
+    sqd = sq.to(DEV).contiguous()
+    y, so = ops.fire_chain(sqd, chain, b1.to(DEV), b3.to(DEV), bs.to(DEV) if s2 else None, want_y=want_y)
+    # the separate launches
+    p1, p3 = ops.pack_conv_weights(w1.to(DEV), tdt), ops.pack_conv_weights(w3.to(DEV), tdt)
+    y_sep = torch.empty((N, H, W, 2 * e), dtype=tdt, device=DEV)
+    ops.conv2d_nhwc(sqd, p1, b1.to(DEV), 1, "SAME", True, out=y_sep, out_coffset=0)
+    ops.conv2d_nhwc(sqd, p3, b3.to(DEV), 1, "SAME", True, out=y_sep, out_coffset=e)
+    torch.cuda.synchronize()
+    if want_y or not s2:
+        assert y is not None and torch.equal(y, y_sep), "chain concat tensor differs from expand1x1 / expand3x3"
+    else:
+        assert y is None
+    # oracle (float16 storage)
+    e1o = O.conv_layer(sq.float(), w1, b1, 1, "SAME", True, storage="fp16")
+    e3o = O.conv_layer(sq.float(), w3, b3, 1, "SAME", True, storage="fp16")
+    cat = torch.cat([e1o, e3o], dim=3)
+    tol = dict(rtol=2 ** -8, atol=2e-3)
+    np.testing.assert_allclose(y_sep.float().cpu().numpy(), cat.numpy(), **tol)
+    if s2:
+        so_sep = ops.conv2d_nhwc(y_sep, ops.pack_conv_weights(ws.to(DEV), tdt), bs.to(DEV), 1, "SAME", True)
+        torch.cuda.synchronize()
+        assert torch.equal(so, so_sep), "chain squeeze tensor differs from the separate squeeze conv"
+        # the oracle squeeze on the DEVICE's concat tensor (one conv of error, like every other conv test)
+        s_ref = O.conv_layer(y_sep.float().cpu(), ws, bs, 1, "SAME", True, storage="fp16")
+        np.testing.assert_allclose(so.float().cpu().numpy(), s_ref.numpy(), **tol)
+    else:
+        assert so is None

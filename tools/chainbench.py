@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Late-map fire modules (fire6..fire11 at batch 32, 24x78, float16): the chain kernel (expand + next squeeze in one
+launch, sqdet_fire_chain_fwd) against the one-launch fused fire module (sqdet_fire_fwd), HIP events, interleaved.
+
+    python tools/chainbench.py [--batch 32] [--iters 20]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from squeezedet_amd import ops  # noqa: E402
+from tools.kbench import timeit  # noqa: E402
+
+LATE = [("fire6", 256, 48, 192), ("fire7", 384, 48, 192), ("fire8", 384, 64, 256), ("fire9", 512, 64, 256),
+        ("fire10", 512, 96, 384), ("fire11", 768, 96, 384)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--h", type=int, default=24)
+    ap.add_argument("--w", type=int, default=78)
+    ap.add_argument("--iters", type=int, default=20)
+    args = ap.parse_args()
+    dev, dt = "cuda:0", torch.float16
+    g = torch.Generator(device="cpu").manual_seed(0)
+    mkw = lambda k, ci, co: (torch.randn((k, k, ci, co), generator=g) * (2.0 / (k * k * ci)) ** 0.5).to(dev)
+    print("%-8s %10s %10s %10s %10s %9s" % ("module", "fused_ms", "squeeze_ms", "chain_ms", "chain+y", "chain TF/s"))
+    tot = [0.0, 0.0, 0.0]
+    npx = args.batch * args.h * args.w
+    for i, (name, cin, s, e) in enumerate(LATE):
+        s2 = LATE[i + 1][2] if i + 1 < len(LATE) else 0
+        x = torch.randn((args.batch, args.h, args.w, cin), generator=g).clamp_(min=0).to(dev, dt)
+        ws, w1, w3 = mkw(1, cin, s), mkw(1, s, e), mkw(3, s, e)
+        wn = mkw(1, 2 * e, s2) if s2 else None
+        ps, p1, p3 = [ops.pack_conv_weights(w_, dt) for w_ in (ws, w1, w3)]
+        bz = [torch.zeros(n_, device=dev) for n_ in (s, e, e, max(s2, 1))]
+        t_fused = timeit(lambda: ops.fire(x, ps, bz[0], p1, bz[1], p3, bz[2]), args.iters)
+        sq = torch.empty((args.batch, args.h, args.w, s), dtype=dt, device=dev)
+        t_sq = timeit(lambda: ops.conv2d_nhwc(x, ps, bz[0], 1, "SAME", True, out=sq), args.iters)
+        chain = ops.FireChainStream(w1, w3, wn, dt)
+        t_chain = timeit(lambda: ops.fire_chain(sq, chain, bz[1], bz[2], bz[3] if s2 else None), args.iters)
+        t_cy = timeit(lambda: ops.fire_chain(sq, chain, bz[1], bz[2], bz[3] if s2 else None, want_y=True), args.iters)
+        flops = 2.0 * npx * (s * e * 10 + 2 * e * s2)
+        print("%-8s %10.4f %10.4f %10.4f %10.4f %9.1f" % (name, t_fused, t_sq, t_chain, t_cy, flops / t_chain / 1e9))
+        tot[0] += t_fused
+        tot[1] += t_chain
+        tot[2] += t_sq if i == 0 else 0.0
+    print("sum fused %.4f ms; chain %.4f ms (+ first squeeze %.4f ms)" % tuple(tot))
+
+
+if __name__ == "__main__":
+    main()
