@@ -66,6 +66,7 @@ struct ChainArgs {
   int tiles_x, tiles_y;
   int nb1, nb3, nstages;
   unsigned in_bytes, out_bytes, y_bytes;
+  int dbg;   // experiments (sqdet_set_option "dbg"): 50 no vmcnt waits, 51 no weight stream at all, 52 no barriers either, 55 prologue only
 };
 
 // One 1-KiB piece of the weight stream straight into LDS (no registers).  Hidden from hipcc's wait-count pass on
@@ -82,21 +83,6 @@ __device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned lds_d
 template <int N>
 __device__ __forceinline__ void vm_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// at most `left` stages of 3 pieces (+ `extra` younger stores) may still be in flight
-__device__ __forceinline__ void vm_wait_stages(int left, bool extra8) {
-  if (!extra8) {
-    if (left >= 3) vm_wait<9>();
-    else if (left == 2) vm_wait<6>();
-    else if (left == 1) vm_wait<3>();
-    else vm_wait<0>();
-  } else {
-    if (left >= 3) vm_wait<17>();
-    else if (left == 2) vm_wait<14>();
-    else if (left == 1) vm_wait<11>();
-    else vm_wait<8>();
-  }
 }
 
 __device__ __forceinline__ i32x4 pack8(const f32x4& a, const f32x4& b) {
@@ -121,7 +107,7 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
 
   int b = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));   // XCD-banded order (gridDim.x % 8 == 0)
   const int npairs = (a.N + 1) >> 1;
-  if (b >= npairs * a.tiles_x * a.tiles_y) return;
+  if (b >= npairs * a.tiles_x * a.tiles_y || a.dbg == 56) return;
   const int tx = b % a.tiles_x; b /= a.tiles_x;
   const int ty = b % a.tiles_y;
   const int np = b / a.tiles_y;
@@ -132,11 +118,39 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
   float* bl = reinterpret_cast<float*>(stile + NIMG * NCH * CCHUNK);   // biases [b1 | b3 | bs2]
   const unsigned ring_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)ring;
 
+  // ---------------------------------------------------------------- squeeze tile (both images, with halo): loads
+  constexpr int NP = NCH * 4;                         // 16-byte pieces per pixel in LDS (zero padded)
+  constexpr int SIT = (NIMG * CHP * NP + 255) / 256;  // pieces per thread
+  i32x4 sv[SIT];
+  {
+    const int s_pieces = a.S * 2 / 16;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.sq_in), 0, a.in_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+      const int idx = it * 256 + (int)threadIdx.x;
+      const int im = idx / (CHP * NP);
+      const int rem = idx - im * (CHP * NP);
+      const int P = rem / NP, q = rem - P * NP;
+      const int r = P / (CCOLS + 2), c = P - r * (CCOLS + 2);
+      const int iy = oy0 - 1 + r, ix = ox0 - 1 + c;
+      const int n = np * 2 + im;
+      const bool ok = idx < NIMG * CHP * NP && q < s_pieces && n < a.N && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const unsigned off = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.S) * 2 + q * 16) : OOB;
+      sv[it] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);   // out of range = the zero padding
+    }
+  }
+
   // ---------------------------------------------------------------- the weight stream
+  // (the stream carries three dummy stages behind the last real one: exactly three stages are in flight behind
+  // the one being waited for at EVERY sync, so the wait count is a constant)
   const unsigned char* gl = a.stream + wave * 1024 + lane * 16;     // this lane's 16 bytes of every slot's quarter
-  int ks = 0;    // stages made available so far (= index of the next one to wait for)
-  int ib = 0;    // ring buffer the next refill goes to
+  const int nissue = a.nstages + 3;
+  int ks = 0;        // stages made available so far (= index of the next one to wait for)
+  int ib = 0;        // ring buffer the next refill goes to
+  int pend = -1;     // stage whose refill is due (issued a few MFMAs behind the barrier, a different few per wave)
   auto issue = [&](int stage) {
+    if (a.dbg == 51 || a.dbg == 52) return;
     const unsigned char* src = gl + (size_t)stage * STAGE_B;
     const unsigned dst = ring_addr + (unsigned)ib * STAGE_B + (unsigned)wave * 1024;
     glds16(src, dst);
@@ -144,27 +158,22 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
     glds16(src + 8192, dst + 8192);
     ib = ib + 1 == RING ? 0 : ib + 1;
   };
+  auto refill = [&]() {
+    if (pend >= 0) { issue(pend); pend = -1; }
+  };
 #pragma unroll
-  for (int s = 0; s < RING - 2; ++s)
-    if (s < a.nstages) issue(s);
+  for (int s = 0; s < RING - 2; ++s) issue(s);   // (nissue >= 4 always)
 
-  // ---------------------------------------------------------------- squeeze tile (both images, with halo) -> LDS
+  // ---------------------------------------------------------------- squeeze tile + biases -> LDS
   {
-    constexpr int NP = NCH * 4;                       // 16-byte pieces per pixel in LDS (zero padded)
-    const int s_pieces = a.S * 2 / 16;
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.sq_in), 0, a.in_bytes, 0x00020000);
-    constexpr unsigned OOB = 0xfffffff0u;
-    for (int idx = threadIdx.x; idx < NIMG * CHP * NP; idx += 256) {
-      const int img = idx / (CHP * NP);
-      const int rem = idx - img * (CHP * NP);
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+      const int idx = it * 256 + (int)threadIdx.x;
+      const int im = idx / (CHP * NP);
+      const int rem = idx - im * (CHP * NP);
       const int P = rem / NP, q = rem - P * NP;
-      const int r = P / (CCOLS + 2), c = P - r * (CCOLS + 2);
-      const int iy = oy0 - 1 + r, ix = ox0 - 1 + c;
-      const int n = np * 2 + img;
-      const bool ok = q < s_pieces && n < a.N && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const unsigned off = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.S) * 2 + q * 16) : OOB;
-      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);   // out of range = the zero padding
-      *reinterpret_cast<i32x4*>(stile + (img * NCH + (q >> 2)) * CCHUNK + P * 64 + (((q & 3) ^ ((P >> 1) & 3)) << 4)) = v;
+      if (idx < NIMG * CHP * NP)
+        *reinterpret_cast<i32x4*>(stile + (im * NCH + (q >> 2)) * CCHUNK + P * 64 + (((q & 3) ^ ((P >> 1) & 3)) << 4)) = sv[it];
     }
     const int nbias = a.E1 + a.E3 + a.S2;
     for (int i = threadIdx.x; i < nbias; i += 256)
@@ -185,16 +194,18 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
   };
   int ep_ks = -100;   // ks at the time of the last concat-tensor stores (WY only)
   // Makes the NEXT stage available: every wave's pieces of it have landed (own vmcnt, then the barrier), and
-  // every wave is past stage ks-2 -- its ring buffer takes the refill.
+  // every wave is past stage ks-2 -- its ring buffer takes the refill (issued by refill(), a few MFMAs later).
+  // Three younger stages (9 pieces) are in flight behind it; the 8 concat-tensor stores of a block epilogue are
+  // younger than stage ks's pieces for the next four syncs (loads and stores retire in issue order).
   auto sync = [&]() {
-    if (ks < a.nstages) {
-      const int left = min(RING - 3, a.nstages - 1 - ks);
-      vm_wait_stages(left, WY && (ks - ep_ks) <= 3);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const int nk = ks + RING - 2;
-      if (nk < a.nstages) issue(nk);
+    if (a.dbg < 50 || a.dbg > 52) {
+      if (WY && (ks - ep_ks) <= 3) vm_wait<17>();
+      else vm_wait<9>();
     }
+    if (a.dbg != 52) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int nk = ks + RING - 2;
+    pend = nk < nissue ? nk : -1;
     ++ks;
   };
   auto next_buf = [&]() { cb = cb + 1 == RING ? 0 : cb + 1; };
@@ -211,8 +222,10 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
   const int ox = ox0 + j;
   const bool col_ok = ox < a.W && n_img < a.N;
 
+  if (a.dbg == 55) { vm_wait<0>(); return; }
   i32x4 an[4];      // first four fragments of the stage about to be consumed
   sync();           // stage 0
+  refill();
 #pragma unroll
   for (int t = 0; t < 4; ++t) an[t] = lda(0, t);
 
@@ -264,7 +277,9 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
         const int u = f / NSQ, t = f - u * NSQ;
 #pragma unroll
         for (int m = 0; m < 4; ++m) mma16<T>(accs[t][m], fr[f], bf[m][u]);
+        if (f - SPLIT == wave) refill();
       }
+      refill();
       next_buf();
     }
   };
@@ -299,9 +314,11 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
           for (int t = 0; t < 4; ++t) nx[t] = lda(nb, t);
         }
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) mma16<T>(acc[m][t], ac[t], b1f[c][m]);
+          if (c + 1 == NCH && m == wave) refill();
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) ac[t] = nx[t];
       }
@@ -313,6 +330,14 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
   }
 
   // ---------------------------------------------------------------- expand3x3 blocks
+  // The 18 B fragments of a K chunk (6 halo rows x 3 column shifts) serve its nine taps.  They are fetched while
+  // the MFMAs run: rows 0,1 of the NEXT chunk during this chunk's last tap row (which reads rows 2..5), rows 2..4
+  // behind the first MFMAs of the chunk (tap row 0 starts on rows 0,1), row 5 during tap row 0.
+  i32x4 B[6][3];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) B[rr][dx] = load_b(0, rr, dx);
 #pragma unroll 1
   for (int blk = 0; blk < a.nb3; ++blk) {
     f32x4 acc[4][4];
@@ -325,13 +350,22 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
     for (int t = 0; t < 4; ++t) ac[t] = an[t];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      i32x4 B[6][3];
-#pragma unroll
-      for (int rr = 0; rr < 6; ++rr)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) B[rr][dx] = load_b(c, rr, dx);
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
+        if (dy == 0) {
+#pragma unroll
+          for (int rr = 2; rr < 5; ++rr)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) B[rr][dx] = load_b(c, rr, dx);
+        } else if (dy == 1) {
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) B[5][dx] = load_b(c, 5, dx);
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) B[rr][dx] = load_b((c + 1) % NCH, rr, dx);
+        }
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
           i32x4 nx[4];
@@ -345,9 +379,11 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
             for (int t = 0; t < 4; ++t) nx[t] = lda(nb, t);
           }
 #pragma unroll
-          for (int m = 0; m < 4; ++m)
+          for (int m = 0; m < 4; ++m) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) mma16<T>(acc[m][t], ac[t], B[m + dy][dx]);
+            if (dx == 2 && m == wave) refill();
+          }
 #pragma unroll
           for (int t = 0; t < 4; ++t) ac[t] = nx[t];
         }
@@ -358,6 +394,7 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
     for (int t = 0; t < 4; ++t) an[t] = ac[t];
     finish_block(acc, a.E1 + blk * 64);
   }
+  vm_wait<0>();   // the dummy stages have landed (nobody reads them) before this wave's LDS can be handed on
 
   // ---------------------------------------------------------------- next squeeze: bias + ReLU -> sq_out
   if constexpr (NSQ > 0) {
@@ -481,7 +518,7 @@ using namespace sqdet;
 
 extern "C" size_t sqdet_fire_chain_stream_bytes(int s1x1, int e1x1, int e3x3, int next_s1x1, int dtype) {
   if (!fire_chain_eligible(s1x1, e1x1, e3x3, next_s1x1, dtype)) return 0;
-  return (size_t)chain_geom(s1x1, e1x1, e3x3, next_s1x1).nstages * STAGE_B;
+  return (size_t)(chain_geom(s1x1, e1x1, e3x3, next_s1x1).nstages + 3) * STAGE_B;   // + the dummy stages
 }
 
 extern "C" int sqdet_fire_chain_pack(const float* w_e1_hwio, const float* w_e3_hwio, const float* w_next_s_hwio,
@@ -518,6 +555,7 @@ extern "C" int sqdet_fire_chain_fwd(const void* sq_in, const void* stream_buf, c
   a.in_bytes = (unsigned)(px * s1x1 * 2);
   a.out_bytes = (unsigned)(px * next_s1x1 * 2);
   a.y_bytes = (unsigned)(px * (e1x1 + e3x3) * 2);
+  a.dbg = tune(TUNE_DBG);
   hipStream_t st = as_stream(stream);
   if (g.nch == 2) return y ? dispatch_chain_nsq<2, true>(a, g.nsq, st) : dispatch_chain_nsq<2, false>(a, g.nsq, st);
   return y ? dispatch_chain_nsq<3, true>(a, g.nsq, st) : dispatch_chain_nsq<3, false>(a, g.nsq, st);

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--h", type=int, default=24)
     ap.add_argument("--w", type=int, default=78)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--dbg", default="", help="comma list of dbg knob values to time the chain kernel under (wrong results)")
     args = ap.parse_args()
     dev, dt = "cuda:0", torch.float16
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -45,6 +46,11 @@ def main():
         t_chain = timeit(lambda: ops.fire_chain(sq, chain, bz[1], bz[2], bz[3] if s2 else None), args.iters)
         t_cy = timeit(lambda: ops.fire_chain(sq, chain, bz[1], bz[2], bz[3] if s2 else None, want_y=True), args.iters)
         flops = 2.0 * npx * (s * e * 10 + 2 * e * s2)
+        for d in [int(v) for v in args.dbg.split(",") if v]:
+            ops.set_option("dbg", d)
+            td = timeit(lambda: ops.fire_chain(sq, chain, bz[1], bz[2], bz[3] if s2 else None), args.iters)
+            ops.set_option("dbg", 0)
+            print("   dbg %d: %.4f ms" % (d, td))
         print("%-8s %10.4f %10.4f %10.4f %10.4f %9.1f" % (name, t_fused, t_sq, t_chain, t_cy, flops / t_chain / 1e9))
         tot[0] += t_fused
         tot[1] += t_chain
