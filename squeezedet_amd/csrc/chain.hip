@@ -35,7 +35,6 @@ namespace {
 constexpr int CROWS = 8, CCOLS = 16;
 constexpr int CHP = (CROWS + 2) * (CCOLS + 2);   // 180 halo pixels of one image's tile
 constexpr int CCHUNK = CHP * 64;                 // bytes of one 64-byte K chunk of a tile
-constexpr int RING = 6;                          // ring stages
 constexpr int STAGE_B = 12288;                   // 3 slots of 4 KiB
 constexpr int NIMG = 2;
 
@@ -66,18 +65,14 @@ struct ChainArgs {
   int tiles_x, tiles_y;
   int nb1, nb3, nstages;
   unsigned in_bytes, out_bytes, y_bytes;
-  int dbg;   // experiments (sqdet_set_option "dbg"): 50 no vmcnt waits, 51 no weight stream at all, 52 no barriers either, 55 prologue only
 };
 
-// One 1-KiB piece of the weight stream straight into LDS (no registers).  Hidden from hipcc's wait-count pass on
-// purpose: its completion is counted by hand (vm_wait below).  M0 = the wave-uniform LDS byte address.
-__device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst)
-      : "memory");
+// One 1-KiB piece of the weight stream straight into LDS (no registers): global address = wave-uniform `sbase` +
+// per-lane `voff`, LDS address = M0 (wave-uniform) + lane * 16.  Hidden from hipcc's wait-count pass on purpose:
+// its completion is counted by hand (vm_wait below).  (hipcc has no other use for M0 in this kernel: gfx9 LDS
+// instructions do not read it.)
+__device__ __forceinline__ void glds16(unsigned voff, const unsigned char* sbase, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
 template <int N>
@@ -96,31 +91,42 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 }
 
 // NCH: 64-byte chunks of the squeeze channels (2 or 3); NSQ: 16-wide tiles of the next squeeze (0 = none, 3, 4, 6);
-// WY: the concat tensor is written.
-template <int NCH, int NSQ, bool WY>
-__global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
+// WY: the concat tensor is written; RING: ring stages (6, or 4 where the exchange area leaves no room for more).
+//
+// Eight waves, two per SIMD (<= 256 registers): wave = (pixel group pg = wave & 3, cout half h = wave >> 2).  The
+// two waves of a pixel group sit on the same SIMD and own the two tile PAIRS of every 64-cout block, i.e. the two
+// K chunks that block contributes to the next squeeze; they swap their rounded float16 results through a 4-KiB
+// LDS slot each (behind the barrier the chain stage has anyway) and each accumulates HALF of the squeeze's cout
+// tiles over both chunks, in the canonical order.  While one wave of a SIMD waits -- for a barrier, an LDS
+// fragment, the ~60 cycles an LDS-DMA issue takes -- the other one keeps the matrix pipe busy.
+template <int NCH, int NSQ, bool WY, int RING>
+__global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
   using T = f16;
+  constexpr int LOOK = RING - 2;            // stages issued ahead of the one being consumed
+  constexpr int TH = (NSQ + 1) / 2;         // squeeze tiles per wave of a pair
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int pg = wave & 3, h = wave >> 2;
   const int j = lane & 15, g = lane >> 4;
 
   int b = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));   // XCD-banded order (gridDim.x % 8 == 0)
   const int npairs = (a.N + 1) >> 1;
-  if (b >= npairs * a.tiles_x * a.tiles_y || a.dbg == 56) return;
+  if (b >= npairs * a.tiles_x * a.tiles_y) return;
   const int tx = b % a.tiles_x; b /= a.tiles_x;
   const int ty = b % a.tiles_y;
   const int np = b / a.tiles_y;
   const int oy0 = ty * CROWS, ox0 = tx * CCOLS;
 
   unsigned char* ring = lds;
-  unsigned char* stile = lds + RING * STAGE_B;                      // [img][chunk][pixel][4 x 16 B swizzled]
-  float* bl = reinterpret_cast<float*>(stile + NIMG * NCH * CCHUNK);   // biases [b1 | b3 | bs2]
+  unsigned char* stile = lds + RING * STAGE_B;                         // [img][chunk][pixel][4 x 16 B swizzled]
+  unsigned char* xch = stile + NIMG * NCH * CCHUNK;                    // [wave][m][lane][16 B] (NSQ > 0)
+  float* bl = reinterpret_cast<float*>(xch + (NSQ > 0 ? 32768 : 0));   // biases [b1 | b3 | bs2]
   const unsigned ring_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)ring;
 
   // ---------------------------------------------------------------- squeeze tile (both images, with halo): loads
   constexpr int NP = NCH * 4;                         // 16-byte pieces per pixel in LDS (zero padded)
-  constexpr int SIT = (NIMG * CHP * NP + 255) / 256;  // pieces per thread
+  constexpr int SIT = (NIMG * CHP * NP + 511) / 512;  // pieces per thread
   i32x4 sv[SIT];
   {
     const int s_pieces = a.S * 2 / 16;
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
     constexpr unsigned OOB = 0xfffffff0u;
 #pragma unroll
     for (int it = 0; it < SIT; ++it) {
-      const int idx = it * 256 + (int)threadIdx.x;
+      const int idx = it * 512 + (int)threadIdx.x;
       const int im = idx / (CHP * NP);
       const int rem = idx - im * (CHP * NP);
       const int P = rem / NP, q = rem - P * NP;
@@ -142,33 +148,28 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
   }
 
   // ---------------------------------------------------------------- the weight stream
-  // (the stream carries three dummy stages behind the last real one: exactly three stages are in flight behind
-  // the one being waited for at EVERY sync, so the wait count is a constant)
-  const unsigned char* gl = a.stream + wave * 1024 + lane * 16;     // this lane's 16 bytes of every slot's quarter
-  const int nissue = a.nstages + 3;
-  int ks = 0;        // stages made available so far (= index of the next one to wait for)
-  int ib = 0;        // ring buffer the next refill goes to
-  int pend = -1;     // stage whose refill is due (issued a few MFMAs behind the barrier, a different few per wave)
-  auto issue = [&](int stage) {
-    if (a.dbg == 51 || a.dbg == 52) return;
-    const unsigned char* src = gl + (size_t)stage * STAGE_B;
-    const unsigned dst = ring_addr + (unsigned)ib * STAGE_B + (unsigned)wave * 1024;
-    glds16(src, dst);
-    glds16(src + 4096, dst + 4096);
-    glds16(src + 8192, dst + 8192);
-    ib = ib + 1 == RING ? 0 : ib + 1;
-  };
+  // A stage is 12 one-KiB pieces (3 slots x 4 fragments): waves 0-3 fetch pieces w and 8 + w, waves 4-7 piece w.
+  // EVERY sync is followed by one refill (the stream buffer carries LOOK + 1 dummy stages behind the last real
+  // one), so exactly LOOK - 1 stages are in flight behind the one being waited for: the wait count is a constant
+  // per wave and the steady state needs no bookkeeping beyond two wrapping ring offsets.
+  const unsigned voff1 = (unsigned)(wave * 1024 + lane * 16), voff2 = voff1 + 8192;
+  const unsigned char* sp = a.stream;                                    // next stage to request
+  const unsigned m0_lo = ring_addr + (unsigned)wave * 1024;
+  unsigned m0n = m0_lo;                                                  // LDS address its pieces go to
   auto refill = [&]() {
-    if (pend >= 0) { issue(pend); pend = -1; }
+    glds16(voff1, sp, m0n);
+    if (h == 0) glds16(voff2, sp, m0n + 8192);
+    sp += STAGE_B;
+    m0n = m0n + STAGE_B == m0_lo + RING * STAGE_B ? m0_lo : m0n + STAGE_B;
   };
 #pragma unroll
-  for (int s = 0; s < RING - 2; ++s) issue(s);   // (nissue >= 4 always)
+  for (int s = 0; s < LOOK; ++s) refill();
 
   // ---------------------------------------------------------------- squeeze tile + biases -> LDS
   {
 #pragma unroll
     for (int it = 0; it < SIT; ++it) {
-      const int idx = it * 256 + (int)threadIdx.x;
+      const int idx = it * 512 + (int)threadIdx.x;
       const int im = idx / (CHP * NP);
       const int rem = idx - im * (CHP * NP);
       const int P = rem / NP, q = rem - P * NP;
@@ -176,43 +177,44 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
         *reinterpret_cast<i32x4*>(stile + (im * NCH + (q >> 2)) * CCHUNK + P * 64 + (((q & 3) ^ ((P >> 1) & 3)) << 4)) = sv[it];
     }
     const int nbias = a.E1 + a.E3 + a.S2;
-    for (int i = threadIdx.x; i < nbias; i += 256)
+    for (int i = threadIdx.x; i < nbias; i += 512)
       bl[i] = i < a.E1 ? a.b1[i] : (i < a.E1 + a.E3 ? a.b3[i - a.E1] : a.bs2[i - a.E1 - a.E3]);
   }
   __syncthreads();
 
-  const int img = wave >> 1, r0 = (wave & 1) * 4;
+  const int img = pg >> 1, r0 = (pg & 1) * 4;
   const unsigned char* simg = stile + img * NCH * CCHUNK;
   // B fragment of (chunk c, halo row rr of this wave = tile row r0 - 1 + rr, column shift dx)
   auto load_b = [&](int c, int rr, int dx) {
     const int P = (r0 + rr) * (CCOLS + 2) + j + dx;
     return *reinterpret_cast<const i32x4*>(simg + c * CCHUNK + P * 64 + ((g ^ ((P >> 1) & 3)) << 4));
   };
-  int cb = 0;    // ring buffer of the stage being consumed
-  auto lda = [&](int buf, int f) {
-    return *reinterpret_cast<const i32x4*>(ring + buf * STAGE_B + f * 1024 + lane * 16);
+  unsigned cbo = 0, nbo = STAGE_B;   // ring offsets of the stage being consumed and of the next one
+  auto lda = [&](unsigned bo, int f) {
+    return *reinterpret_cast<const i32x4*>(ring + bo + f * 1024 + lane * 16);
   };
-  int ep_ks = -100;   // ks at the time of the last concat-tensor stores (WY only)
+  int ks = 0, ep_ks = -100;   // (WY only) syncs so far, and their number at the time of the last concat-tensor stores
   // Makes the NEXT stage available: every wave's pieces of it have landed (own vmcnt, then the barrier), and
-  // every wave is past stage ks-2 -- its ring buffer takes the refill (issued by refill(), a few MFMAs later).
-  // Three younger stages (9 pieces) are in flight behind it; the 8 concat-tensor stores of a block epilogue are
-  // younger than stage ks's pieces for the next four syncs (loads and stores retire in issue order).
-  auto sync = [&]() {
-    if (a.dbg < 50 || a.dbg > 52) {
-      if (WY && (ks - ep_ks) <= 3) vm_wait<17>();
-      else vm_wait<9>();
-    }
-    if (a.dbg != 52) __builtin_amdgcn_s_barrier();
+  // every wave is past the stage before the current one -- its ring buffer takes the refill that follows.
+  // LOOK - 1 younger stages are in flight behind it; the 4 concat-tensor stores of a block epilogue are younger
+  // than the awaited pieces for the next LOOK syncs (loads and stores retire in issue order).
+  auto sync = [&](bool lds_writes) {
+    bool st = false;
+    if constexpr (WY) { st = (ks - ep_ks) < LOOK; ++ks; }
+    if (h == 0) { if (st) vm_wait<2 * (LOOK - 1) + 4>(); else vm_wait<2 * (LOOK - 1)>(); }
+    else { if (st) vm_wait<(LOOK - 1) + 4>(); else vm_wait<(LOOK - 1)>(); }
+    if (lds_writes) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const int nk = ks + RING - 2;
-    pend = nk < nissue ? nk : -1;
-    ++ks;
   };
-  auto next_buf = [&]() { cb = cb + 1 == RING ? 0 : cb + 1; };
+  auto next_buf = [&]() {
+    cbo = nbo;
+    nbo = nbo + STAGE_B == RING * STAGE_B ? 0 : nbo + STAGE_B;
+  };
 
-  f32x4 accs[NSQ > 0 ? NSQ : 1][4];
+  f32x4 accs[TH > 0 ? TH : 1][4];
 #pragma unroll
-  for (int t = 0; t < (NSQ > 0 ? NSQ : 1); ++t)
+  for (int t = 0; t < (TH > 0 ? TH : 1); ++t)
 #pragma unroll
     for (int m = 0; m < 4; ++m) accs[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -222,64 +224,66 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
   const int ox = ox0 + j;
   const bool col_ok = ox < a.W && n_img < a.N;
 
-  if (a.dbg == 55) { vm_wait<0>(); return; }
-  i32x4 an[4];      // first four fragments of the stage about to be consumed
-  sync();           // stage 0
+  i32x4 an[2];      // this wave's two fragments (tiles 2h, 2h+1) of slot 0 of the stage about to be consumed
+  sync(false);      // stage 0
   refill();
 #pragma unroll
-  for (int t = 0; t < 4; ++t) an[t] = lda(0, t);
+  for (int n = 0; n < 2; ++n) an[n] = lda(0, 2 * h + n);
 
-  // Block epilogue: bias + ReLU + float16 rounding of the 64 couts (concat channels cc0 .. cc0+64) of this wave's
+  // Block epilogue: bias + ReLU + float16 rounding of this wave's 32 couts (concat channels cc0 + 32h .. +32) of its
   // 64 pixels; optional store; chain into the next squeeze (consumes one ring stage: Ws2 rows cc0 .. cc0+64).
-  auto finish_block = [&](f32x4 (&acc)[4][4], int cc0) {
-    i32x4 bf[4][2];
+  auto finish_block = [&](f32x4 (&acc)[4][2], int cc0) {
+    i32x4 bf[4];
+    {
+      const f32x4 bias0 = *reinterpret_cast<const f32x4*>(bl + cc0 + h * 32 + g * 8);
+      const f32x4 bias1 = *reinterpret_cast<const f32x4*>(bl + cc0 + h * 32 + g * 8 + 4);
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const f32x4 bias0 = *reinterpret_cast<const f32x4*>(bl + cc0 + p * 32 + g * 8);
-      const f32x4 bias1 = *reinterpret_cast<const f32x4*>(bl + cc0 + p * 32 + g * 8 + 4);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) bf[m][p] = pack8(relu4(acc[m][2 * p] + bias0), relu4(acc[m][2 * p + 1] + bias1));
+      for (int m = 0; m < 4; ++m) bf[m] = pack8(relu4(acc[m][0] + bias0), relu4(acc[m][1] + bias1));
     }
     if (WY) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int oy = oy0 + r0 + m;
         const bool ok = col_ok && oy < a.H;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const unsigned off = ok ? (unsigned)((((n_img * a.H + oy) * a.W + ox) * ctot + cc0 + p * 32 + g * 8) * 2) : 0xfffffff0u;
-          __builtin_amdgcn_raw_buffer_store_b128(bf[m][p], ry, off, 0, 0);   // out of range = dropped
-        }
+        const unsigned off = ok ? (unsigned)((((n_img * a.H + oy) * a.W + ox) * ctot + cc0 + h * 32 + g * 8) * 2) : 0xfffffff0u;
+        __builtin_amdgcn_raw_buffer_store_b128(bf[m], ry, off, 0, 0);   // out of range = dropped
       }
       ep_ks = ks;
     }
     if constexpr (NSQ > 0) {
-      // chain stage: fragments f = u * NSQ + t (u = chunk of the pair, t = squeeze tile), an = fragments 0..3
-      constexpr int NF = 2 * NSQ;
-      i32x4 fr[NF];
+      // chain stage: ring fragments f = u * NSQ + t (u = chunk = the pair member that produced it, t = squeeze tile);
+      // this wave accumulates tiles h*TH .. (+TH) over u = 0, 1 in that order
+      i32x4 fr[2][TH];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) fr[f] = an[f];
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int f = 4; f < NF; ++f) fr[f] = lda(cb, f);
-      constexpr int SPLIT = NF > 8 ? 8 : (NF > 4 ? 4 : 0);   // the last group of MFMAs runs behind the next sync
+        for (int i = 0; i < TH; ++i) {
+          const int t = min(h * TH + i, NSQ - 1);
+          fr[u][i] = lda(cbo, u * NSQ + t);
+        }
 #pragma unroll
-      for (int f = 0; f < SPLIT; ++f) {
-        const int u = f / NSQ, t = f - u * NSQ;
+      for (int m = 0; m < 4; ++m)
+        *reinterpret_cast<i32x4*>(xch + (wave * 4 + m) * 1024 + lane * 16) = bf[m];
+      sync(true);
+      i32x4 bo[4];   // the partner's chunk
 #pragma unroll
-        for (int m = 0; m < 4; ++m) mma16<T>(accs[t][m], fr[f], bf[m][u]);
+      for (int m = 0; m < 4; ++m) bo[m] = *reinterpret_cast<const i32x4*>(xch + ((wave ^ 4) * 4 + m) * 1024 + lane * 16);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) an[n] = lda(nbo, 2 * h + n);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int i = 0; i < TH; ++i) {
+          if (h * TH + i < NSQ) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              const i32x4 bv = (u == h) ? bf[m] : bo[m];
+              mma16<T>(accs[i][m], fr[u][i], bv);
+            }
+          }
+          if (u == 0 && i == 0) refill();
+        }
       }
-      sync();
-      const int nb = cb + 1 == RING ? 0 : cb + 1;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) an[t] = lda(nb, t);
-#pragma unroll
-      for (int f = SPLIT; f < NF; ++f) {
-        const int u = f / NSQ, t = f - u * NSQ;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) mma16<T>(accs[t][m], fr[f], bf[m][u]);
-        if (f - SPLIT == wave) refill();
-      }
-      refill();
       next_buf();
     }
   };
@@ -293,37 +297,36 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
       for (int m = 0; m < 4; ++m) b1f[c][m] = load_b(c, m + 1, 1);
 #pragma unroll 1
     for (int blk = 0; blk < a.nb1; ++blk) {
-      f32x4 acc[4][4];
+      f32x4 acc[4][2];
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      i32x4 ac[4];
+        for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      i32x4 ac[2];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) ac[t] = an[t];
+      for (int n = 0; n < 2; ++n) ac[n] = an[n];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        i32x4 nx[4];
+        i32x4 nx[2];
         if (c + 1 < NCH) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) nx[t] = lda(cb, (c + 1) * 4 + t);
+          for (int n = 0; n < 2; ++n) nx[n] = lda(cbo, (c + 1) * 4 + 2 * h + n);
         } else {
-          sync();
-          const int nb = cb + 1 == RING ? 0 : cb + 1;
+          sync(false);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) nx[t] = lda(nb, t);
+          for (int n = 0; n < 2; ++n) nx[n] = lda(nbo, 2 * h + n);
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) mma16<T>(acc[m][t], ac[t], b1f[c][m]);
-          if (c + 1 == NCH && m == wave) refill();
+          for (int n = 0; n < 2; ++n) mma16<T>(acc[m][n], ac[n], b1f[c][m]);
+          if (c + 1 == NCH && m == 1) refill();
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) ac[t] = nx[t];
+        for (int n = 0; n < 2; ++n) ac[n] = nx[n];
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) an[t] = ac[t];
+      for (int n = 0; n < 2; ++n) an[n] = ac[n];
       next_buf();
       finish_block(acc, blk * 64);
     }
@@ -340,14 +343,14 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
     for (int dx = 0; dx < 3; ++dx) B[rr][dx] = load_b(0, rr, dx);
 #pragma unroll 1
   for (int blk = 0; blk < a.nb3; ++blk) {
-    f32x4 acc[4][4];
+    f32x4 acc[4][2];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    i32x4 ac[4];
+      for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    i32x4 ac[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) ac[t] = an[t];
+    for (int n = 0; n < 2; ++n) ac[n] = an[n];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
 #pragma unroll
@@ -368,33 +371,32 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
         }
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-          i32x4 nx[4];
+          i32x4 nx[2];
           if (dx < 2) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) nx[t] = lda(cb, (dx + 1) * 4 + t);
+            for (int n = 0; n < 2; ++n) nx[n] = lda(cbo, (dx + 1) * 4 + 2 * h + n);
           } else {
-            sync();
-            const int nb = cb + 1 == RING ? 0 : cb + 1;
+            sync(false);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) nx[t] = lda(nb, t);
+            for (int n = 0; n < 2; ++n) nx[n] = lda(nbo, 2 * h + n);
           }
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) mma16<T>(acc[m][t], ac[t], B[m + dy][dx]);
-            if (dx == 2 && m == wave) refill();
+            for (int n = 0; n < 2; ++n) mma16<T>(acc[m][n], ac[n], B[m + dy][dx]);
+            if (dx == 2 && m == 1) refill();
           }
 #pragma unroll
-          for (int t = 0; t < 4; ++t) ac[t] = nx[t];
+          for (int n = 0; n < 2; ++n) ac[n] = nx[n];
         }
         next_buf();
       }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) an[t] = ac[t];
+    for (int n = 0; n < 2; ++n) an[n] = ac[n];
     finish_block(acc, a.E1 + blk * 64);
   }
-  vm_wait<0>();   // the dummy stages have landed (nobody reads them) before this wave's LDS can be handed on
+  vm_wait<0>();   // the dummy stages have landed (nobody reads them) before this workgroup's LDS is handed on
 
   // ---------------------------------------------------------------- next squeeze: bias + ReLU -> sq_out
   if constexpr (NSQ > 0) {
@@ -406,9 +408,12 @@ __global__ __launch_bounds__(256, 1) void fire_chain(ChainArgs a) {
       if (col_ok && oy < a.H) {
         T* dst = so + ((size_t)(n_img * a.H + oy) * a.W + ox) * a.S2 + g * 4 * NSQ;
 #pragma unroll
-        for (int t = 0; t < NSQ; ++t) {
-          const f32x4 bias = *reinterpret_cast<const f32x4*>(bs + g * 4 * NSQ + t * 4);
-          store4<T>(dst + t * 4, relu4(accs[t][m] + bias));
+        for (int i = 0; i < TH; ++i) {
+          const int t = h * TH + i;
+          if (t < NSQ) {
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(bs + g * 4 * NSQ + t * 4);
+            store4<T>(dst + t * 4, relu4(accs[i][m] + bias));
+          }
         }
       }
     }
@@ -471,17 +476,24 @@ __global__ void chain_pack_kernel(const float* __restrict__ w1, const float* __r
   }
 }
 
+constexpr size_t chain_lds_bytes(int nch, int nsq, int ring, int nbias) {
+  return (size_t)ring * STAGE_B + (size_t)NIMG * nch * CCHUNK + (nsq > 0 ? 32768 : 0) + (size_t)nbias * 4;
+}
+// deepest ring the 160 KiB allow (the squeeze tile of 3 chunks + the exchange area leave room for 4 stages only)
+constexpr int chain_ring(int nch, int nsq) { return chain_lds_bytes(nch, nsq, 6, 768 + 96) <= 160 * 1024 ? 6 : 4; }
+
 template <int NCH, int NSQ, bool WY>
 int launch_chain(const ChainArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)RING * STAGE_B + (size_t)NIMG * NCH * CCHUNK + (size_t)(a.E1 + a.E3 + a.S2) * 4;
+  constexpr int RG = chain_ring(NCH, NSQ);
+  const size_t lds = chain_lds_bytes(NCH, NSQ, RG, a.E1 + a.E3 + a.S2);
   static bool attr_done = false;
   if (!attr_done) {
-    SQDET_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_chain<NCH, NSQ, WY>),
+    SQDET_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_chain<NCH, NSQ, WY, RG>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
   const int wgs = ((a.N + 1) / 2) * a.tiles_x * a.tiles_y;
-  hipLaunchKernelGGL((fire_chain<NCH, NSQ, WY>), dim3((unsigned)((wgs + 7) / 8 * 8)), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((fire_chain<NCH, NSQ, WY, RG>), dim3((unsigned)((wgs + 7) / 8 * 8)), dim3(512), lds, st, a);
   SQDET_CHECK_HIP(hipGetLastError());
   return SQDET_OK;
 }
@@ -508,8 +520,8 @@ bool fire_chain_eligible(int s, int e1, int e3, int s2, int dtype) {
   if (!(s2 == 0 || s2 == 48 || s2 == 64 || s2 == 96)) return false;
   const ChainGeom g = chain_geom(s, e1, e3, s2);
   if (g.nch < 2 || g.nch > 3) return false;
-  const size_t lds = (size_t)RING * STAGE_B + (size_t)NIMG * g.nch * CCHUNK + (size_t)(e1 + e3 + s2) * 4;
-  return lds <= 160 * 1024;
+  if (e1 + e3 + s2 > 768 + 96) return false;   // (the ring depth is chosen for at most this many biases)
+  return chain_lds_bytes(g.nch, g.nsq, chain_ring(g.nch, g.nsq), e1 + e3 + s2) <= 160 * 1024;
 }
 
 }  // namespace sqdet
@@ -518,7 +530,7 @@ using namespace sqdet;
 
 extern "C" size_t sqdet_fire_chain_stream_bytes(int s1x1, int e1x1, int e3x3, int next_s1x1, int dtype) {
   if (!fire_chain_eligible(s1x1, e1x1, e3x3, next_s1x1, dtype)) return 0;
-  return (size_t)(chain_geom(s1x1, e1x1, e3x3, next_s1x1).nstages + 3) * STAGE_B;   // + the dummy stages
+  return (size_t)(chain_geom(s1x1, e1x1, e3x3, next_s1x1).nstages + 5) * STAGE_B;   // + the dummy stages (up to LOOK + 1 = 5)
 }
 
 extern "C" int sqdet_fire_chain_pack(const float* w_e1_hwio, const float* w_e3_hwio, const float* w_next_s_hwio,
@@ -555,7 +567,6 @@ extern "C" int sqdet_fire_chain_fwd(const void* sq_in, const void* stream_buf, c
   a.in_bytes = (unsigned)(px * s1x1 * 2);
   a.out_bytes = (unsigned)(px * next_s1x1 * 2);
   a.y_bytes = (unsigned)(px * (e1x1 + e3x3) * 2);
-  a.dbg = tune(TUNE_DBG);
   hipStream_t st = as_stream(stream);
   if (g.nch == 2) return y ? dispatch_chain_nsq<2, true>(a, g.nsq, st) : dispatch_chain_nsq<2, false>(a, g.nsq, st);
   return y ? dispatch_chain_nsq<3, true>(a, g.nsq, st) : dispatch_chain_nsq<3, false>(a, g.nsq, st);
