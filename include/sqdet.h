@@ -43,9 +43,8 @@ const char* sqdet_version(void);
 const char* sqdet_last_error(void);
 /* Tuning knobs (process-wide).  "conv_algo": 0 = auto (specialised kernels when eligible,
  * default), 1 = generic implicit-GEMM kernels only (also env SQDET_CONV_ALGO=generic).
- * "fire_overlap": 1 (default 0) = sqdet_net_forward runs the trailing small-map launches as two half-batches on two
- * streams skewed by one layer (half 1 of layer k beside half 0 of layer k+1); measured 2 % SLOWER on MI355X
- * (0.877 vs 0.857 ms per 32-image forward), like the earlier expand1x1 || expand3x3 variant of this knob. */
+ * "fire_fuse": 0 = plan heuristic (default), 1 = one launch per fire module wherever the kernels cover it, 2 = never
+ * fuse, 3 = no streaming kernel, 4 = fire modules and the pools behind them stay apart, 5 = no fire-module chains. */
 int sqdet_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------ conv --

@@ -58,6 +58,7 @@ def _newer(target, deps):
 
 
 def build(force=False, verbose=True):
+    """SQDET_EXTRA_DEFINES="-DSQDET_CHAIN_DBG ..." adds experiment-only defines (tools/chainbench.py --dbg)."""
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(ROOT, "include", "sqdet.h"))
@@ -70,7 +71,7 @@ def build(force=False, verbose=True):
         o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _newer(o, [s] + headers):
-            cmd = [hipcc] + COMMON + extra + ["-x", "hip", "-c", s, "-o", o]
+            cmd = [hipcc] + COMMON + extra + os.environ.get("SQDET_EXTRA_DEFINES", "").split() + ["-x", "hip", "-c", s, "-o", o]
             jobs.append(cmd)
 
     def run(cmd):

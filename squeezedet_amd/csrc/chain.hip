@@ -99,7 +99,9 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 // LDS slot each (behind the barrier the chain stage has anyway) and each accumulates HALF of the squeeze's cout
 // tiles over both chunks, in the canonical order.  While one wave of a SIMD waits -- for a barrier, an LDS
 // fragment, the ~60 cycles an LDS-DMA issue takes -- the other one keeps the matrix pipe busy.
-template <int NCH, int NSQ, bool WY, int RING>
+// DBG (experiments only, wrong results): 1 no vmcnt waits, 2 + no weight stream, 3 + no barriers, 4 + B fragments loaded once,
+// 5 + A fragments loaded once, 6 + no block epilogue / chain.
+template <int NCH, int NSQ, bool WY, int RING, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
   using T = f16;
   constexpr int LOOK = RING - 2;            // stages issued ahead of the one being consumed
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
   const unsigned m0_lo = ring_addr + (unsigned)wave * 1024;
   unsigned m0n = m0_lo;                                                  // LDS address its pieces go to
   auto refill = [&]() {
+    if constexpr (DBG >= 2) return;
     glds16(voff1, sp, m0n);
     if (h == 0) glds16(voff2, sp, m0n + 8192);
     sp += STAGE_B;
@@ -201,10 +204,12 @@ __global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
   auto sync = [&](bool lds_writes) {
     bool st = false;
     if constexpr (WY) { st = (ks - ep_ks) < LOOK; ++ks; }
-    if (h == 0) { if (st) vm_wait<2 * (LOOK - 1) + 4>(); else vm_wait<2 * (LOOK - 1)>(); }
-    else { if (st) vm_wait<(LOOK - 1) + 4>(); else vm_wait<(LOOK - 1)>(); }
+    if constexpr (DBG < 1) {
+      if (h == 0) { if (st) vm_wait<2 * (LOOK - 1) + 4>(); else vm_wait<2 * (LOOK - 1)>(); }
+      else { if (st) vm_wait<(LOOK - 1) + 4>(); else vm_wait<(LOOK - 1)>(); }
+    }
     if (lds_writes) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr (DBG < 3) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
   auto next_buf = [&]() {
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
           for (int n = 0; n < 2; ++n) mma16<T>(acc[m][n], ac[n], b1f[c][m]);
-          if (c + 1 == NCH && m == 1) refill();
+          if (c + 1 == NCH && m == 2 * h) refill();
         }
 #pragma unroll
         for (int n = 0; n < 2; ++n) ac[n] = nx[n];
@@ -355,7 +360,8 @@ __global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
     for (int c = 0; c < NCH; ++c) {
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
-        if (dy == 0) {
+        if (DBG >= 4 && blk > 0) {
+        } else if (dy == 0) {
 #pragma unroll
           for (int rr = 2; rr < 5; ++rr)
 #pragma unroll
@@ -372,7 +378,10 @@ __global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
           i32x4 nx[2];
-          if (dx < 2) {
+          if (DBG >= 5 && blk > 0) {
+            nx[0] = ac[1]; nx[1] = ac[0];
+            if (dx == 2) sync(false);
+          } else if (dx < 2) {
 #pragma unroll
             for (int n = 0; n < 2; ++n) nx[n] = lda(cbo, (dx + 1) * 4 + 2 * h + n);
           } else {
@@ -384,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
           for (int m = 0; m < 4; ++m) {
 #pragma unroll
             for (int n = 0; n < 2; ++n) mma16<T>(acc[m][n], ac[n], B[m + dy][dx]);
-            if (dx == 2 && m == 1) refill();
+            if (dx == 2 && m == 2 * h) refill();
           }
 #pragma unroll
           for (int n = 0; n < 2; ++n) ac[n] = nx[n];
@@ -394,7 +403,15 @@ __global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
     }
 #pragma unroll
     for (int n = 0; n < 2; ++n) an[n] = ac[n];
-    finish_block(acc, a.E1 + blk * 64);
+    if constexpr (DBG >= 6) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) accs[0][m] += acc[m][n];   // (keeps the MFMAs alive)
+      next_buf();
+    } else {
+      finish_block(acc, a.E1 + blk * 64);
+    }
   }
   vm_wait<0>();   // the dummy stages have landed (nobody reads them) before this workgroup's LDS is handed on
 
@@ -493,7 +510,32 @@ int launch_chain(const ChainArgs& a, hipStream_t st) {
     attr_done = true;
   }
   const int wgs = ((a.N + 1) / 2) * a.tiles_x * a.tiles_y;
-  hipLaunchKernelGGL((fire_chain<NCH, NSQ, WY, RG>), dim3((unsigned)((wgs + 7) / 8 * 8)), dim3(512), lds, st, a);
+  const dim3 grid((unsigned)((wgs + 7) / 8 * 8));
+#ifdef SQDET_CHAIN_DBG   // experiment builds only (tools/chainbench.py --dbg): cost ladder of the fire10 -> fire11 shape
+  if constexpr (NCH == 3 && NSQ == 6 && !WY) {
+    const int d = tune(TUNE_DBG);
+    static bool dbg_attr = false;
+    if (!dbg_attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_chain<NCH, NSQ, WY, RG, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_chain<NCH, NSQ, WY, RG, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_chain<NCH, NSQ, WY, RG, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_chain<NCH, NSQ, WY, RG, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_chain<NCH, NSQ, WY, RG, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_chain<NCH, NSQ, WY, RG, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      dbg_attr = true;
+    }
+    switch (d) {
+      case 1: hipLaunchKernelGGL((fire_chain<NCH, NSQ, WY, RG, 1>), grid, dim3(512), lds, st, a); return SQDET_OK;
+      case 2: hipLaunchKernelGGL((fire_chain<NCH, NSQ, WY, RG, 2>), grid, dim3(512), lds, st, a); return SQDET_OK;
+      case 3: hipLaunchKernelGGL((fire_chain<NCH, NSQ, WY, RG, 3>), grid, dim3(512), lds, st, a); return SQDET_OK;
+      case 4: hipLaunchKernelGGL((fire_chain<NCH, NSQ, WY, RG, 4>), grid, dim3(512), lds, st, a); return SQDET_OK;
+      case 5: hipLaunchKernelGGL((fire_chain<NCH, NSQ, WY, RG, 5>), grid, dim3(512), lds, st, a); return SQDET_OK;
+      case 6: hipLaunchKernelGGL((fire_chain<NCH, NSQ, WY, RG, 6>), grid, dim3(512), lds, st, a); return SQDET_OK;
+      default: break;
+    }
+  }
+#endif
+  hipLaunchKernelGGL((fire_chain<NCH, NSQ, WY, RG>), grid, dim3(512), lds, st, a);
   SQDET_CHECK_HIP(hipGetLastError());
   return SQDET_OK;
 }

@@ -346,8 +346,6 @@ int conv_algo() {
   return g_conv_algo;
 }
 void set_conv_algo(int v) { g_conv_algo = v; }
-static int g_fire_overlap = 0;  // two-stream schedules of the plan: measured slower on MI355X both times (see sqdet.h)
-int fire_overlap() { return g_fire_overlap; }
 
 // Experiment knobs (0 = built-in heuristic): see tune() call sites.
 static const char* const kTuneNames[] = {"c1_waves", "c1_mt", "c1_min_tiles", "fire_fuse", "stem_algo", "dbg"};
@@ -364,10 +362,6 @@ extern "C" int sqdet_set_option(const char* name, int value) {
   if (!strcmp(name, "conv_algo")) {
     SQDET_REQUIRE(value == 0 || value == 1, "set_option: conv_algo must be 0 (auto) or 1 (generic kernels only)");
     set_conv_algo(value);
-    return SQDET_OK;
-  }
-  if (!strcmp(name, "fire_overlap")) {
-    g_fire_overlap = value ? 1 : 0;
     return SQDET_OK;
   }
   for (int i = 0; i < kNumTune; ++i) {

@@ -31,8 +31,8 @@ bool fire_stream_eligible(int cin, int s, int e1, int e3, int dtype);
 int fire_stream_launch_ex(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
                           const float* b3, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
                           int pool, hipStream_t st, bool* handled);
+bool fire_chain_eligible(int s, int e1, int e3, int s2, int dtype);
 int conv_algo();
-int fire_overlap();
 int tune(int which);
 }  // namespace sqdet
 
@@ -41,8 +41,9 @@ using namespace sqdet;
 namespace {
 
 enum { BUF_INPUT = -1, BUF_PREDS = -2, BUF_A = 0, BUF_B = 1, BUF_S = 2, BUF_T = 3, NUM_BUFS = 4 };
-// L_STEM: conv(k, s2, Cin 3)+relu+maxpool(3, s2) in one launch; L_FIRE: squeeze + both expands in one launch
-enum { L_CONV = 0, L_POOL = 1, L_STEM = 2, L_FIRE = 3 };
+// L_STEM: conv(k, s2, Cin 3)+relu+maxpool(3, s2) in one launch; L_FIRE: squeeze + both expands in one launch;
+// L_CHAIN: both expands of a fire module + the squeeze of the NEXT module in one launch (sqdet_fire_chain_fwd)
+enum { L_CONV = 0, L_POOL = 1, L_STEM = 2, L_FIRE = 3, L_CHAIN = 4 };
 
 struct Param {
   std::string name;
@@ -78,6 +79,10 @@ struct Layer {
   int fs, fe1, fe3;
   int kp_s, bp_s, kp_1, bp_1, kp_3, bp_3;
   int fire_pool = 0;   // L_FIRE: the 3x3/s2 SAME max-pool that follows is taken inside the kernel (ho, wo = pooled dims)
+  // L_CHAIN: in_buf holds the module's squeeze tensor (fs channels); fs2 > 0: the next module's squeeze tensor goes to
+  // out_buf, else the concat tensor does; kp_s2 / bp_s2 = the next module's squeeze parameters; the packed stream
+  int fs2 = 0, kp_s2 = -1, bp_s2 = -1;
+  size_t chain_off = 0;
   double flops, bytes;
 };
 
@@ -104,10 +109,6 @@ struct sqdet_net {
   int probe_layer = -1;
   int probe_count = 0;
   std::vector<hipEvent_t> probe_events;  // 2 per record
-  // expand1x1 || expand3x3 overlap: the two expand convs of a fire module read the same squeeze
-  // tensor and write disjoint channel ranges, so expand1x1 runs on a side stream
-  hipStream_t side = nullptr;
-  std::vector<hipEvent_t> fork_events, join_events;
 };
 
 namespace {
@@ -276,6 +277,15 @@ void* buf_ptr(const sqdet_net* net, int buf, const void* input, void* preds) {
 // sub-batch is a pointer offset).
 int run_layer_part(sqdet_net* net, const Layer& L, const void* input, void* preds, int n0, int nb, hipStream_t st) {
   const size_t esz = dtype_size(net->dtype);
+  if (L.type == L_CHAIN) {
+    const size_t px0 = (size_t)n0 * L.h * L.w;
+    const char* sq_in = reinterpret_cast<const char*>(buf_ptr(net, L.in_buf, input, preds)) + px0 * L.fs * esz;
+    char* out = reinterpret_cast<char*>(buf_ptr(net, L.out_buf, input, preds)) + px0 * (L.fs2 > 0 ? L.fs2 : L.fe1 + L.fe3) * esz;
+    auto pb = [&](int i) { return i >= 0 ? reinterpret_cast<const float*>(net->param_mem + net->params[i].offset) : nullptr; };
+    return sqdet_fire_chain_fwd(sq_in, net->param_mem + L.chain_off, pb(L.bp_1), pb(L.bp_3), pb(L.bp_s2),
+                                L.fs2 > 0 ? nullptr : out, L.fs2 > 0 ? out : nullptr, nb, L.h, L.w, L.fs, L.fe1, L.fe3, L.fs2,
+                                net->dtype, reinterpret_cast<sqdet_stream_t>(st));
+  }
   const int in_c = L.type == L_STEM ? 3 : L.cin;
   const void* x = reinterpret_cast<const char*>(buf_ptr(net, L.in_buf, input, preds)) + (size_t)n0 * L.h * L.w * in_c * esz;
   void* y = reinterpret_cast<char*>(buf_ptr(net, L.out_buf, input, preds)) +
@@ -413,6 +423,68 @@ void fuse_fire_pools(sqdet_net* net, size_t esz) {
   }
 }
 
+// Runs of fire modules on ONE feature map (SqueezeDet's fire6 .. fire11, nets/squeezeDet.py:58-69): the only reader of
+// a module's concat tensor is the next module's squeeze1x1, so the run becomes
+//   squeeze1x1 of the first module  ->  [expand of module i + squeeze of module i+1] ...  ->  expand of the last module
+// and only 48-96-channel squeeze tensors travel between the launches (sqdet_fire_chain_fwd; float16).  "fire_fuse" = 5
+// keeps the one-launch-per-module form.
+void fuse_chains(sqdet_net* net, size_t esz) {
+  if (conv_algo() != 0 || tune(3) == 2 || tune(3) == 5) return;
+  const std::vector<Layer> in = net->layers;
+  std::vector<Layer> out;
+  for (size_t i = 0; i < in.size();) {
+    size_t j = i;
+    auto chainable = [&](size_t k) {
+      return k < in.size() && in[k].type == L_FIRE && !in[k].fire_pool && in[k].h == in[i].h && in[k].w == in[i].w &&
+             (long)net->batch * in[k].h * in[k].w <= 100000 && (k == i || in[k].in_buf == in[k - 1].out_buf);
+    };
+    while (chainable(j)) ++j;
+    // every member must be covered with its successor's squeeze (the last one with none)
+    bool ok = j - i >= 2;
+    for (size_t k = i; ok && k < j; ++k)
+      ok = fire_chain_eligible(in[k].fs, in[k].fe1, in[k].fe3, k + 1 < j ? in[k + 1].fs : 0, net->dtype);
+    if (!ok) { out.push_back(in[i]); ++i; continue; }
+    const double npix = (double)net->batch * in[i].h * in[i].w;
+    Layer sq = in[i];   // the first module's squeeze as a plain conv
+    sq.type = L_CONV;
+    sq.name = in[i].name + "/squeeze1x1";
+    sq.out_buf = BUF_S;
+    sq.cout = in[i].fs; sq.k = 1; sq.stride = 1; sq.pad_mode = SQDET_PAD_SAME; sq.relu = 1;
+    sq.ho = in[i].h; sq.wo = in[i].w;
+    sq.y_cstride = in[i].fs; sq.y_coffset = 0;
+    sq.kparam = in[i].kp_s; sq.bparam = in[i].bp_s;
+    sq.flops = 2.0 * in[i].cin * in[i].fs * npix;
+    sq.bytes = (npix * in[i].cin + npix * in[i].fs + (double)in[i].cin * in[i].fs) * (double)esz + 4.0 * in[i].fs;
+    out.push_back(sq);
+    int sbuf = BUF_S;
+    for (size_t k = i; k < j; ++k) {
+      const Layer& f = in[k];
+      const bool last = k + 1 == j;
+      Layer c = f;
+      c.type = L_CHAIN;
+      c.in_buf = sbuf;
+      c.fs2 = last ? 0 : in[k + 1].fs;
+      c.kp_s2 = last ? -1 : in[k + 1].kp_s;
+      c.bp_s2 = last ? -1 : in[k + 1].bp_s;
+      c.out_buf = last ? f.out_buf : (sbuf == BUF_S ? BUF_T : BUF_S);
+      c.name = last ? f.name + "/expand" : f.name + "/expand+" + in[k + 1].name + "/squeeze1x1";
+      c.flops = (2.0 * f.fs * f.fe1 + 18.0 * f.fs * f.fe3 + 2.0 * (f.fe1 + f.fe3) * c.fs2) * npix;
+      // algorithmic bytes: squeeze tensor in + (next squeeze tensor | concat tensor) out + the weights
+      c.bytes = (npix * f.fs + npix * (last ? f.fe1 + f.fe3 : c.fs2) + (double)f.fs * f.fe1 + 9.0 * f.fs * f.fe3 +
+                 (double)(f.fe1 + f.fe3) * c.fs2) * (double)esz + 4.0 * (f.fe1 + f.fe3 + c.fs2);
+      c.chain_off = net->param_bytes;
+      net->param_bytes = align_up(net->param_bytes + sqdet_fire_chain_stream_bytes(f.fs, f.fe1, f.fe3, c.fs2, net->dtype), 256);
+      const size_t selems = (size_t)net->batch * f.h * f.w * (size_t)(f.fs > c.fs2 ? f.fs : c.fs2);
+      if (selems > net->buf_elems[BUF_S]) net->buf_elems[BUF_S] = selems;
+      if (selems > net->buf_elems[BUF_T]) net->buf_elems[BUF_T] = selems;
+      out.push_back(c);
+      sbuf = c.out_buf;
+    }
+    i = j;
+  }
+  net->layers.swap(out);
+}
+
 // conv1 + pool1 -> one L_STEM launch when the fused kernel applies (decided at plan creation).
 void fuse_stem(sqdet_net* net, size_t esz) {
   if (conv_algo() != 0 || net->layers.size() < 2) return;
@@ -487,6 +559,7 @@ extern "C" int sqdet_net_create(sqdet_net_t** out, int arch, int dtype, int batc
   fuse_stem(net, b.esz);
   fuse_fires(net, b.esz);
   fuse_fire_pools(net, b.esz);
+  fuse_chains(net, b.esz);
   net->fold_scratch_off = net->param_bytes;
   net->param_bytes = align_up(net->param_bytes + net->fold_scratch_bytes, 256);
   size_t off = 0;
@@ -503,9 +576,6 @@ extern "C" void sqdet_net_destroy(sqdet_net_t* net) {
   if (!net) return;
   for (hipEvent_t e : net->events) (void)hipEventDestroy(e);
   for (hipEvent_t e : net->probe_events) (void)hipEventDestroy(e);
-  for (hipEvent_t e : net->fork_events) (void)hipEventDestroy(e);
-  for (hipEvent_t e : net->join_events) (void)hipEventDestroy(e);
-  if (net->side) (void)hipStreamDestroy(net->side);
   delete net;
 }
 
@@ -550,9 +620,19 @@ extern "C" int sqdet_net_set_param(sqdet_net_t* net, const char* name, const flo
       f.dirty = true;
       return SQDET_OK;
     }
-    if (p.ndim == 4)
+    if (p.ndim == 4) {
+      // kernels that also travel in a chain stream (expand1x1 / expand3x3 of a chained module, squeeze1x1 of its successor)
+      const int pi = (int)(&p - net->params.data());
+      for (const Layer& L : net->layers) {
+        if (L.type != L_CHAIN || (pi != L.kp_1 && pi != L.kp_3 && pi != L.kp_s2)) continue;
+        const int rc = sqdet_fire_chain_pack(pi == L.kp_1 ? value_f32 : nullptr, pi == L.kp_3 ? value_f32 : nullptr,
+                                             pi == L.kp_s2 ? value_f32 : nullptr, net->param_mem + L.chain_off, L.fs, L.fe1,
+                                             L.fe3, L.fs2, net->dtype, stream);
+        if (rc != SQDET_OK) return rc;
+      }
       return sqdet_conv_pack_weights(value_f32, net->param_mem + p.offset, p.shape[0], p.shape[2], p.shape[3],
                                      net->dtype, stream);
+    }
     SQDET_CHECK_HIP(hipMemcpyAsync(net->param_mem + p.offset, value_f32, (size_t)p.shape[0] * 4,
                                    hipMemcpyDeviceToDevice, as_stream(stream)));
     return SQDET_OK;
@@ -583,17 +663,6 @@ extern "C" int sqdet_net_forward(sqdet_net_t* net, const void* image_input, void
   const int frc = refresh_folds(net, st);
   if (frc != SQDET_OK) return frc;
   const int nl = (int)net->layers.size();
-  // "late_split" (sqdet_set_option): the trailing run of small-map launches (one wave of workgroups each: their
-  // time is one workgroup's critical path, with the matrix pipes idle during its memory phase and vice versa) is
-  // run as two half-batches on two streams SKEWED by one layer -- half 1 of layer k next to half 0 of layer k+1 --
-  // so that one half's memory phase sits beside the other half's MFMA phase.
-  int split = nl;
-  if (fire_overlap() != 0 && net->batch % 2 == 0) {
-    while (split > 0 && (long)net->batch * net->layers[split - 1].h * net->layers[split - 1].w <= 100000 &&
-           net->layers[split - 1].type != L_STEM)
-      --split;
-    if (nl - split < 2) split = nl;
-  }
   auto one = [&](int i, int n0, int nb, hipStream_t ls) -> int {
     const bool probe = n0 == 0 && i == net->probe_layer && 2 * (net->probe_count + 1) <= (int)net->probe_events.size();
     if (probe) SQDET_CHECK_HIP(hipEventRecord(net->probe_events[2 * net->probe_count], ls));
@@ -605,35 +674,9 @@ extern "C" int sqdet_net_forward(sqdet_net_t* net, const void* image_input, void
     }
     return SQDET_OK;
   };
-  for (int i = 0; i < split; ++i) {
+  for (int i = 0; i < nl; ++i) {
     const int rc = one(i, 0, net->batch, st);
     if (rc != SQDET_OK) return rc;
-  }
-  if (split < nl) {
-    if (!net->side) SQDET_CHECK_HIP(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking));
-    if (net->fork_events.empty()) {
-      hipEvent_t e1, e2;
-      SQDET_CHECK_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-      SQDET_CHECK_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-      net->fork_events.push_back(e1);
-      net->join_events.push_back(e2);
-    }
-    const int hb = net->batch / 2;
-    // half 0 of the first late layer goes first; the side stream may start once it is done
-    int rc = one(split, 0, hb, st);
-    if (rc != SQDET_OK) return rc;
-    SQDET_CHECK_HIP(hipEventRecord(net->fork_events[0], st));
-    SQDET_CHECK_HIP(hipStreamWaitEvent(net->side, net->fork_events[0], 0));
-    for (int i = split; i < nl; ++i) {
-      rc = one(i, hb, hb, net->side);                       // half 1 of layer i ...
-      if (rc != SQDET_OK) return rc;
-      if (i + 1 < nl) {
-        rc = one(i + 1, 0, hb, st);                          // ... beside half 0 of layer i + 1
-        if (rc != SQDET_OK) return rc;
-      }
-    }
-    SQDET_CHECK_HIP(hipEventRecord(net->join_events[0], net->side));
-    SQDET_CHECK_HIP(hipStreamWaitEvent(st, net->join_events[0], 0));
   }
   return SQDET_OK;
 }

@@ -53,18 +53,34 @@ def test_net_plan_tables_without_gpu(lib):
     """The plan is host-side: parameter table, workspace sizes and the layer table can be
     inspected without a device."""
     h = C.c_void_p()
-    # default plan: conv1+pool1 fused; one launch per fire module -- the persistent streaming kernel on the large
-    # few-channel maps (fire2-5), the tile kernel on the small late maps (fire6-11)
+    # default plan: conv1+pool1 fused; one launch per fire module on the large few-channel maps (fire2-5, the persistent
+    # streaming kernel); the late 24x78 modules as a CHAIN: fire6's squeeze, then expand_i + squeeze_{i+1} per launch
+    def layer_names():
+        nm = C.create_string_buffer(128)
+        out = []
+        for i in range(lib.sqdet_net_num_layers(h)):
+            assert lib.sqdet_net_layer_info(h, i, nm, 128, None, None) == 0
+            out.append(nm.value.decode())
+        return out
     assert lib.sqdet_net_create(C.byref(h), _lib.ARCH_SQUEEZEDET, _lib.F16, 32, 375, 1242, 3, 9) == 0
-    nm = C.create_string_buffer(128)
-    names_default = []
-    for i in range(lib.sqdet_net_num_layers(h)):
-        assert lib.sqdet_net_layer_info(h, i, nm, 128, None, None) == 0
-        names_default.append(nm.value.decode())
-    assert names_default[0] == "conv1+pool1" and "fire2" in names_default and "fire11" in names_default
+    names_default = layer_names()
+    assert names_default[0] == "conv1+pool1" and "fire2" in names_default and "fire4" in names_default
     # ... and the two max-pools behind fire3 / fire5 are taken inside those launches
     assert "fire3+pool3" in names_default and "fire5+pool5" in names_default and "pool3" not in names_default
-    assert len(names_default) == 34 - 2 * 10 - 2
+    assert names_default[5:] == ["fire6/squeeze1x1", "fire6/expand+fire7/squeeze1x1", "fire7/expand+fire8/squeeze1x1",
+                                 "fire8/expand+fire9/squeeze1x1", "fire9/expand+fire10/squeeze1x1",
+                                 "fire10/expand+fire11/squeeze1x1", "fire11/expand", "conv12"]
+    lib.sqdet_net_destroy(h)
+    # without the chains ("fire_fuse" = 5): one launch per fire module everywhere (the tile kernel on the late maps);
+    # float32 plans never chain (the chain kernel is float16)
+    assert lib.sqdet_set_option(b"fire_fuse", 5) == 0
+    assert lib.sqdet_net_create(C.byref(h), _lib.ARCH_SQUEEZEDET, _lib.F16, 32, 375, 1242, 3, 9) == 0
+    assert lib.sqdet_set_option(b"fire_fuse", 0) == 0
+    names_nochain = layer_names()
+    assert "fire6" in names_nochain and "fire11" in names_nochain and len(names_nochain) == 34 - 2 * 10 - 2
+    lib.sqdet_net_destroy(h)
+    assert lib.sqdet_net_create(C.byref(h), _lib.ARCH_SQUEEZEDET, _lib.F32, 2, 384, 1248, 3, 9) == 0
+    assert not any("+fire" in n or n.endswith("/expand") for n in layer_names())
     lib.sqdet_net_destroy(h)
     # the rest of this test inspects the per-conv plan (fire fusion off)
     assert lib.sqdet_set_option(b"fire_fuse", 2) == 0
