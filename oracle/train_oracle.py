@@ -2,7 +2,13 @@
 (nn_skeleton.py:285-327), the train graph (nn_skeleton.py:329-361) and the dense-label builder
 (dataset/imdb.py:195-239 + train.py:205-222), restated with PyTorch-CPU float32 autograd.
 
-Parity status: **unpinned** -- all of this arithmetic lives in tensorflow-gpu==1.0.0 (softmax,
+Parity status: the label assignment (assign_anchors) is **pinned**: the reference's own imdb.read_batch is imported
+unchanged (oracle/ref_imdb_half.py, cv2 stubbed -- the label half never looks at pixels) and run on seeded annotations;
+tests/golden/labels.npz holds its anchor indices / deltas and tests/test_oracle_golden.py checks assign_anchors against
+them bit for bit.  (Decision points with TIES -- equal IoU between two free anchors, structural for boxes lying inside
+or containing several anchors of one shape -- are resolved by np.argsort's unspecified order in the reference, i.e. by
+the NumPy build; the golden cases are drawn tie-free, and ours resolve ties towards the higher anchor index.)
+The loss / optimizer half is **unpinned** -- that arithmetic lives in tensorflow-gpu==1.0.0 (softmax,
 sigmoid, log, MomentumOptimizer, clip_by_norm, exponential_decay), which cannot run here; the
 reference ships no training vectors.  Restated from the call sites + TF's documented semantics:
   * tf.nn.l2_loss(v) = sum(v**2)/2, so the weight-decay gradient is wd*v (kernels of trainable

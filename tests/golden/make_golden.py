@@ -14,6 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
+from oracle import ref_imdb_half as ref_imdb  # noqa: E402
 from oracle import ref_numpy_half as ref  # noqa: E402
 from tests.golden import cases  # noqa: E402
 
@@ -76,6 +77,50 @@ def main():
         out[name + "_cls"] = np.array(fc, np.int64)
         print(name, "->", len(fp), "detections; first probs", fp[:3])
     np.savez(os.path.join(HERE, "filter_prediction.npz"), **out)
+
+    # ---- label assignment: imdb.read_batch (dataset/imdb.py:120-260) on seeded annotations ----
+    out = {}
+    cfgs = {"squeezeDet": (ns.cfg_squeezeDet, "kitti_squeezeDet_config"), "squeezeDetPlus": (ns.cfg_squeezeDetPlus, "kitti_squeezeDetPlus_config"),
+            "res50": (ns.cfg_res50, "kitti_res50_config")}
+    for name in cases.LABEL_CASES:
+        cfg, rois, sizes = cases.make_label_case(name)
+        mc = getattr(cfgs[cfg][0], cfgs[cfg][1])()
+        labels, deltas, aidx, bboxes = ref_imdb.read_batch(mc, rois, sizes)
+        # every pick must be decided by a STRICT inequality: np.argsort's order among equal keys is unspecified
+        # (NumPy-version and CPU dependent), so a case with a tie at a decision point pins nothing
+        anchors = np.asarray(mc.ANCHOR_BOX)
+        for i in range(len(rois)):
+            taken = set()
+            for k, a in enumerate(aidx[i]):
+                ov = ns.util.batch_iou(anchors, bboxes[i][k])
+                free = np.ones(len(anchors), bool)
+                free[list(taken)] = False
+                if ov[a] > 0:
+                    rest = free.copy(); rest[a] = False
+                    assert ov[a] > ov[rest].max(), "%s image %d object %d: IoU tie at the pick" % (name, i, k)
+                else:
+                    assert ov[free].max() <= 0
+                    dist = np.sum(np.square(bboxes[i][k] - anchors), axis=1)
+                    rest = free.copy(); rest[a] = False
+                    assert dist[a] < dist[rest].min(), "%s image %d object %d: distance tie at the pick" % (name, i, k)
+                taken.add(int(a))
+        B, M = len(rois), cases.LABEL_MAX_OBJECTS
+        a = -np.ones((B, M), np.int64)
+        d = np.zeros((B, M, 4), np.float64)
+        bb = np.zeros((B, M, 4), np.float64)
+        lb = -np.ones((B, M), np.int64)
+        cnt = np.zeros(B, np.int32)
+        for i in range(B):
+            n = len(aidx[i])
+            cnt[i] = n
+            a[i, :n] = np.asarray(aidx[i], np.int64)
+            d[i, :n] = np.asarray(deltas[i], np.float64)
+            bb[i, :n] = np.asarray(bboxes[i], np.float64)
+            lb[i, :n] = np.asarray(labels[i], np.int64)
+            assert len(set(aidx[i])) == n
+        out[name + "_aidx"], out[name + "_delta"], out[name + "_bbox"], out[name + "_label"], out[name + "_count"] = a, d, bb, lb, cnt
+        print(name, "->", int(cnt.sum()), "objects; anchors of image 0:", a[0, :cnt[0]].tolist())
+    np.savez(os.path.join(HERE, "labels.npz"), **out)
 
 
 if __name__ == "__main__":

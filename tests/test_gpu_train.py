@@ -4,6 +4,8 @@ see that module's header), then one whole training step.
 
 Tolerances: gradients are sums of up to ~1e5 float32 products evaluated in a different order than
 the CPU's, so they are compared at 2e-4 relative to the tensor's max (north_star: 1e-3 rel)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -462,3 +464,31 @@ def test_squeezedet_plus_training_step_vs_oracle():
         scale = float(gref.abs().max())
         err = float((got - gref).abs().max())
         assert err <= 1e-3 * scale + 1e-7, "%s: grad err %g vs scale %g" % (name, err, scale)
+
+
+@pytest.mark.parametrize("name", __import__("tests.golden.cases", fromlist=["x"]).LABEL_CASES)
+def test_build_labels_vs_reference_golden(name):
+    """sqdet_build_labels against what the REFERENCE's own imdb.read_batch returned (dataset/imdb.py:120-260, run
+    unchanged by tests/golden/make_golden.py on seeded annotations; tests/golden/labels.npz): anchor indices
+    bit-exact -- boxes competing for one anchor, boxes that overlap nothing, three anchor sets -- and the float32
+    deltas / boxes equal to the float64 golden values rounded once (1e-6)."""
+    from tests.golden import cases
+    ops = _ops()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "labels.npz"))
+    cfg = name.split("_")[0]
+    mc = {"squeezeDet": O.kitti_squeezeDet_config, "squeezeDetPlus": O.kitti_squeezeDetPlus_config, "res50": O.kitti_res50_config}[cfg]()
+    aidx, delta, bbox, label, cnt = [g[name + k] for k in ("_aidx", "_delta", "_bbox", "_label", "_count")]
+    B, M = aidx.shape
+    assert M == cases.LABEL_MAX_OBJECTS
+    cls = np.where(label >= 0, label, 0).astype(np.int32)
+    mask, d_delta, d_box, lab, d_aidx = ops.build_labels(mc.ANCHOR_BOX, bbox.copy(), cls, cnt.astype(np.int32), mc.CLASSES, device=DEV)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_aidx.cpu().numpy().astype(np.int64), aidx), "anchor picks differ from the reference's"
+    dm, dd, db, dl = mask.cpu().numpy(), d_delta.cpu().numpy(), d_box.cpu().numpy(), lab.cpu().numpy()
+    assert dm.sum() == cnt.sum()
+    for b in range(B):
+        for k in range(int(cnt[b])):
+            a = int(aidx[b, k])
+            assert dm[b, a] == 1 and dl[b, a, int(label[b, k])] == 1 and dl[b, a].sum() == 1
+            np.testing.assert_allclose(dd[b, a], delta[b, k], rtol=1e-6, atol=1e-7)
+            assert np.array_equal(db[b, a], bbox[b, k].astype(np.float32))

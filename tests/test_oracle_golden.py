@@ -110,3 +110,48 @@ def test_oracle_vs_live_reference():
               "LOSS_COEF_CONF_NEG", "LOSS_COEF_CLASS", "EPSILON", "DECAY_STEPS"):
         assert mc[k] == mc_ref[k], k
     np.testing.assert_array_equal(mc.ANCHOR_BOX, mc_ref.ANCHOR_BOX)
+
+
+_LABEL_CFG = {"squeezeDet": O.kitti_squeezeDet_config, "squeezeDetPlus": O.kitti_squeezeDetPlus_config, "res50": O.kitti_res50_config}
+
+
+@pytest.mark.parametrize("name", cases.LABEL_CASES)
+def test_label_assignment_matches_reference(golden_dir, name):
+    """train_oracle.assign_anchors (the restatement the GPU label builder is checked against) reproduces, bit for bit,
+    what the reference's own imdb.read_batch (dataset/imdb.py:120-260, run unchanged by make_golden.py) produced:
+    anchor indices (incl. boxes competing for one anchor and boxes that overlap nothing) and the float64 deltas."""
+    from oracle import train_oracle as TO
+    g = np.load(os.path.join(golden_dir, "labels.npz"))
+    mc = _LABEL_CFG[name.split("_")[0]]()
+    aidx, delta, bbox, cnt = g[name + "_aidx"], g[name + "_delta"], g[name + "_bbox"], g[name + "_count"]
+    assert cnt.sum() >= 12
+    for b in range(len(cnt)):
+        n = int(cnt[b])
+        a, d = TO.assign_anchors(mc, bbox[b, :n])
+        assert a == aidx[b, :n].tolist(), "%s image %d" % (name, b)
+        assert np.array_equal(np.asarray(d, np.float64).reshape(n, 4), delta[b, :n]), "%s image %d deltas" % (name, b)
+        assert (aidx[b, n:] == -1).all()
+    if "contention" in name:      # identical boxes did get DIFFERENT anchors, in order of preference
+        n0 = int(cnt[0])
+        dup = [k for k in range(1, n0) if np.array_equal(bbox[0, k], bbox[0, 0])]
+        assert dup and len(set(aidx[0, :n0].tolist())) == n0
+    if "nooverlap" in name:       # the far boxes took the nearest free corner anchors
+        A = mc.ANCHORS
+        assert aidx[0, 0] == 0 and aidx[0, int(cnt[0]) - 1] >= A - 9
+
+
+@pytest.mark.skipif(not ref.available(), reason="reference tree not mounted")
+def test_label_golden_regenerates_from_live_reference(golden_dir):
+    """The committed labels.npz is what the reference's read_batch returns today (scaled boxes included)."""
+    from oracle import ref_imdb_half as ref_imdb
+    ns = ref.load()
+    g = np.load(os.path.join(golden_dir, "labels.npz"))
+    for name in cases.LABEL_CASES[:2]:
+        cfg, rois, sizes = cases.make_label_case(name)
+        mc = ns.cfg_squeezeDet.kitti_squeezeDet_config()
+        labels, deltas, aidx, bboxes = ref_imdb.read_batch(mc, rois, sizes)
+        for b in range(len(rois)):
+            n = len(aidx[b])
+            assert [int(v) for v in aidx[b]] == g[name + "_aidx"][b, :n].tolist()
+            assert np.array_equal(np.asarray(bboxes[b], np.float64), g[name + "_bbox"][b, :n])
+            assert [int(v) for v in labels[b]] == g[name + "_label"][b, :n].tolist()
