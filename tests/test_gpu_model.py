@@ -30,18 +30,24 @@ def _model(arch="squeezeDet", dtype=torch.float32, batch=1, size=None, seed=0):
     return m, mc, params, storage
 
 
+OBSERVED = {}   # what -> largest observed max-error / tensor-scale (printed by test_zz_report_observed_errors)
+
+
 def _check_layers(got, ref, dtype, what):
     got = got.float().cpu().numpy()
     ref = ref.numpy() if isinstance(ref, torch.Tensor) else ref
     assert got.shape == ref.shape, what
     scale = np.abs(ref).max()
     err = np.abs(got - ref).max()
+    key = ("fp32 " if dtype == torch.float32 else "fp16 ") + what.split("[")[0]
+    OBSERVED[key] = max(OBSERVED.get(key, 0.0), float(err / max(scale, 1e-30)))
     if dtype == torch.float32:
         assert err <= 1e-3 * scale + 1e-5, "%s: max err %g vs scale %g" % (what, err, scale)  # north_star 1e-3 rel
     else:
-        # fp16 storage: both sides round every activation to fp16; rounding decisions can flip
-        # by one fp16 ulp and propagate -> allow 1% of the tensor scale
-        assert err <= 1e-2 * scale + 1e-3, "%s: max err %g vs scale %g" % (what, err, scale)
+        # fp16 storage: both sides round every activation to fp16; rounding decisions can flip by one fp16 ulp and
+        # propagate.  Observed (test_zz_report_observed_errors, round 2): 5e-4 of the tensor scale after conv1, growing
+        # to 2.2e-3 at preds (conv12) -> 5e-3 of the scale allowed (2x the largest observed)
+        assert err <= 5e-3 * scale + 1e-3, "%s: max err %g vs scale %g" % (what, err, scale)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
@@ -182,3 +188,37 @@ def test_pipelined_step_equals_sequential():
         for i in range(4):
             for t in range(4):
                 assert torch.equal(got[t][i, :n[i]], want[t][i, :n[i]])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("size", [(384, 1248), (375, 1242)], ids=["384x1248", "375x1242"])
+def test_end_to_end_decision_margins(size, dtype, capsys):
+    """image -> picks on the device against image -> picks in the oracle for 16 seeded images.  Where
+    every decision of filter_prediction (top-64 boundary, rank inside the class, class arg-max, IoU vs NMS_THRESH) has
+    a margin above twice the measured float noise, the picks -- anchor indices, in output order -- must be IDENTICAL;
+    the margins are printed (pytest -s, or tools/decision_margins.py)."""
+    from tests import decision_margins as DM
+    rows, summary = DM.run(size, dtype, nimg=16, seed=40)
+    with capsys.disabled():
+        print("\n" + DM.format_report(rows, summary))
+    for r in rows:
+        if r["decidable"]:
+            assert r["same_picks"], "image %d: margins above the noise but the picks differ: %r" % (r["image"], r)
+    # The comparison must not be vacuous in float32: about half of the images are decidable (observed 9 of 16 at noise
+    # 1.8e-6, and all 16 pick identically).  In float16 the score noise (~1e-3: one-ulp activation flips propagate) is
+    # ABOVE the gap between the 64th and 65th of 16848 random-weight scores (~1e-4), so no image is decidable end to
+    # end -- stated, not hidden: the float16 path is pinned stage-wise instead (its own decoded arrays through the
+    # oracle's filter_prediction give identical picks: test_full_config_properties_batch32_fp16, smoke()).
+    if dtype == "fp32":
+        assert summary["decidable"] >= 6 and summary["all_same"] >= summary["decidable"], summary
+        assert summary["max_n_p"] < 2e-5, summary
+    else:
+        assert summary["max_n_p"] < 1e-2 and summary["mean_jaccard"] > 0.5, summary
+
+
+def test_zz_report_observed_errors(capsys):
+    """Prints the largest observed error / tensor scale of every _check_layers comparison of this module (runs last)."""
+    with capsys.disabled():
+        print("\nobserved max-error / tensor-scale vs the oracle:")
+        for k in sorted(OBSERVED):
+            print("  %-40s %.3e" % (k, OBSERVED[k]))

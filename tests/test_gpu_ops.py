@@ -492,3 +492,32 @@ def test_fire_chain_parity(case, want_y):
         np.testing.assert_allclose(so.float().cpu().numpy(), s_ref.numpy(), **tol)
     else:
         assert so is None
+
+
+@pytest.mark.parametrize("case", [("fire3+pool3", 128, 16, 64, 94, 311, 2), ("fire5+pool5", 256, 32, 128, 47, 156, 2)], ids=["fire3+pool3", "fire5+pool5"])
+def test_fire_pool_full_size_fp16_vs_oracle(case):
+    """fire3+pool3 / fire5+pool5 (nets/squeezeDet.py:49-57) as ONE launch at their real SqueezeDet shapes in float16,
+    DIRECTLY against the oracle (fire_layer -> pooling_layer in float16-storage mode) -- not only against the repo's own
+    unfused path: 2 float16 ulps + 2e-3 abs, the fused-fire tolerance (the S = 16 module pairs two taps per MFMA)."""
+    ops = _ops()
+    name, cin, s, e, H, W, N = case
+    tdt = torch.float16
+    rs = np.random.RandomState(zlib.crc32(("full" + name).encode()) % (2 ** 31))
+    fn = name.split("+")[0]
+    p = {}
+    for sub, (k, ci, co) in (("squeeze1x1", (1, cin, s)), ("expand1x1", (1, s, e)), ("expand3x3", (3, s, e))):
+        w = torch.from_numpy((rs.randn(k, k, ci, co) * (2.0 / (k * k * ci)) ** 0.5).astype(np.float32))
+        p["%s/%s/kernels" % (fn, sub)] = w.half().float()
+        p["%s/%s/biases" % (fn, sub)] = torch.from_numpy(rs.uniform(-0.3, 0.3, co).astype(np.float32))
+    x = torch.from_numpy(np.maximum(rs.randn(N, H, W, cin), 0).astype(np.float32)).half().float()
+    ref = O.pooling_layer(O.fire_layer(p, fn, x, storage="fp16"), 3, 2, "SAME").numpy()
+    pk = {n: ops.pack_conv_weights(p["%s/%s/kernels" % (fn, n)].to(DEV), tdt) for n in ("squeeze1x1", "expand1x1", "expand3x3")}
+    bs = {n: p["%s/%s/biases" % (fn, n)].to(DEV) for n in pk}
+    y = ops.fire_maxpool(x.to(DEV, tdt).contiguous(), pk["squeeze1x1"], bs["squeeze1x1"], pk["expand1x1"], bs["expand1x1"],
+                         pk["expand3x3"], bs["expand3x3"])
+    torch.cuda.synchronize()
+    got = y.float().cpu().numpy()
+    assert got.shape == ref.shape == (N, -(-H // 2), -(-W // 2), 2 * e)
+    np.testing.assert_allclose(got, ref, rtol=2 ** -8, atol=2e-3)
+    frac = float((got != ref).mean())
+    assert frac < 0.05, "more than 5 %% of the pooled float16 values differ from the oracle's (%g)" % frac
