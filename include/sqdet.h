@@ -242,6 +242,27 @@ int sqdet_loss_fwd_bwd(const float* preds, const float* anchors, const float* in
                        float exp_thresh, float epsilon, float coef_class, float coef_conf_pos, float coef_conf_neg,
                        float coef_bbox, float num_objects, sqdet_stream_t stream);
 
+/* Same, with num_objects read from the DEVICE (float32 scalar, e.g. sqdet_sum_f32 of input_mask -- nn_skeleton.py:180 --
+ * optionally SUM-all-reduced over the replicas first: the exact global-batch normalisation of SURVEY.md 8e option b):
+ * no device -> host round trip, so the whole step can be captured in a hipGraph. */
+int sqdet_loss_fwd_bwd_dev(const float* preds, const float* anchors, const float* input_mask, const float* box_delta_input,
+                           const float* box_input, const float* labels, float* dpreds, float* ious, float* losses3,
+                           float* workspace, int batch, int gh, int gw, int apg, int classes, float img_w, float img_h,
+                           float exp_thresh, float epsilon, float coef_class, float coef_conf_pos, float coef_conf_neg,
+                           float coef_bbox, const float* num_objects_dev, sqdet_stream_t stream);
+/* out[0] = sum(x[0..count)) in a fixed order (deterministic): tf.reduce_sum(self.input_mask), nn_skeleton.py:180. */
+int sqdet_sum_f32(const float* x, size_t count, float* out, sqdet_stream_t stream);
+/* y = max(a + b, 0): tf.nn.relu(shortcut + branch) (nets/resnet50_convDet.py:55) where the producing conv could not take
+ * the add in its epilogue.  count elements, a multiple of 16 bytes; y may alias a or b. */
+int sqdet_add_relu(const void* a, const void* b, void* y, size_t count, int dtype, sqdet_stream_t stream);
+/* y[p, y_coffset .. +c) = x[p, 0 .. c) for `pixels` rows: one input of tf.concat(values, 3) (nets/squeezeDet.py:106) whose
+ * producer could not write its channel range directly.  c, y_cstride, y_coffset multiples of 16 bytes. */
+int sqdet_copy_channels(const void* x, void* y, size_t pixels, int c, int y_cstride, int y_coffset, int dtype,
+                        sqdet_stream_t stream);
+/* mask[i] = floor(keep_prob + u_i), u_i ~ U[0,1) from a counter-based generator of (seed, i): the keep mask of
+ * tf.nn.dropout (nets/squeezeDet.py:74), to be applied with sqdet_scale_mask(x, mask, 1/keep_prob). */
+int sqdet_dropout_mask(void* mask, size_t count, float keep_prob, uint64_t seed, int dtype, sqdet_stream_t stream);
+
 /* Momentum + per-variable clip_by_norm over flat parameter / gradient / momentum buffers.
  * Variable v = elements [offsets[v], +counts[v]); decays[v] = weight decay added to its gradient
  * BEFORE clipping (0 for biases).  step: g = g*grad_scale (1/world_size after a SUM all-reduce) + decay*w; g *= max_norm/max(||g||,max_norm);

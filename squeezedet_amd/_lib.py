@@ -48,6 +48,11 @@ SIGNATURES = {
     "sqdet_maxpool_nhwc_bwd": (ci, [vp, vp, vp] + [ci] * 8 + [vp]),
     "sqdet_loss_workspace_bytes": (sz, []),
     "sqdet_loss_fwd_bwd": (ci, [vp] * 10 + [ci] * 5 + [cf] * 9 + [vp]),
+    "sqdet_loss_fwd_bwd_dev": (ci, [vp] * 10 + [ci] * 5 + [cf] * 8 + [vp, vp]),
+    "sqdet_sum_f32": (ci, [vp, sz, vp, vp]),
+    "sqdet_add_relu": (ci, [vp, vp, vp, sz, ci, vp]),
+    "sqdet_copy_channels": (ci, [vp, vp, sz, ci, ci, ci, ci, vp]),
+    "sqdet_dropout_mask": (ci, [vp, sz, cf, C.c_uint64, ci, vp]),
     "sqdet_optimizer_create": (ci, [C.POINTER(vp), C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(cf), ci]),
     "sqdet_optimizer_destroy": (None, [vp]),
     "sqdet_optimizer_workspace_bytes": (sz, [vp]),

@@ -247,10 +247,12 @@ struct LossArgs {
   int B, cells, K, C;
   float w1, h1, thr, slope, eps;
   float coef_class, coef_pos, coef_neg, coef_bbox;
-  float num_obj;           // sum(mask) over the whole batch (host computed from the label tensors)
+  float num_obj;           // sum(mask) over the whole batch (host computed from the label tensors) ...
+  const float* num_obj_dev;   // ... or, when not NULL, read from the device (sqdet_sum_f32 of the mask: no host round trip)
 };
 
 __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
+  const float nobj = a.num_obj_dev ? a.num_obj_dev[0] : a.num_obj;
   __shared__ float red[3][256];
   const int A = a.cells * a.K;
   const int ch = a.K * (a.C + 5);
@@ -275,13 +277,13 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
       const float pc = expf(lg[c] - mx) * inv;
       const float lab = a.labels[idx * a.C + c];
       l_class += (lab * (-logf(pc + a.eps)) + (1.0f - lab) * (-logf(1.0f - pc + a.eps))) * m * a.coef_class;
-      const float gc = m * a.coef_class / a.num_obj * (-lab / (pc + a.eps) + (1.0f - lab) / (1.0f - pc + a.eps));
+      const float gc = m * a.coef_class / nobj * (-lab / (pc + a.eps) + (1.0f - lab) / (1.0f - pc + a.eps));
       gdotp += gc * pc;
     }
     for (int c = 0; c < a.C; ++c) {
       const float pc = expf(lg[c] - mx) * inv;
       const float lab = a.labels[idx * a.C + c];
-      const float gc = m * a.coef_class / a.num_obj * (-lab / (pc + a.eps) + (1.0f - lab) / (1.0f - pc + a.eps));
+      const float gc = m * a.coef_class / nobj * (-lab / (pc + a.eps) + (1.0f - lab) / (1.0f - pc + a.eps));
       dp[k * a.C + c] = pc * (gc - gdotp);
     }
     // decode (as interpret_output) -> IoU with the ground-truth box (nn_skeleton.py:240-269)
@@ -309,18 +311,18 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
     const float iou = inter / (uni + a.eps) * m;
     a.ious[idx] = iou;
     // confidence loss (:304-312): mean over the batch of sum_a (iou-conf)^2 * w_a
-    const float wgt = m * a.coef_pos / a.num_obj + (1.0f - m) * a.coef_neg / ((float)A - a.num_obj);
+    const float wgt = m * a.coef_pos / nobj + (1.0f - m) * a.coef_neg / ((float)A - nobj);
     const float dc = iou - conf;
     l_conf += dc * dc * wgt / (float)a.B;
     dp[a.K * a.C + k] = 2.0f * (conf - iou) * wgt / (float)a.B * conf * (1.0f - conf);
     // bbox loss (:317-323)
     for (int d = 0; d < 4; ++d) {
       const float df = m * (dl[d] - a.delta_in[idx * 4 + d]);
-      l_bbox += a.coef_bbox * df * df / a.num_obj;
-      dp[a.K * (a.C + 1) + 4 * k + d] = 2.0f * a.coef_bbox * m * df / a.num_obj;
+      l_bbox += a.coef_bbox * df * df / nobj;
+      dp[a.K * (a.C + 1) + 4 * k + d] = 2.0f * a.coef_bbox * m * df / nobj;
     }
   }
-  l_class = l_class / a.num_obj;
+  l_class = l_class / nobj;
   red[0][threadIdx.x] = l_class; red[1][threadIdx.x] = l_conf; red[2][threadIdx.x] = l_bbox;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {
@@ -396,6 +398,62 @@ __global__ __launch_bounds__(256) void opt_apply_kernel(const OptSeg* __restrict
     const float ac = momentum * accum[s.off + i] + gc;   // MomentumOptimizer: accum = m*accum + g ; var -= lr*accum
     accum[s.off + i] = ac;
     w[s.off + i] = w[s.off + i] - lr * ac;
+  }
+}
+
+// out[0] = sum of x[0..n) in a fixed order (one workgroup: per-thread strided partial sums, then a tree over LDS):
+// num_objects = sum(input_mask), nn_skeleton.py:180, without a device -> host round trip
+__global__ __launch_bounds__(256) void sum_f32_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 256) s += x[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// y = max(a + b, 0) (tf.nn.relu(shortcut + branch), resnet50_convDet.py:55) -- the residual add where the producing conv
+// could not take it in its epilogue; 16-byte vectors
+template <typename T>
+__global__ void add_relu_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, size_t nv) {
+  typedef typename Vec16<T>::type V;
+  constexpr int EV = 16 / sizeof(T);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+    const V va = reinterpret_cast<const V*>(a)[i], vb = reinterpret_cast<const V*>(b)[i];
+    V r;
+#pragma unroll
+    for (int e = 0; e < EV; ++e) { const float t = (float)va[e] + (float)vb[e]; r[e] = (T)(t > 0.f ? t : 0.f); }
+    reinterpret_cast<V*>(y)[i] = r;
+  }
+}
+
+// y[p, coff .. coff + c) = x[p, 0 .. c): one input of tf.concat(axis=3) (nets/squeezeDet.py:106); 16-byte vectors
+template <typename T>
+__global__ void copy_channels_kernel(const T* __restrict__ x, T* __restrict__ y, size_t pixels, int cv, int cstride_v, int coff_v) {
+  typedef typename Vec16<T>::type V;
+  const size_t total = pixels * (size_t)cv;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = i / cv;
+    const int c = (int)(i - p * cv);
+    reinterpret_cast<V*>(y)[p * cstride_v + coff_v + c] = reinterpret_cast<const V*>(x)[i];
+  }
+}
+
+// mask[i] = floor(keep_prob + u_i), u_i uniform in [0,1): tf.nn.dropout's keep mask (nets/squeezeDet.py:74).  Counter-based
+// generator (one 64-bit mix of (seed, i) per element -- splitmix64), so the mask depends on (seed, index) only.
+template <typename T>
+__global__ void dropout_mask_kernel(T* __restrict__ mask, size_t n, float keep_prob, unsigned long long seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);   // 24 random bits -> [0, 1)
+    mask[i] = (T)floorf(keep_prob + u);
   }
 }
 
@@ -514,12 +572,89 @@ extern "C" int sqdet_maxpool_nhwc_bwd(const void* x, const void* dy, void* dx, i
   return SQDET_OK;
 }
 
+extern "C" int sqdet_sum_f32(const float* x, size_t count, float* out, sqdet_stream_t stream) {
+  SQDET_REQUIRE(x && out && count > 0, "sum_f32: bad arguments");
+  hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(256), 0, as_stream(stream), x, count, out);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_add_relu(const void* a, const void* b, void* y, size_t count, int dtype, sqdet_stream_t stream) {
+  SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "add_relu: bad dtype");
+  const size_t ev = 16 / dtype_size(dtype);
+  SQDET_REQUIRE(a && b && y && count % ev == 0, "add_relu: bad arguments (count must be a multiple of 16 bytes)");
+  const dim3 grid(grid_for(count / ev, 8192));
+  if (dtype == SQDET_F16)
+    hipLaunchKernelGGL(add_relu_kernel<f16>, grid, dim3(256), 0, as_stream(stream), (const f16*)a, (const f16*)b, (f16*)y, count / ev);
+  else
+    hipLaunchKernelGGL(add_relu_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)a, (const float*)b, (float*)y, count / ev);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_copy_channels(const void* x, void* y, size_t pixels, int c, int y_cstride, int y_coffset, int dtype,
+                                   sqdet_stream_t stream) {
+  SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "copy_channels: bad dtype");
+  const int ev = 16 / (int)dtype_size(dtype);
+  SQDET_REQUIRE(x && y && pixels > 0 && c > 0 && c % ev == 0 && y_cstride % ev == 0 && y_coffset % ev == 0 && y_coffset >= 0 &&
+                    y_coffset + c <= y_cstride, "copy_channels: channel counts / offsets must be multiples of 16 bytes");
+  const dim3 grid(grid_for(pixels * (size_t)(c / ev), 8192));
+  if (dtype == SQDET_F16)
+    hipLaunchKernelGGL(copy_channels_kernel<f16>, grid, dim3(256), 0, as_stream(stream), (const f16*)x, (f16*)y, pixels, c / ev, y_cstride / ev, y_coffset / ev);
+  else
+    hipLaunchKernelGGL(copy_channels_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, pixels, c / ev, y_cstride / ev, y_coffset / ev);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_dropout_mask(void* mask, size_t count, float keep_prob, uint64_t seed, int dtype, sqdet_stream_t stream) {
+  SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "dropout_mask: bad dtype");
+  SQDET_REQUIRE(mask && count > 0 && keep_prob > 0.f && keep_prob <= 1.f, "dropout_mask: bad arguments");
+  const dim3 grid(grid_for(count, 8192));
+  if (dtype == SQDET_F16)
+    hipLaunchKernelGGL(dropout_mask_kernel<f16>, grid, dim3(256), 0, as_stream(stream), (f16*)mask, count, keep_prob, (unsigned long long)seed);
+  else
+    hipLaunchKernelGGL(dropout_mask_kernel<float>, grid, dim3(256), 0, as_stream(stream), (float*)mask, count, keep_prob, (unsigned long long)seed);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
+static int loss_fwd_bwd_impl(const float* preds, const float* anchors, const float* input_mask,
+                             const float* box_delta_input, const float* box_input, const float* labels,
+                             float* dpreds, float* ious, float* losses3, float* workspace, int batch, int gh, int gw,
+                             int apg, int classes, float img_w, float img_h, float exp_thresh, float epsilon,
+                             float coef_class, float coef_conf_pos, float coef_conf_neg, float coef_bbox,
+                             float num_objects, const float* num_objects_dev, sqdet_stream_t stream);
+
+extern "C" int sqdet_loss_fwd_bwd_dev(const float* preds, const float* anchors, const float* input_mask,
+                                      const float* box_delta_input, const float* box_input, const float* labels,
+                                      float* dpreds, float* ious, float* losses3, float* workspace, int batch, int gh, int gw,
+                                      int apg, int classes, float img_w, float img_h, float exp_thresh, float epsilon,
+                                      float coef_class, float coef_conf_pos, float coef_conf_neg, float coef_bbox,
+                                      const float* num_objects_dev, sqdet_stream_t stream) {
+  SQDET_REQUIRE(num_objects_dev, "loss_fwd_bwd_dev: null num_objects");
+  return loss_fwd_bwd_impl(preds, anchors, input_mask, box_delta_input, box_input, labels, dpreds, ious, losses3, workspace,
+                           batch, gh, gw, apg, classes, img_w, img_h, exp_thresh, epsilon, coef_class, coef_conf_pos,
+                           coef_conf_neg, coef_bbox, 1.0f, num_objects_dev, stream);
+}
+
 extern "C" int sqdet_loss_fwd_bwd(const float* preds, const float* anchors, const float* input_mask,
                                   const float* box_delta_input, const float* box_input, const float* labels,
                                   float* dpreds, float* ious, float* losses3, float* workspace, int batch, int gh, int gw,
                                   int apg, int classes, float img_w, float img_h, float exp_thresh, float epsilon,
                                   float coef_class, float coef_conf_pos, float coef_conf_neg, float coef_bbox,
                                   float num_objects, sqdet_stream_t stream) {
+  return loss_fwd_bwd_impl(preds, anchors, input_mask, box_delta_input, box_input, labels, dpreds, ious, losses3, workspace,
+                           batch, gh, gw, apg, classes, img_w, img_h, exp_thresh, epsilon, coef_class, coef_conf_pos,
+                           coef_conf_neg, coef_bbox, num_objects, nullptr, stream);
+}
+
+static int loss_fwd_bwd_impl(const float* preds, const float* anchors, const float* input_mask,
+                                  const float* box_delta_input, const float* box_input, const float* labels,
+                                  float* dpreds, float* ious, float* losses3, float* workspace, int batch, int gh, int gw,
+                                  int apg, int classes, float img_w, float img_h, float exp_thresh, float epsilon,
+                                  float coef_class, float coef_conf_pos, float coef_conf_neg, float coef_bbox,
+                                  float num_objects, const float* num_objects_dev, sqdet_stream_t stream) {
   SQDET_REQUIRE(preds && anchors && input_mask && box_delta_input && box_input && labels && dpreds && ious && losses3 &&
                     workspace, "loss_fwd_bwd: null pointer");
   SQDET_REQUIRE(batch > 0 && gh > 0 && gw > 0 && apg > 0 && classes > 0 && num_objects > 0.f, "loss_fwd_bwd: bad arguments");
@@ -530,6 +665,7 @@ extern "C" int sqdet_loss_fwd_bwd(const float* preds, const float* anchors, cons
   a.w1 = img_w - 1.0f; a.h1 = img_h - 1.0f; a.thr = exp_thresh; a.slope = (float)exp((double)exp_thresh); a.eps = epsilon;
   a.coef_class = coef_class; a.coef_pos = coef_conf_pos; a.coef_neg = coef_conf_neg; a.coef_bbox = coef_bbox;
   a.num_obj = num_objects;
+  a.num_obj_dev = num_objects_dev;
   const long total = (long)batch * gh * gw * apg;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 512) blocks = 512;

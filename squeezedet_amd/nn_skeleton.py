@@ -82,6 +82,7 @@ class ModelSkeleton:
         # nn_skeleton.py:78
         self.keep_prob = 0.5 if mc.IS_TRAINING else 1.0
         self._gen = torch.Generator().manual_seed(seed)
+        self._seed = int(seed)
         # nn_skeleton.py:81-84,121: [BATCH, H, W, 3] float32 BGR mean-subtracted NHWC
         self.ph_image_input = Node(self, "placeholder", shape=(mc.BATCH_SIZE, mc.IMAGE_HEIGHT, mc.IMAGE_WIDTH, 3), name="image_input")
         self.image_input = self.ph_image_input
@@ -299,6 +300,8 @@ class ModelSkeleton:
 
     def _to_input(self, value):
         x = value if isinstance(value, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(value, dtype=np.float32)))
+        if x.is_cuda and x.dtype != self.dtype and x.dtype in (torch.float32, torch.float16) and x.numel() % 4 == 0:
+            x = ops.convert_scale(x.contiguous(), self.dtype)      # (device float32 -> float16: the HIP cast kernel)
         x = x.to(self.device, self.dtype).contiguous()
         mc = self.mc
         if x.dim() != 4 or tuple(x.shape[1:]) != (mc.IMAGE_HEIGHT, mc.IMAGE_WIDTH, 3):
@@ -338,7 +341,7 @@ class ModelSkeleton:
             else:
                 a = self._eval(shortcut, env, use_plan)
                 b = self._eval(branch, env, use_plan)
-                v = torch.relu(a + b)
+                v = ops.add_relu(a, b)
         elif node.op == "pool":
             x = self._eval(node.inputs[0], env, use_plan)
             v = ops.maxpool_nhwc(x, node.attrs["size"], node.attrs["stride"], node.attrs["padding"])
@@ -354,12 +357,18 @@ class ModelSkeleton:
                                     i.attrs["padding"], i.attrs["relu"], out=v, out_coffset=off)
                     off += i.shape[3]
             else:
-                v = torch.cat([self._eval(i, env, use_plan) for i in node.inputs], dim=3).contiguous()
+                xs = [self._eval(i, env, use_plan) for i in node.inputs]
+                v = torch.empty(tuple(xs[0].shape[:3]) + (node.shape[3],), dtype=self.dtype, device=self.device)
+                off = 0
+                for x in xs:
+                    ops.copy_channels(x.contiguous(), v, off)
+                    off += int(x.shape[3])
         elif node.op == "dropout":
             x = self._eval(node.inputs[0], env, use_plan)
             kp = node.attrs["keep_prob"]
-            dmask = torch.floor(kp + torch.rand(x.shape, device=x.device))
-            v = ops.scale_mask(x.float().contiguous(), dmask, 1.0 / kp).to(x.dtype)
+            self._dropout_calls = getattr(self, "_dropout_calls", 0) + 1
+            dmask = ops.dropout_mask(tuple(x.shape), kp, (self._seed << 32) + self._dropout_calls, x.dtype, x.device)
+            v = ops.scale_mask(x.contiguous(), dmask, 1.0 / kp)
         elif node.op == "interpret":
             preds = self._eval(node.inputs[0], env, use_plan)
             v = ops.interpret_output(preds, self.anchors_f32(), mc.CLASSES, mc.ANCHOR_PER_GRID, mc.IMAGE_WIDTH,
@@ -379,6 +388,10 @@ class ModelSkeleton:
         """Evaluates graph nodes.  feed_dict: {model.image_input: array or device tensor}."""
         if not self.has_device:
             raise SqdetError("squeezedet_amd needs a HIP device to run: there is no CPU path")
+        with torch.cuda.device(self.device):     # kernels go to the stream of the MODEL's device (gpu_id), whatever is current
+            return self._run(fetches, feed_dict, as_numpy, use_plan)
+
+    def _run(self, fetches, feed_dict, as_numpy, use_plan):
         env = {}
         self._fetching = set(fetches)
         for k, v in feed_dict.items():
@@ -397,7 +410,7 @@ class ModelSkeleton:
         return tuple(self.run([self.det_boxes, self.det_probs, self.det_class], {self.image_input: images},
                               use_plan=use_plan))
 
-    def detect_filter_pipelined(self, images):
+    def detect_filter_pipelined(self, images, to_host=False):
         """One step of the serving loop as a two-stage pipeline: the network forward runs on the caller's stream,
         interpret_output + filter_prediction (a few dozen microseconds of latency-bound work on 32 workgroups)
         run on a side HIP stream behind an event, so the NEXT batch's forward starts while this batch's boxes
@@ -409,7 +422,14 @@ class ModelSkeleton:
         version: preds had to be record_stream'ed for the side stream, so the caching allocator could not reuse a
         block until its event had completed; a host running a hundred steps ahead then asked for a hundred preds
         buffers, i.e. hipMalloc inside the serving loop -- the same binary measured 0.77 or 1.0-1.2 ms per step from
-        one run to the next.)  The returned tensors are those of the slot: valid until the second-next call."""
+        one run to the next.)  The returned tensors are those of the slot: valid until the second-next call.
+        to_host=True: the filtered rows (<= TOP_N per image: boxes, probs, classes, anchor indices, counts) are also copied
+        to the slot's PINNED host buffers on the side stream -- what sess.run + filter_prediction hand the reference's
+        caller -- and those host tensors are returned (complete once the side stream / the device is synchronised)."""
+        with torch.cuda.device(self.device):
+            return self._detect_filter_pipelined(images, to_host)
+
+    def _detect_filter_pipelined(self, images, to_host):
         mc = self.mc
         if getattr(self, "post_stream", None) is None:
             # high priority: the two small post-processing kernels are dispatched as soon as CUs free up at a kernel
@@ -432,7 +452,7 @@ class ModelSkeleton:
                                   out=(torch.empty((B, M, 4), dtype=f32, device=dev), torch.empty((B, M), dtype=f32, device=dev),
                                        torch.empty((B, M), dtype=torch.int32, device=dev), torch.empty((B, M), dtype=torch.int32, device=dev),
                                        torch.empty((B,), dtype=torch.int32, device=dev)),
-                                  fwd_done=torch.cuda.Event(), post_done=torch.cuda.Event(), used=False)
+                                  fwd_done=torch.cuda.Event(), post_done=torch.cuda.Event(), used=False, host=None)
                 self._pipe = dict(batch=B, slots=[mk(), mk()], k=0)
             s = self._pipe["slots"][self._pipe["k"] & 1]
             self._pipe["k"] += 1
@@ -446,9 +466,14 @@ class ModelSkeleton:
                                      mc.IMAGE_HEIGHT, mc.EXP_THRESH, out=s["det"])
                 ops.filter_prediction(s["det"][0], s["det"][1], s["det"][2], mc.CLASSES, mc.TOP_N_DETECTION, mc.NMS_THRESH,
                                       mc.PROB_THRESH, out=s["out"])
+                if to_host:
+                    if s["host"] is None:
+                        s["host"] = tuple(torch.empty(t_.shape, dtype=t_.dtype).pin_memory() for t_ in s["out"])
+                    for h_, d_ in zip(s["host"], s["out"]):
+                        h_.copy_(d_, non_blocking=True)
                 s["post_done"].record(self.post_stream)
             s["used"] = True
-            return s["out"]
+            return s["host"] if to_host else s["out"]
         (preds,) = self.run([self.preds], {self.image_input: images})
         self._post_event.record(cur)
         with torch.cuda.stream(self.post_stream):
@@ -457,6 +482,8 @@ class ModelSkeleton:
                                                      mc.IMAGE_HEIGHT, mc.EXP_THRESH)[:3]
             out = self.filter_prediction_batch(boxes, probs, cls)
             preds.record_stream(self.post_stream)      # the allocator must not hand preds' memory out before the side stream is done
+            if to_host:
+                out = tuple(t_.to("cpu", non_blocking=True) for t_ in out)
         return out
 
     # ------------------------------------------------------------------ filter_prediction

@@ -361,9 +361,49 @@ def maxpool_bwd(x, dy, size, stride, padding="SAME"):
     return dx
 
 
+def sum_f32(x, out=None):
+    """Deterministic sum of a float32 tensor into a device scalar (sqdet_sum_f32): num_objects = sum(input_mask)."""
+    out = torch.empty(1, dtype=torch.float32, device=x.device) if out is None else out
+    check(lib().sqdet_sum_f32(_dev(x, "x", torch.float32), int(x.numel()), _dev(out, "out", torch.float32), stream_ptr()), "sqdet_sum_f32")
+    return out
+
+
+def add_relu(a, b, out=None):
+    """max(a + b, 0) (sqdet_add_relu)."""
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise _lib.SqdetError("add_relu: operands differ in shape / dtype")
+    out = torch.empty_like(a) if out is None else out
+    check(lib().sqdet_add_relu(_dev(a, "a"), _dev(b, "b"), _dev(out, "out"), int(a.numel()), dtype_code(a.dtype), stream_ptr()), "sqdet_add_relu")
+    return out
+
+
+def copy_channels(x, out, out_coffset):
+    """out[..., out_coffset : out_coffset + C] = x (sqdet_copy_channels): one input of a channel concat."""
+    c = int(x.shape[-1])
+    check(lib().sqdet_copy_channels(_dev(x, "x"), _dev(out, "out"), int(x.numel() // c), c, int(out.shape[-1]), int(out_coffset),
+                                    dtype_code(x.dtype), stream_ptr()), "sqdet_copy_channels")
+    return out
+
+
+def dropout_mask(shape, keep_prob, seed, dtype, device):
+    """floor(keep_prob + U[0,1)) per element from a counter-based generator (sqdet_dropout_mask)."""
+    m = torch.empty(shape, dtype=dtype, device=device)
+    check(lib().sqdet_dropout_mask(_dev(m, "mask"), int(m.numel()), float(keep_prob), int(seed) & (2 ** 64 - 1), dtype_code(dtype),
+                                   stream_ptr()), "sqdet_dropout_mask")
+    return m
+
+
+def dropout_mask_into(mask, keep_prob, seed):
+    """Refills an existing mask tensor (static buffer of a captured step)."""
+    check(lib().sqdet_dropout_mask(_dev(mask, "mask"), int(mask.numel()), float(keep_prob), int(seed) & (2 ** 64 - 1),
+                                   dtype_code(mask.dtype), stream_ptr()), "sqdet_dropout_mask")
+    return mask
+
+
 def loss_fwd_bwd(preds, anchors_f32, input_mask, box_delta_input, box_input, labels, mc, num_objects):
     """ModelSkeleton._add_loss_graph forward + backward (nn_skeleton.py:285-327).  All tensors float32 on
-    the device.  Returns (dpreds, ious [B,A], losses [3] = class, conf, bbox)."""
+    the device.  num_objects: a Python number, or a float32 DEVICE scalar (no host round trip: hipGraph-capturable).
+    Returns (dpreds, ious [B,A], losses [3] = class, conf, bbox)."""
     n, gh, gw, ch = [int(v) for v in preds.shape]
     A = gh * gw * mc.ANCHOR_PER_GRID
     dev = preds.device
@@ -371,6 +411,16 @@ def loss_fwd_bwd(preds, anchors_f32, input_mask, box_delta_input, box_input, lab
     ious = torch.empty((n, A), dtype=torch.float32, device=dev)
     losses = torch.empty((3,), dtype=torch.float32, device=dev)
     ws = torch.empty(int(lib().sqdet_loss_workspace_bytes()) // 4 + 16, dtype=torch.float32, device=dev)
+    if isinstance(num_objects, torch.Tensor):
+        check(lib().sqdet_loss_fwd_bwd_dev(_dev(preds, "preds", torch.float32), _dev(anchors_f32, "anchors", torch.float32),
+                                           _dev(input_mask, "mask", torch.float32), _dev(box_delta_input, "delta", torch.float32),
+                                           _dev(box_input, "box", torch.float32), _dev(labels, "labels", torch.float32),
+                                           _dev(dpreds, "dpreds"), _dev(ious, "ious"), _dev(losses, "losses"), _dev(ws, "ws"),
+                                           n, gh, gw, int(mc.ANCHOR_PER_GRID), int(mc.CLASSES), float(mc.IMAGE_WIDTH),
+                                           float(mc.IMAGE_HEIGHT), float(mc.EXP_THRESH), float(mc.EPSILON), float(mc.LOSS_COEF_CLASS),
+                                           float(mc.LOSS_COEF_CONF_POS), float(mc.LOSS_COEF_CONF_NEG), float(mc.LOSS_COEF_BBOX),
+                                           _dev(num_objects, "num_objects", torch.float32), stream_ptr()), "sqdet_loss_fwd_bwd_dev")
+        return dpreds, ious, losses
     check(lib().sqdet_loss_fwd_bwd(_dev(preds, "preds", torch.float32), _dev(anchors_f32, "anchors", torch.float32),
                                    _dev(input_mask, "mask", torch.float32), _dev(box_delta_input, "delta", torch.float32),
                                    _dev(box_input, "box", torch.float32), _dev(labels, "labels", torch.float32),

@@ -7,9 +7,15 @@ _add_train_graph) and the training loop body of src/train.py:302-304
 Data parallelism: one process per GPU, replicas hold full weights, ONE flat float32
 gradient bucket all-reduced (SUM) per step over RCCL (torch.distributed backend "nccl"), divided by
 the world size inside the optimizer kernel, then per-variable clip_by_norm and Momentum -- applied
-identically (and deterministically) on every rank, so replicas stay bit-identical.  Loss
-normalisation is "replica-mean": each replica normalises by its own num_objects (the reference at
-its own batch size), gradients are averaged.
+identically (and deterministically) on every rank, so replicas stay bit-identical (the flat parameter and momentum
+buffers are broadcast from rank 0 when a trainer is built).  Loss normalisation: "replica-mean" by default -- each
+replica normalises by its own num_objects (the reference at its own batch size), gradients are averaged --, or, with
+`global_num_objects=True`, the exact global-batch form (SURVEY.md 8e option b): num_objects is SUM-all-reduced over the
+replicas before the loss (one extra scalar collective) and the gradient bucket is summed, not averaged, so N replicas of
+batch B compute what the reference computes at batch N*B (nn_skeleton.py:180,297,307-308,321).
+
+num_objects lives on the device (sqdet_sum_f32 of the mask) and the overflow flag is read lazily, so the forward +
+loss + backward of a step has no host round trip and can be replayed as one hipGraph (GraphedStep below).
 """
 import collections
 
@@ -40,7 +46,8 @@ class _TrainerBase:
     gradients overflowed (inf / NaN norm in any variable, on any rank -- the SUM all-reduce spreads it) is skipped by
     the optimizer kernel and halves the scale; `growth_interval` clean steps double it."""
 
-    def __init__(self, model, process_group=None, loss_scale=1024.0, growth_interval=200, lazy_overflow_check=False):
+    def __init__(self, model, process_group=None, loss_scale=1024.0, growth_interval=200, lazy_overflow_check=False,
+                 global_num_objects=False, seed=0):
         if model.dtype not in (torch.float32, torch.float16):
             raise SqdetError("training runs in float32 (the reference's training dtype) or float16 (mixed precision)")
         self.adt = model.dtype                       # activation dtype
@@ -55,10 +62,13 @@ class _TrainerBase:
         if not model.has_device:
             raise SqdetError("squeezedet_amd needs a HIP device: there is no CPU path")
         self.model, self.mc, self.dev = model, model.mc, model.device
+        # process_group=None: the default (WORLD) group when torch.distributed is initialised, else single-process
         self.pg = process_group
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+        self.global_num_objects = bool(global_num_objects)
+        self.seed, self._mask_calls = int(seed), 0
         self.global_step = 0
         # trainable variables (conv1 is frozen: nets/squeezeDet.py:40-42) packed into flat buffers
         self.names = [n for n in model.params if model.trainable[n]]
@@ -84,6 +94,9 @@ class _TrainerBase:
         model._plan_stale = True
         self.opt = ops.MomentumOptimizer(offs, cnts, decs, self.dev)
         self.found_inf = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        if self.world > 1:      # replicas start from rank 0's variables and momentum: they stay bit-identical from here on
+            torch.distributed.broadcast(self.flat_params, src=torch.distributed.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+            torch.distributed.broadcast(self.flat_accum, src=torch.distributed.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
 
     def learning_rate(self):
         mc = self.mc
@@ -92,9 +105,25 @@ class _TrainerBase:
     def _labels(self, B, input_mask, box_delta_input, box_input, labels, num_objects=None):
         t = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))).to(self.dev, torch.float32).contiguous()
         mask = t(input_mask).reshape(B, -1)
-        if num_objects is None:       # sum(input_mask): a device -> host sync; callers that know the count pass it
-            num_objects = float(mask.sum().item())
-        return t, mask, t(box_delta_input), t(box_input), t(labels), float(num_objects)
+        if num_objects is None:       # sum(input_mask) on the device (nn_skeleton.py:180): no host round trip
+            num_objects = ops.sum_f32(mask)
+        elif not isinstance(num_objects, torch.Tensor):
+            num_objects = torch.full((1,), float(num_objects), dtype=torch.float32, device=self.dev)
+        if self.global_num_objects and self.world > 1:      # exact global-batch normalisation: one scalar all-reduce
+            torch.distributed.all_reduce(num_objects, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        return t, mask, t(box_delta_input), t(box_input), t(labels), num_objects
+
+    def _mask_tensor(self, dropout_mask, t):
+        """A caller-supplied or generated keep mask as a device tensor of the activation dtype."""
+        if isinstance(dropout_mask, torch.Tensor) and dropout_mask.is_cuda and dropout_mask.dtype == self.adt:
+            return dropout_mask.contiguous()
+        dm = t(dropout_mask)                           # float32 on the device
+        return dm if self.adt == torch.float32 else ops.convert_scale(dm, self.adt)
+
+    def _dropout_mask(self, shape, keep):
+        """tf.nn.dropout's keep mask floor(keep_prob + U) from the counter-based HIP generator; a new seed per call."""
+        self._mask_calls += 1
+        return ops.dropout_mask(tuple(shape), keep, (self.seed << 32) + self._mask_calls, self.adt, self.dev)
 
     def _loss(self, preds, mask, delta, box, lab, num_objects):
         """Loss forward + backward in float32; returns (gradient w.r.t. preds in the activation dtype -- times
@@ -107,18 +136,19 @@ class _TrainerBase:
     def _finish_step(self, apply_update):
         """Gradient all-reduce (the one collective) + clipped Momentum update on the flat buffers."""
         grad_scale = allreduce_gradients(self.flat_grads, self.world, self.pg)
+        if self.global_num_objects:
+            grad_scale = 1.0      # every replica's loss is already divided by the GLOBAL num_objects: the bucket is a sum
         if apply_update:
+            # (the kernel skips the whole update when any gradient norm is inf / NaN, in either precision: found_inf tells)
             self.opt.step(self.flat_params, self.flat_grads, self.flat_accum, self.learning_rate(), self.mc.MOMENTUM,
-                          self.mc.MAX_GRAD_NORM, grad_scale, found_inf=self.found_inf if self.half else None)
+                          self.mc.MAX_GRAD_NORM, grad_scale, found_inf=self.found_inf)
             # packed / BN-folded kernels of the layers whose variables just changed are stale; the frozen layers'
             # (conv1 of SqueezeDet, conv1 .. res3d of ResNet50 -- re-folded and re-packed every step before) are not
             tr = self.model.trainable
             for k in [k for k in self.model._packed if tr.get(k + "/kernels", True)]:
                 del self.model._packed[k]
             self.model._plan_stale = True
-            if not self.half:
-                self.global_step += 1
-            elif not self.lazy_overflow_check:
+            if not self.lazy_overflow_check:
                 self._account(bool(int(self.found_inf.item())))
             else:
                 self.flush()                                  # the PREVIOUS step's flag (its event completed long ago)
@@ -137,6 +167,14 @@ class _TrainerBase:
             self._account(bool(int(self._flag_host[0])))
 
     def _account(self, overflowed):
+        if overflowed and not self.half:
+            # float32 has no loss scale to lower: a non-finite gradient means the run has diverged.  The reference asserts
+            # on the loss (train.py:313); here the kernel has left weights and momentum untouched and the caller is told.
+            self.skipped_steps += 1
+            raise FloatingPointError("non-finite gradient norm in float32 training (step %d): the update was skipped" % self.global_step)
+        if not self.half:
+            self.global_step += 1
+            return
         if overflowed:
             # the kernel left weights and momentum untouched; retry the next batch at half the scale
             self.loss_scale = max(self.loss_scale / 2.0, 2.0 ** -14)
@@ -196,6 +234,15 @@ class SqueezeDetTrainer(_TrainerBase):
         with loss, class_loss, conf_loss, bbox_loss (device scalars).  keep_activations: also return every stored
         forward activation as out["activations"] = {name: tensor} (names as oracle/train_oracle.py forward_train's
         `override`), for parity tests of the backward pass."""
+        with torch.cuda.device(self.dev):
+            out = self.forward_backward(images, input_mask, box_delta_input, box_input, labels, dropout_mask, keep_activations, num_objects)
+            self._finish_step(apply_update)
+        return out
+
+    def forward_backward(self, images, input_mask, box_delta_input, box_input, labels, dropout_mask=None,
+                         keep_activations=False, num_objects=None):
+        """Forward + loss + backward into the flat gradient bucket: kernel launches and stream-ordered allocations only,
+        no host round trip (hipGraph-capturable).  _finish_step (all-reduce + update) completes the step."""
         m, mc, P = self.model, self.mc, self.model.params
         acts = {}
         x = m._to_input(images)
@@ -212,8 +259,8 @@ class SqueezeDetTrainer(_TrainerBase):
                 if node.name == "conv12":
                     drop_in = cur
                     if dropout_mask is None:
-                        dropout_mask = torch.floor(keep + torch.rand(cur.shape, device=self.dev))   # tf.nn.dropout's mask
-                    dm = t(dropout_mask).to(self.adt)
+                        dropout_mask = self._dropout_mask(cur.shape, keep)                           # tf.nn.dropout's mask
+                    dm = self._mask_tensor(dropout_mask, t)
                     cur = ops.scale_mask(cur, dm, 1.0 / keep) if keep != 1.0 else cur
                     acts["drop"] = cur
                 y = ops.conv2d_nhwc(cur, self._pack(node.name), P[node.name + "/biases"], node.attrs["stride"],
@@ -279,8 +326,6 @@ class SqueezeDetTrainer(_TrainerBase):
                 ops.conv2d_bwd_filter(xin, ds, 1, int(xin.shape[3]), ns, dw=self.gview[sq.name + "/kernels"], db=self.gview[sq.name + "/biases"], grad_scale=gs)
                 if need_dx:
                     g = ops.conv2d_bwd_data(ds, bwd(sq.name))
-        # ---------------- gradient all-reduce + update ----------------
-        self._finish_step(apply_update)
         out = collections.OrderedDict(class_loss=losses[0], conf_loss=losses[1], bbox_loss=losses[2], ious=ious, preds=preds,
                                       dpreds=dpreds, num_objects=num_objects)
         if keep_activations:
@@ -324,6 +369,13 @@ class ResNet50ConvDetTrainer(_TrainerBase):
 
     def step(self, images, input_mask, box_delta_input, box_input, labels, dropout_mask=None, apply_update=True,
              keep_activations=False, num_objects=None):
+        with torch.cuda.device(self.dev):
+            out = self.forward_backward(images, input_mask, box_delta_input, box_input, labels, dropout_mask, keep_activations, num_objects)
+            self._finish_step(apply_update)
+        return out
+
+    def forward_backward(self, images, input_mask, box_delta_input, box_input, labels, dropout_mask=None,
+                         keep_activations=False, num_objects=None):
         m, mc, P = self.model, self.mc, self.model.params
         eps = mc.BATCH_NORM_EPSILON
         (xb,) = m.run([self.boundary], {m.image_input: images}, use_plan=False)
@@ -344,7 +396,7 @@ class ResNet50ConvDetTrainer(_TrainerBase):
             elif n.op == "add_relu":
                 sc, br = n.inputs
                 if br in val:
-                    val[n] = torch.relu(val[sc] + val[br])
+                    val[n] = ops.add_relu(val[sc], val[br])
                 else:
                     wf, bf = aux[br], aux[(br, "bf")]
                     out = val[sc].clone()         # the shortcut is branch2a's input: its value is needed by the backward
@@ -354,8 +406,8 @@ class ResNet50ConvDetTrainer(_TrainerBase):
                 x = val[n.inputs[0]]
                 keep = n.attrs["keep_prob"]
                 if dropout_mask is None:
-                    dropout_mask = torch.floor(keep + torch.rand(x.shape, device=self.dev))
-                aux[n] = t(dropout_mask).to(self.adt)
+                    dropout_mask = self._dropout_mask(x.shape, keep)
+                aux[n] = self._mask_tensor(dropout_mask, t)
                 val[n] = ops.scale_mask(x, aux[n], 1.0 / keep)
             elif n.op == "conv":
                 x = val[n.inputs[0]]
@@ -412,9 +464,57 @@ class ResNet50ConvDetTrainer(_TrainerBase):
                                        dgamma=self.gview[n.name + "/gamma"], dbeta=self.gview[n.name + "/beta"])
                 if stride == 1:
                     give(n.inputs[0], gy, ops.PackedConvBwd(aux[n], self.adt))
-        self._finish_step(apply_update)
         out = collections.OrderedDict(class_loss=losses[0], conf_loss=losses[1], bbox_loss=losses[2], ious=ious, preds=preds,
                                       dpreds=dpreds, num_objects=num_objects)
         if keep_activations:     # names as oracle/resnet_oracle.py forward_train's `override`
             out["activations"] = {n.name: v for n, v in val.items()}
         return out
+
+
+class GraphedStep:
+    """A training step replayed as ONE hipGraph (the reference issues one sess.run per step, train.py:302-304; issuing the
+    ~300 launches of a step from Python took longer than the GPU needs to run them).  The graph holds the GPU label build
+    (sqdet_build_labels), forward, loss and backward into the flat gradient bucket -- static shapes, no host round trip;
+    the inputs are copied into static buffers, the dropout mask is drawn by one launch ahead of the replay, and the
+    gradient all-reduce + optimizer step follow it eagerly (so the collective is an ordinary RCCL call).  Anything that
+    enters the captured launches BY VALUE (the loss scale) triggers a re-capture when it changes."""
+
+    def __init__(self, trainer, anchors_f64, classes):
+        self.tr, self.anchors, self.classes = trainer, anchors_f64, int(classes)
+        self.graph, self.static, self.out, self.key = None, None, None, None
+
+    def _capture(self, x, gt, gcls, gcnt):
+        tr = self.tr
+        st = dict(x=x.clone(), gt=gt.clone(), gcls=gcls.clone(), gcnt=gcnt.clone())
+        keep = tr.model.keep_prob
+        # the dropout sits in front of the last conv: its input has the last conv's Cin channels on the output grid
+        last = tr.model.preds
+        din = last.inputs[0]
+        dshape = (int(x.shape[0]),) + tuple(int(v) for v in din.get_shape()[1:])
+        st["mask"] = torch.ones(dshape, dtype=tr.adt, device=tr.dev)
+        run = lambda: tr.forward_backward(st["x"], *ops.build_labels(self.anchors, st["gt"], st["gcls"], st["gcnt"], self.classes)[:4],
+                                          dropout_mask=st["mask"] if keep != 1.0 else None)
+        side = torch.cuda.Stream(device=tr.dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run()                                     # warm-up on the side stream (allocator pools, lazy one-time set-up)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                out = run()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph, self.static, self.out = g, st, out
+        self.key = (tr.loss_scale, tuple(x.shape))
+
+    def step(self, x, gt, gcls, gcnt, apply_update=True):
+        tr = self.tr
+        with torch.cuda.device(tr.dev):
+            if self.graph is None or self.key != (tr.loss_scale, tuple(x.shape)):
+                self._capture(x, gt, gcls, gcnt)
+            st = self.static
+            st["x"].copy_(x); st["gt"].copy_(gt); st["gcls"].copy_(gcls); st["gcnt"].copy_(gcnt)
+            if tr.model.keep_prob != 1.0:
+                tr._mask_calls += 1
+                ops.dropout_mask_into(st["mask"], tr.model.keep_prob, (tr.seed << 32) + tr._mask_calls)
+            self.graph.replay()
+            tr._finish_step(apply_update)
+        return self.out

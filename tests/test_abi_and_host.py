@@ -183,6 +183,7 @@ def test_loss_scale_bookkeeping_state_machine():
     from squeezedet_amd.train import _TrainerBase
     tr = _TrainerBase.__new__(_TrainerBase)          # no device needed for the state machine
     tr.loss_scale, tr.growth_interval, tr._clean_steps, tr.skipped_steps, tr.global_step = 1024.0, 3, 0, 0, 0
+    tr.half = True
     tr._account(True)
     assert (tr.loss_scale, tr.skipped_steps, tr.global_step, tr._clean_steps) == (512.0, 1, 0, 0)
     for _ in range(2):
@@ -201,3 +202,12 @@ def test_loss_scale_bookkeeping_state_machine():
     tr._pending_flag = None
     tr.flush()                                       # nothing pending: a no-op
     assert tr.global_step == 4
+    # float32 training has no scale to lower: clean steps just count, a non-finite gradient norm is an error (the
+    # reference asserts on a NaN loss, train.py:313) -- the kernel has skipped the update, the caller is told
+    tr.half, tr.loss_scale = False, 1.0
+    for _ in range(5):
+        tr._account(False)
+    assert tr.global_step == 9 and tr.loss_scale == 1.0
+    with pytest.raises(FloatingPointError):
+        tr._account(True)
+    assert tr.skipped_steps == 4 and tr.global_step == 9

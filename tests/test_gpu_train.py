@@ -422,7 +422,7 @@ def test_training_step_from_gpu_built_labels():
     mask, delta, box, lab, _ = ops.build_labels(omc.ANCHOR_BOX, gt, cls, cnt, 3, device=DEV)
     x = O.synthetic_images(2, 128, 256, seed=9)
     out = tr.step(x, mask, delta, box, lab)
-    assert out["num_objects"] == 6.0 and np.isfinite(float(out["bbox_loss"]))
+    assert float(out["num_objects"]) == 6.0 and np.isfinite(float(out["bbox_loss"]))
 
 
 def test_squeezedet_plus_training_step_vs_oracle():
