@@ -353,7 +353,13 @@ int sqdet_preprocess_bgr(const uint8_t* src_bgr_u8, void* dst, int n, int src_h,
                          float mean_b, float mean_g, float mean_r, int dtype, sqdet_stream_t stream);
 
 /* ------------------------------------------------------------ utilities --
- * Hardware self-test used by the GPU test-suite: runs one MFMA of each shape
+ * Device -> pinned-host copy issued as a KERNEL: dst is host memory mapped into the device's address space
+ * (hipHostMalloc); nbytes a multiple of 16.  Used by the serving loop to hand the <= 64 filtered rows per image
+ * (the return value of the reference's filter_prediction, nn_skeleton.py:696-734) to the host without a blocking
+ * memcpy call.  The data is complete on the host once `stream` has been synchronised. */
+int sqdet_copy_to_mapped_host(const void* src_device, void* dst_pinned_host, size_t nbytes, sqdet_stream_t stream);
+
+/* Hardware self-test used by the GPU test-suite: runs one MFMA of each shape
  * the kernels rely on with index-encoded operands and writes the observed
  * (row, col) of every accumulator register to host_out (see csrc/probe.hip). */
 int sqdet_probe_mfma_layout(int32_t* host_out, int capacity);

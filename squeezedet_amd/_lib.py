@@ -75,6 +75,7 @@ SIGNATURES = {
     "sqdet_net_read_probe": (ci, [vp, C.POINTER(cf), ci, C.POINTER(ci)]),
     "sqdet_build_labels": (ci, [vp] * 9 + [ci] * 4 + [vp]),
     "sqdet_preprocess_bgr": (ci, [vp, vp] + [ci] * 5 + [cf, cf, cf, ci, vp]),
+    "sqdet_copy_to_mapped_host": (ci, [vp, vp, sz, vp]),
     "sqdet_probe_mfma_layout": (ci, [C.POINTER(C.c_int32), ci]),
 }
 

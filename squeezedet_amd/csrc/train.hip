@@ -747,3 +747,23 @@ extern "C" int sqdet_optimizer_step(sqdet_optimizer* o, float* params, float* gr
   SQDET_CHECK_HIP(hipGetLastError());
   return SQDET_OK;
 }
+
+// Device -> PINNED HOST copy as a kernel (the destination is host memory mapped into the device's address space:
+// hipHostMalloc / torch pin_memory).  hipMemcpyAsync device -> host was observed to hold the calling host thread until
+// the stream reached the copy, which serialised the serving loop's two-stage pipeline; a kernel launch never does.
+namespace sqdet {
+__global__ void copy_to_mapped_host_kernel(const int4* __restrict__ src, int4* __restrict__ dst, size_t nv) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+}  // namespace sqdet
+
+extern "C" int sqdet_copy_to_mapped_host(const void* src_device, void* dst_pinned_host, size_t nbytes, sqdet_stream_t stream) {
+  SQDET_REQUIRE(src_device && dst_pinned_host && nbytes > 0 && nbytes % 16 == 0, "copy_to_mapped_host: bad arguments (16-byte multiples)");
+  const size_t nv = nbytes / 16;
+  size_t blocks = (nv + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(sqdet::copy_to_mapped_host_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                     (const int4*)src_device, (int4*)dst_pinned_host, nv);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}

@@ -446,13 +446,25 @@ class ModelSkeleton:
                 A = mc.ANCHORS
                 M = mc.TOP_N_DETECTION if 0 < mc.TOP_N_DETECTION < A else min(A, 1024)
                 f32, dev = torch.float32, self.device
-                mk = lambda: dict(preds=torch.empty((B, plan.gh, plan.gw, plan.out_ch), dtype=self.dtype, device=dev),
-                                  det=(torch.empty((B, A, 4), dtype=f32, device=dev), torch.empty((B, A), dtype=f32, device=dev),
-                                       torch.empty((B, A), dtype=torch.int64, device=dev)),
-                                  out=(torch.empty((B, M, 4), dtype=f32, device=dev), torch.empty((B, M), dtype=f32, device=dev),
-                                       torch.empty((B, M), dtype=torch.int32, device=dev), torch.empty((B, M), dtype=torch.int32, device=dev),
-                                       torch.empty((B,), dtype=torch.int32, device=dev)),
-                                  fwd_done=torch.cuda.Event(), post_done=torch.cuda.Event(), used=False, host=None)
+                def out_views(flat):
+                    """(boxes [B,M,4] f32, probs [B,M] f32, cls [B,M] i32, anchor index [B,M] i32, count [B] i32) as views of ONE
+                    byte buffer, so the filtered rows leave the device in a single copy"""
+                    o, views = 0, []
+                    for shape, dt in (((B, M, 4), f32), ((B, M), f32), ((B, M), torch.int32), ((B, M), torch.int32), ((B,), torch.int32)):
+                        nb = int(np.prod(shape)) * 4
+                        views.append(flat[o:o + nb].view(dt).view(shape))
+                        o += (nb + 255) // 256 * 256
+                    return tuple(views)
+                out_bytes = sum((int(np.prod(sh)) * 4 + 255) // 256 * 256 for sh in ((B, M, 4), (B, M), (B, M), (B, M), (B,)))
+
+                def mk():
+                    flat = torch.empty(out_bytes, dtype=torch.uint8, device=dev)
+                    return dict(preds=torch.empty((B, plan.gh, plan.gw, plan.out_ch), dtype=self.dtype, device=dev),
+                                det=(torch.empty((B, A, 4), dtype=f32, device=dev), torch.empty((B, A), dtype=f32, device=dev),
+                                     torch.empty((B, A), dtype=torch.int64, device=dev)),
+                                flat=flat, out=out_views(flat), host_flat=None, host=None,
+                                fwd_done=torch.cuda.Event(), post_done=torch.cuda.Event(), used=False)
+                self._out_views = out_views
                 self._pipe = dict(batch=B, slots=[mk(), mk()], k=0)
             s = self._pipe["slots"][self._pipe["k"] & 1]
             self._pipe["k"] += 1
@@ -468,9 +480,9 @@ class ModelSkeleton:
                                       mc.PROB_THRESH, out=s["out"])
                 if to_host:
                     if s["host"] is None:
-                        s["host"] = tuple(torch.empty(t_.shape, dtype=t_.dtype).pin_memory() for t_ in s["out"])
-                    for h_, d_ in zip(s["host"], s["out"]):
-                        h_.copy_(d_, non_blocking=True)
+                        s["host_flat"] = torch.empty(s["flat"].shape, dtype=torch.uint8).pin_memory()
+                        s["host"] = self._out_views(s["host_flat"])
+                    ops.copy_to_pinned_host(s["flat"], s["host_flat"])      # all five outputs in one launch (never blocks the host)
                 s["post_done"].record(self.post_stream)
             s["used"] = True
             return s["host"] if to_host else s["out"]

@@ -393,6 +393,16 @@ def dropout_mask(shape, keep_prob, seed, dtype, device):
     return m
 
 
+def copy_to_pinned_host(src, dst_pinned):
+    """src (device, contiguous) -> dst_pinned (a pin_memory() host tensor of the same byte size) by a kernel launch on the
+    current stream (sqdet_copy_to_mapped_host): never blocks the host thread."""
+    if not dst_pinned.is_pinned() or dst_pinned.numel() * dst_pinned.element_size() != src.numel() * src.element_size():
+        raise _lib.SqdetError("copy_to_pinned_host: dst must be pinned host memory of the same size")
+    check(lib().sqdet_copy_to_mapped_host(_dev(src, "src"), C.c_void_p(dst_pinned.data_ptr()), int(src.numel() * src.element_size()),
+                                          stream_ptr()), "sqdet_copy_to_mapped_host")
+    return dst_pinned
+
+
 def dropout_mask_into(mask, keep_prob, seed):
     """Refills an existing mask tensor (static buffer of a captured step)."""
     check(lib().sqdet_dropout_mask(_dev(mask, "mask"), int(mask.numel()), float(keep_prob), int(seed) & (2 ** 64 - 1),

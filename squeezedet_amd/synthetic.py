@@ -25,8 +25,13 @@ def synthetic_params(model, seed=0):
             sigma = math.sqrt(2.0 / (shp[0] * shp[1] * shp[2]))
             if name.startswith("conv1/"):
                 sigma /= 64.0   # inputs are pixel-scale (rms ~74): bring activations to O(1)
-            if name.startswith("conv12") or name.startswith("conv5/"):
+            if name.startswith("conv12"):
                 sigma *= 2.0    # preds of std ~2: scores spread without saturating
+            if name.startswith("conv5/"):
+                # ResNet50+ConvDet: the residual stream reaches conv5 with std ~7 under these synthetic BN statistics
+                # (measured); He x 2 gave preds of std 24 -- box deltas of +-50, exp() of them, a bbox loss of 6e4 and
+                # float16 gradient overflow on EVERY step (all updates skipped).  He / 6 brings preds back to std ~2.
+                sigma /= 6.0
             z = np.clip(rng.standard_normal(size=shp), -2.0, 2.0)
             out[name] = torch.from_numpy((z * sigma).astype(np.float32))
         elif name.endswith("/gamma") or name.endswith("/var"):

@@ -482,6 +482,7 @@ class GraphedStep:
     def __init__(self, trainer, anchors_f64, classes):
         self.tr, self.anchors, self.classes = trainer, anchors_f64, int(classes)
         self.graph, self.static, self.out, self.key = None, None, None, None
+        self.cache = {}      # (loss scale, input shape) -> (graph, static buffers, outputs): a scale seen before is not re-captured
 
     def _capture(self, x, gt, gcls, gcnt):
         tr = self.tr
@@ -504,12 +505,18 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         self.graph, self.static, self.out = g, st, out
         self.key = (tr.loss_scale, tuple(x.shape))
+        self.cache[self.key] = (g, st, out)
 
     def step(self, x, gt, gcls, gcnt, apply_update=True):
         tr = self.tr
         with torch.cuda.device(tr.dev):
-            if self.graph is None or self.key != (tr.loss_scale, tuple(x.shape)):
-                self._capture(x, gt, gcls, gcnt)
+            key = (tr.loss_scale, tuple(x.shape))
+            if self.key != key:
+                if key in self.cache:
+                    self.graph, self.static, self.out = self.cache[key]
+                    self.key = key
+                else:
+                    self._capture(x, gt, gcls, gcnt)
             st = self.static
             st["x"].copy_(x); st["gt"].copy_(gt); st["gcls"].copy_(gcls); st["gcnt"].copy_(gcnt)
             if tr.model.keep_prob != 1.0:
