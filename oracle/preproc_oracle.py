@@ -10,9 +10,10 @@ import numpy as np
 
 
 def _coords(n_dst, n_src):
-    f32 = np.float32
-    scale = f32(float(n_src) / float(n_dst))
-    f = (np.arange(n_dst, dtype=np.float32) + f32(0.5)) * scale - f32(0.5)
+    # cv::resize forms the source coordinate in double -- (float)((dx + 0.5) * scale - 0.5), scale = (double)src / dst --
+    # and rounds it once to float32
+    scale = float(n_src) / float(n_dst)
+    f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
     s = np.floor(f).astype(np.int64)
     f = (f - s.astype(np.float32)).astype(np.float32)
     lo = s < 0

@@ -162,30 +162,31 @@ __global__ __launch_bounds__(FT) void filter_topn_fast(FilterArgs a) {
     if (rank < M) s.sel[rank] = mine;
   }
   __syncthreads();
-  if (tid >= 64) return;
-
-  // ---- 5. wave 0: NMS + ordered output ----
+  // ---- 5. wave 0: NMS + ordered output (the other waves stay alive and take part in the two barriers: a barrier
+  //         behind an early return is undefined in the HIP programming model) ----
+  const bool w0 = tid < 64;
   const int r = tid;
   int idx = 0, c = -1;
   f32x4 bj = {0.f, 0.f, 0.f, 0.f};
-  if (r < M) {
+  if (w0 && r < M) {
     idx = (int)(s.sel[r] & 0xffffffffull);
     bj = *reinterpret_cast<const f32x4*>(boxes + (size_t)idx * 4);
     c = (int)cls[idx];
     s.box[r] = bj;
     s.cls[r] = c;
   }
-  __syncthreads();  // only wave 0 is left (terminated waves do not take part in the barrier)
+  __syncthreads();
   // the reference's non-greedy NMS (utils/util.py:56-76): r is dropped iff ANY higher-ranked
   // same-class box has IoU > threshold (compared in float64, as under the reference's NumPy 1.12)
-  bool keep = r < M && c >= 0 && c < a.C;
+  bool keep = w0 && r < M && c >= 0 && c < a.C;
   for (int i = 0; i < r && keep; ++i) {
     if (s.cls[i] != c) continue;
     const float ov = iou_center(bj, s.box[i]);
     if ((double)ov > a.nms_thresh) keep = false;
   }
-  s.keep[r] = keep ? 1 : 0;
+  if (w0) s.keep[r] = keep ? 1 : 0;
   __syncthreads();
+  if (!w0) return;
   // output position: kept entries ordered by class, then rank (nn_skeleton.py:726-733)
   int pos = 0, kept = 0;
   for (int i = 0; i < M; ++i) {

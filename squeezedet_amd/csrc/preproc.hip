@@ -3,7 +3,8 @@
 // input = im - mc.BGR_MEANS  -> one kernel: uint8 BGR HWC in, NHWC network input (storage dtype) out.
 //
 // cv2.resize, INTER_LINEAR, float32 (the default interpolation): source coordinate of destination x is
-//   fx = (x + 0.5) * (Ws / Wd) - 0.5;  sx = floor(fx);  fx -= sx;  sx < 0 -> (sx, fx) = (0, 0);
+//   fx = (float)((x + 0.5) * scale_x - 0.5) with scale_x = (double)Ws / Wd -- the coordinate is formed in DOUBLE and
+//   rounded once to float32, as cv::resize does --;  sx = floor(fx);  fx -= sx;  sx < 0 -> (sx, fx) = (0, 0);
 //   sx >= Ws - 1 -> (sx, fx) = (Ws - 1, 0)           (likewise in y),
 // rows are interpolated horizontally first (S[sx]*(1-fx) + S[sx+1]*fx), then vertically
 // (r0*(1-fy) + r1*fy), all in float32.  The same order is kept here, without FMA contraction.
@@ -14,13 +15,13 @@ namespace sqdet {
 template <typename T>
 __global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char* __restrict__ src, T* __restrict__ dst, int N,
                                                          int Hs, int Ws, int Hd, int Wd, float m0, float m1, float m2) {
-  const float scale_x = (float)((double)Ws / (double)Wd), scale_y = (float)((double)Hs / (double)Hd);
+  const double scale_x = (double)Ws / (double)Wd, scale_y = (double)Hs / (double)Hd;
   const size_t total = (size_t)N * Hd * Wd;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int x = (int)(idx % Wd);
     const int y = (int)((idx / Wd) % Hd);
     const int n = (int)(idx / ((size_t)Wd * Hd));
-    float fx = (x + 0.5f) * scale_x - 0.5f, fy = (y + 0.5f) * scale_y - 0.5f;
+    float fx = (float)((x + 0.5) * scale_x - 0.5), fy = (float)((y + 0.5) * scale_y - 0.5);
     int sx = (int)floorf(fx), sy = (int)floorf(fy);
     fx -= sx; fy -= sy;
     if (sx < 0) { sx = 0; fx = 0.f; }
