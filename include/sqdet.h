@@ -142,7 +142,8 @@ int sqdet_fire_maxpool_fwd(const void* x, const void* w_s, const float* b_s, con
  * y != NULL; sq_out [n,h,w,next_s1x1] only when next_s1x1 > 0 (at least one of the two).  The three kernels travel as
  * ONE packed weight stream (sqdet_fire_chain_pack: float32 HWIO in, any of the three may be NULL = that part of the
  * stream is left as it is); sqdet_fire_chain_stream_bytes returns 0 for shapes the kernel does not cover
- * (float16 only; s1x1 in 40..96 step 8, e1x1 / e3x3 multiples of 64, next_s1x1 in {0,48,64,96}).  Results are bitwise
+ * (float16 only; s1x1 in 8..96 step 8, e1x1 / e3x3 multiples of 64, next_s1x1 in {0,16,32,48} behind a squeeze of up to
+ * 32 channels, {0,48,64,96} behind a wider one).  Results are bitwise
  * those of sqdet_fire_fwd followed by the next module's squeeze conv. */
 size_t sqdet_fire_chain_stream_bytes(int s1x1, int e1x1, int e3x3, int next_s1x1, int dtype);
 int sqdet_fire_chain_pack(const float* w_e1_hwio, const float* w_e3_hwio, const float* w_next_s_hwio, void* stream_buf,

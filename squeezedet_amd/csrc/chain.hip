@@ -542,12 +542,23 @@ int launch_chain(const ChainArgs& a, hipStream_t st) {
 
 template <int NCH, bool WY>
 int dispatch_chain_nsq(const ChainArgs& a, int nsq, hipStream_t st) {
-  switch (nsq) {
-    case 0: if (WY) return launch_chain<NCH, 0, true>(a, st); break;
-    case 3: return launch_chain<NCH, 3, WY>(a, st);
-    case 4: return launch_chain<NCH, 4, WY>(a, st);
-    case 6: return launch_chain<NCH, 6, WY>(a, st);
-    default: break;
+  // (instantiated: the squeeze widths SqueezeDet pairs with each squeeze depth class -- fire2..5: 16 / 32 / 48 behind a
+  //  one-chunk squeeze; fire6..11: 48 / 64 / 96 behind two or three chunks)
+  if (nsq == 0) { if constexpr (WY) return launch_chain<NCH, 0, true>(a, st); }
+  if constexpr (NCH == 1) {
+    switch (nsq) {
+      case 1: return launch_chain<NCH, 1, WY>(a, st);
+      case 2: return launch_chain<NCH, 2, WY>(a, st);
+      case 3: return launch_chain<NCH, 3, WY>(a, st);
+      default: break;
+    }
+  } else {
+    switch (nsq) {
+      case 3: return launch_chain<NCH, 3, WY>(a, st);
+      case 4: return launch_chain<NCH, 4, WY>(a, st);
+      case 6: return launch_chain<NCH, 6, WY>(a, st);
+      default: break;
+    }
   }
   set_error("fire_chain: unsupported next-squeeze width");
   return SQDET_EUNSUPPORTED;
@@ -559,9 +570,9 @@ bool fire_chain_eligible(int s, int e1, int e3, int s2, int dtype) {
   if (dtype != SQDET_F16 || conv_algo() != 0) return false;
   if (s <= 0 || s % 8 != 0 || s > 96) return false;
   if (e1 <= 0 || e3 <= 0 || e1 % 64 != 0 || e3 % 64 != 0) return false;
-  if (!(s2 == 0 || s2 == 48 || s2 == 64 || s2 == 96)) return false;
+  if (!(s2 == 0 || s2 == 16 || s2 == 32 || s2 == 48 || s2 == 64 || s2 == 96)) return false;
   const ChainGeom g = chain_geom(s, e1, e3, s2);
-  if (g.nch < 2 || g.nch > 3) return false;
+  if (g.nch < 1 || g.nch > 3) return false;
   if (e1 + e3 + s2 > 768 + 96) return false;   // (the ring depth is chosen for at most this many biases)
   return chain_lds_bytes(g.nch, g.nsq, chain_ring(g.nch, g.nsq), e1 + e3 + s2) <= 160 * 1024;
 }
@@ -610,6 +621,7 @@ extern "C" int sqdet_fire_chain_fwd(const void* sq_in, const void* stream_buf, c
   a.out_bytes = (unsigned)(px * next_s1x1 * 2);
   a.y_bytes = (unsigned)(px * (e1x1 + e3x3) * 2);
   hipStream_t st = as_stream(stream);
+  if (g.nch == 1) return y ? dispatch_chain_nsq<1, true>(a, g.nsq, st) : dispatch_chain_nsq<1, false>(a, g.nsq, st);
   if (g.nch == 2) return y ? dispatch_chain_nsq<2, true>(a, g.nsq, st) : dispatch_chain_nsq<2, false>(a, g.nsq, st);
   return y ? dispatch_chain_nsq<3, true>(a, g.nsq, st) : dispatch_chain_nsq<3, false>(a, g.nsq, st);
 }

@@ -444,7 +444,10 @@ def test_fused_stem_conv_pool_parity(case, dtype):
 # of the last workgroup's pair does not exist); next_S = 0: expand only (fire11: the concat tensor is the output)
 CHAIN_CASES = [("fire6-7", 48, 192, 48, 24, 78, 2), ("fire7-8", 48, 192, 64, 11, 19, 3), ("fire8-9", 64, 256, 64, 24, 78, 1),
                ("fire9-10", 64, 256, 96, 9, 31, 2), ("fire10-11", 96, 384, 96, 24, 78, 3), ("fire11", 96, 384, 0, 24, 78, 2),
-               ("fire11-ragged", 96, 384, 0, 13, 21, 5), ("fire7-only", 48, 192, 0, 8, 16, 1), ("one-pixel", 64, 256, 64, 1, 1, 1)]
+               ("fire11-ragged", 96, 384, 0, 13, 21, 5), ("fire7-only", 48, 192, 0, 8, 16, 1), ("one-pixel", 64, 256, 64, 1, 1, 1),
+               # the large early maps (one-chunk squeezes): fire2 -> 3, fire4 -> 5, fire5 -> (pool) fire6's width, expand only
+               ("fire2-3", 16, 64, 16, 47, 83, 2), ("fire4-5", 32, 128, 32, 23, 40, 3), ("fire5-w48", 32, 128, 48, 9, 17, 1),
+               ("fire3-only", 16, 64, 0, 19, 33, 1)]
 
 
 @pytest.mark.parametrize("want_y", [False, True])

@@ -83,6 +83,20 @@ def main():
         tot[1] += t_chain
         tot[2] += t_sq if i == 0 else 0.0
     print("sum fused %.4f ms; chain %.4f ms (+ first squeeze %.4f ms)" % tuple(tot))
+    # the early maps: fire2 -> fire3's squeeze at 94x311, fire4 -> fire5's squeeze at 47x156
+    print("%-8s %10s %10s %10s %10s" % ("module", "fused_ms", "squeeze_ms", "chain_ms", "chain+y"))
+    for name, cin, s, e, s2, h, w in (("fire2", 64, 16, 64, 16, 94, 311), ("fire4", 128, 32, 128, 32, 47, 156)):
+        x = torch.randn((args.batch, h, w, cin), generator=g).clamp_(min=0).to(dev, dt)
+        ws, w1, w3, wn = mkw(1, cin, s), mkw(1, s, e), mkw(3, s, e), mkw(1, 2 * e, s2)
+        ps, p1, p3 = [ops.pack_conv_weights(w_, dt) for w_ in (ws, w1, w3)]
+        bz = [torch.zeros(n_, device=dev) for n_ in (s, e, e, s2)]
+        t_fused = timeit(lambda: ops.fire(x, ps, bz[0], p1, bz[1], p3, bz[2]), args.iters)
+        sq = torch.empty((args.batch, h, w, s), dtype=dt, device=dev)
+        t_sq = timeit(lambda: ops.conv2d_nhwc(x, ps, bz[0], 1, "SAME", True, out=sq), args.iters)
+        chain = ops.FireChainStream(w1, w3, wn, dt)
+        t_chain = timeit(lambda: ops.fire_chain(sq, chain, bz[1], bz[2], bz[3]), args.iters)
+        t_cy = timeit(lambda: ops.fire_chain(sq, chain, bz[1], bz[2], bz[3], want_y=True), args.iters)
+        print("%-8s %10.4f %10.4f %10.4f %10.4f" % (name, t_fused, t_sq, t_chain, t_cy))
 
 
 if __name__ == "__main__":
