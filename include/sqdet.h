@@ -44,7 +44,8 @@ const char* sqdet_last_error(void);
 /* Tuning knobs (process-wide).  "conv_algo": 0 = auto (specialised kernels when eligible,
  * default), 1 = generic implicit-GEMM kernels only (also env SQDET_CONV_ALGO=generic).
  * "fire_fuse": 0 = plan heuristic (default), 1 = one launch per fire module wherever the kernels cover it, 2 = never
- * fuse, 3 = no streaming kernel, 4 = fire modules and the pools behind them stay apart, 5 = no fire-module chains. */
+ * fuse, 3 = no streaming kernel, 4 = fire modules and the pools behind them stay apart, 5 = no fire-module chains, 6 = chains on
+ * the late (small) maps only. */
 int sqdet_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------ conv --
@@ -133,6 +134,15 @@ int sqdet_fire_fwd(const void* x, const void* w_s, const float* b_s, const void*
 int sqdet_fire_maxpool_fwd(const void* x, const void* w_s, const float* b_s, const void* w_e1, const float* b_e1,
                            const void* w_e3, const float* b_e3, void* sq_scratch, void* fire_scratch, void* y,
                            int n, int h, int w, int cin, int s1x1, int e1x1, int e3x3, int dtype, sqdet_stream_t stream);
+
+/* The expand half of a fire module from its squeeze tensor sq_in [n,h,w,s1x1] (produced by a chain launch, below):
+ *   y = concat(relu(conv1x1(sq_in, W_e1) + b_e1), relu(conv3x3(sq_in, W_e3) + b_e3))     (nets/squeezeDet.py:92-106),
+ * pool != 0: followed by max_pool 3x3 / stride 2 / SAME (fire3 -> pool3, fire5 -> pool5: nets/squeezeDet.py:49-57) taken
+ * in registers -- y is then the pooled tensor [n, ceil(h/2), ceil(w/2), e1x1+e3x3] (float16 shapes of the streaming
+ * kernel only).  w_e1 / w_e3: packed by sqdet_conv_pack_weights.  Bitwise sqdet_fire_fwd / sqdet_fire_maxpool_fwd. */
+int sqdet_fire_expand_fwd(const void* sq_in, const void* w_e1, const float* b_e1, const void* w_e3, const float* b_e3,
+                          void* y, int n, int h, int w, int s1x1, int e1x1, int e3x3, int pool, int dtype,
+                          sqdet_stream_t stream);
 
 /* Fire-module CHAIN (float16): the expand half of one fire module and the squeeze of the NEXT module in one launch.
  * Replaces, for consecutive fire modules on one feature map (fire6 .. fire11, nets/squeezeDet.py:58-69), the pair

@@ -33,6 +33,7 @@ SIGNATURES = {
     "sqdet_stem_conv_pool_fwd": (ci, [vp, vp, vp, vp] + [ci] * 8 + [vp]),
     "sqdet_fire_fwd": (ci, [vp] * 9 + [ci] * 8 + [vp]),
     "sqdet_fire_maxpool_fwd": (ci, [vp] * 10 + [ci] * 8 + [vp]),
+    "sqdet_fire_expand_fwd": (ci, [vp] * 6 + [ci] * 8 + [vp]),
     "sqdet_fire_chain_stream_bytes": (sz, [ci] * 5),
     "sqdet_fire_chain_pack": (ci, [vp] * 4 + [ci] * 5 + [vp]),
     "sqdet_fire_chain_fwd": (ci, [vp] * 7 + [ci] * 8 + [vp]),

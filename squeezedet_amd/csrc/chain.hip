@@ -493,6 +493,262 @@ __global__ void chain_pack_kernel(const float* __restrict__ w1, const float* __r
   }
 }
 
+// =====================================================================================================================
+// Persistent form for the LARGE maps with one-chunk squeezes (fire2 .. fire5 of SqueezeDet: 94x311 / 47x156, squeeze 16 / 32,
+// expand 64 / 128).  There a 256-pixel workgroup has ~100 MFMAs per wave to do: the ring kernel above spends its time
+// filling the ring and passing barriers (measured: no faster than the streaming fused fire).  Here the weights -- 44-104
+// KiB -- are RESIDENT in LDS (copied once per workgroup from the same packed stream), the workgroups are persistent
+// (one per CU) and walk the map four 8x16 tiles at a time: wave w owns tile slot w>>1, rows 4*(w&1)..+4, and -- since
+// nothing is shared but the weights -- ALL couts of its 64 pixels, so the chained squeeze needs no exchange.  The next
+// four tiles' squeeze halos (46 KiB) are prefetched into registers while the current ones are computed; two barriers
+// per four tiles.  Accumulation orders are the ring kernel's (canonical): bitwise the separate convs.
+struct ChainSArgs {
+  const void* sq_in;
+  void* sq_out;
+  const unsigned char* stream;
+  const float *b1, *b3, *bs2;
+  int N, H, W, S, E1, E3, S2;
+  int tiles_x, tiles_y, ntiles, nquads;
+  int nb1, nb3;
+  unsigned in_bytes;
+};
+
+constexpr int CS_TILES = 4;                                   // tiles per workgroup step
+// LDS row pitch of a squeeze tile: 24 pixels, not 18 (as in fire2.hip): with a pitch that is a multiple of 8 the swizzle
+// term ((pixel >> 1) & 3) of a fragment read does not depend on the row, so the reads of one column shift share ONE
+// address register + immediate row offsets
+constexpr int CS_LW = 24;
+constexpr int CS_TILE_B = (CROWS + 2) * CS_LW * 64;           // bytes of one tile slot (15360)
+
+template <int NSQ>
+__global__ __launch_bounds__(512, 2) void fire_chain_stream(ChainSArgs a) {
+  using T = f16;
+  constexpr int F1 = 4 + 2 * NSQ;                             // resident fragments per expand1x1 block (+ its chain)
+  constexpr int F3 = 36 + 2 * NSQ;                            // ... per expand3x3 block
+  constexpr int NP = 4;                                       // 16-byte pieces per pixel of the (zero padded) chunk
+  constexpr int SIT = (CHP * NP + 127) / 128;                 // pieces per thread per step: a tile slot is fetched by its two waves
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int j = lane & 15, g = lane >> 4;
+  const int nfrag = a.nb1 * F1 + a.nb3 * F3;
+  unsigned char* wres = lds;                                  // [fragment][64 lanes][16 B]
+  unsigned char* stile = lds + (size_t)nfrag * 1024;          // [tile slot][halo row][24 pixels][4 x 16 B swizzled]
+  float* bl = reinterpret_cast<float*>(stile + CS_TILES * CS_TILE_B);
+
+  // ---- one-time: weights (the valid fragments of the packed stream's stages) and biases -> LDS
+  {
+    const int base3s = a.nb1 * 2;                             // stream stage of the first expand3x3 block (NCH = 1)
+    for (int f = wave; f < nfrag; f += 8) {
+      int stage, fs;
+      if (f < a.nb1 * F1) {
+        const int blk = f / F1, r = f - blk * F1;
+        stage = blk * 2 + (r < 4 ? 0 : 1);
+        fs = r < 4 ? r : r - 4;
+      } else {
+        const int f2 = f - a.nb1 * F1;
+        const int blk = f2 / F3, r = f2 - blk * F3;
+        stage = base3s + blk * 4 + (r < 36 ? r / 12 : 3);
+        fs = r < 36 ? r % 12 : r - 36;
+      }
+      reinterpret_cast<i32x4*>(wres)[(size_t)f * 64 + lane] =
+          reinterpret_cast<const i32x4*>(a.stream + (size_t)stage * STAGE_B)[fs * 64 + lane];
+    }
+    const int nbias = a.E1 + a.E3 + a.S2;
+    for (int i = threadIdx.x; i < nbias; i += 512)
+      bl[i] = i < a.E1 ? a.b1[i] : (i < a.E1 + a.E3 ? a.b3[i - a.E1] : a.bs2[i - a.E1 - a.E3]);
+  }
+
+  // every XCD owns a contiguous band of tile quads (halo re-reads stay in one L2)
+  const int xcd = blockIdx.x & 7, lid = blockIdx.x >> 3, nl = gridDim.x >> 3;   // gridDim.x is a multiple of 8
+  const int per = (a.nquads + 7) >> 3;
+  const int band_end = min(a.nquads, (xcd + 1) * per);
+  int quad = xcd * per + lid;
+
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.sq_in), 0, a.in_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xfffffff0u;
+  const int s_pieces = a.S * 2 / 16;
+  const int ts = wave >> 1, r0 = (wave & 1) * 4;              // this wave's tile slot and first tile row
+  const int tl = (int)(threadIdx.x & 127);                    // index among the two waves of the slot
+  i32x4 sv[SIT];
+  auto prefetch = [&](int q) {       // this slot's squeeze halo of quad q -> registers (out of range = the zero padding)
+    int t = q * CS_TILES + ts;       // (wave-uniform tile decode)
+    const bool tile_ok = q < band_end && t < a.ntiles;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int pix0 = (n * a.H + ty * CROWS - 1) * a.W + tx * CCOLS - 1;
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+      const int idx = it * 128 + tl;
+      const int P = idx / NP, pc = idx - P * NP;
+      const int r = P / (CCOLS + 2), c = P - r * (CCOLS + 2);
+      const int iy = ty * CROWS - 1 + r, ix = tx * CCOLS - 1 + c;
+      const bool ok = tile_ok && idx < CHP * NP && pc < s_pieces && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const unsigned off = ok ? (unsigned)(((pix0 + r * a.W + c) * a.S) * 2 + pc * 16) : OOB;
+      sv[it] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
+    }
+  };
+  prefetch(quad);
+
+  unsigned char* simg = stile + ts * CS_TILE_B;
+  // B fragment (halo row r0 + rr, column shift dx): the swizzle term depends on the column only (pitch 24)
+  const unsigned char* bbase[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    const int P0 = r0 * CS_LW + j + dx;
+    bbase[dx] = simg + P0 * 64 + ((g ^ ((P0 >> 1) & 3)) << 4);
+  }
+  auto load_b = [&](int rr, int dx) { return *reinterpret_cast<const i32x4*>(bbase[dx] + rr * (CS_LW * 64)); };
+  auto wfrag = [&](int f) { return *reinterpret_cast<const i32x4*>(wres + (size_t)f * 1024 + lane * 16); };
+  T* so = reinterpret_cast<T*>(a.sq_out);
+
+  for (; quad < band_end; quad += nl) {
+    // ---- the prefetched halo -> this slot's LDS tile
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+      const int idx = it * 128 + tl;
+      const int P = idx / NP, pc = idx - P * NP;
+      const int r = P / (CCOLS + 2), c = P - r * (CCOLS + 2);
+      const int PL = r * CS_LW + c;
+      if (idx < CHP * NP) *reinterpret_cast<i32x4*>(simg + PL * 64 + ((pc ^ ((PL >> 1) & 3)) << 4)) = sv[it];
+    }
+    __syncthreads();
+    prefetch(quad + nl);              // lands while this quad is computed
+    int t = quad * CS_TILES + ts;
+    const bool tile_ok = t < a.ntiles;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int n_img = t / a.tiles_y;
+    const int oy0 = ty * CROWS, ox = tx * CCOLS + j;
+    const bool col_ok = tile_ok && ox < a.W;
+
+    f32x4 accs[NSQ][4];
+#pragma unroll
+    for (int tq = 0; tq < NSQ; ++tq)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) accs[tq][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias + ReLU + float16 rounding of a 64-cout block; its two 32-cout pairs are two K chunks of the next squeeze
+    auto finish_block = [&](f32x4 (&acc)[4][4], int cc0, int fchain) {
+      i32x4 bf[4][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const f32x4 bias0 = *reinterpret_cast<const f32x4*>(bl + cc0 + p * 32 + g * 8);
+        const f32x4 bias1 = *reinterpret_cast<const f32x4*>(bl + cc0 + p * 32 + g * 8 + 4);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) bf[m][p] = pack8(relu4(acc[m][2 * p] + bias0), relu4(acc[m][2 * p + 1] + bias1));
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int tq = 0; tq < NSQ; ++tq) {
+          const i32x4 fr = wfrag(fchain + u * NSQ + tq);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) mma16<T>(accs[tq][m], fr, bf[m][u]);
+        }
+    };
+    // ---- expand1x1 blocks (centre tap)
+    {
+      i32x4 b1f[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) b1f[m] = load_b(m + 1, 1);
+#pragma unroll 1
+      for (int blk = 0; blk < a.nb1; ++blk) {
+        f32x4 acc[4][4];
+        i32x4 af[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) af[tt] = wfrag(blk * F1 + tt);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) {
+            acc[m][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma16<T>(acc[m][tt], af[tt], b1f[m]);
+          }
+        finish_block(acc, blk * 64, blk * F1 + 4);
+      }
+    }
+    // ---- expand3x3 blocks
+#pragma unroll 1
+    for (int blk = 0; blk < a.nb3; ++blk) {
+      f32x4 acc[4][4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) acc[m][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int f0 = a.nb1 * F1 + blk * F3;
+      // nine taps, the next tap's eight LDS fragments requested before the current tap's 16 MFMAs (two register sets;
+      // the scheduling barriers keep hipcc from hoisting every tap's reads to the top, which spilled)
+      i32x4 Bc[4], ac[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) Bc[m] = load_b(m, 0);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) ac[tt] = wfrag(f0 + tt);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        i32x4 Bn[4], an[4];
+        if (tap + 1 < 9) {
+          const int dy = (tap + 1) / 3, dx = (tap + 1) % 3;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) Bn[m] = load_b(m + dy, dx);
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) an[tt] = wfrag(f0 + (tap + 1) * 4 + tt);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) mma16<T>(acc[m][tt], ac[tt], Bc[m]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap + 1 < 9) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) Bc[m] = Bn[m];
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) ac[tt] = an[tt];
+        }
+      }
+      finish_block(acc, a.E1 + blk * 64, f0 + 36);
+    }
+    // ---- next squeeze: bias + ReLU -> sq_out
+    {
+      const float* bs = bl + a.E1 + a.E3;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int oy = oy0 + r0 + m;
+        if (col_ok && oy < a.H) {
+          T* dst = so + ((size_t)(n_img * a.H + oy) * a.W + ox) * a.S2 + g * 4 * NSQ;
+#pragma unroll
+          for (int tq = 0; tq < NSQ; ++tq) {
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(bs + g * 4 * NSQ + tq * 4);
+            store4<T>(dst + tq * 4, relu4(accs[tq][m] + bias));
+          }
+        }
+      }
+    }
+    __syncthreads();                  // every wave is done with the squeeze tiles before they are overwritten
+  }
+}
+
+bool fire_chain_stream_shape(int s, int e1, int e3, int s2) {
+  return s > 0 && s <= 32 && s % 8 == 0 && e1 % 64 == 0 && e3 % 64 == 0 && e1 > 0 && e3 > 0 && (s2 == 16 || s2 == 32 || s2 == 48) &&
+         (size_t)((e1 / 64) * (4 + s2 / 8) + (e3 / 64) * (36 + s2 / 8)) * 1024 + CS_TILES * CS_TILE_B + (size_t)(e1 + e3 + s2) * 4 <= 160 * 1024;
+}
+
+template <int NSQ>
+int launch_chain_stream(const ChainSArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)(a.nb1 * (4 + 2 * NSQ) + a.nb3 * (36 + 2 * NSQ)) * 1024 + CS_TILES * CS_TILE_B + (size_t)(a.E1 + a.E3 + a.S2) * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    SQDET_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_chain_stream<NSQ>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  int grid = 256;                                           // one persistent workgroup per CU
+  if (grid > (a.nquads + 7) / 8 * 8) grid = (a.nquads + 7) / 8 * 8;
+  hipLaunchKernelGGL((fire_chain_stream<NSQ>), dim3((unsigned)grid), dim3(512), lds, st, a);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
 constexpr size_t chain_lds_bytes(int nch, int nsq, int ring, int nbias) {
   return (size_t)ring * STAGE_B + (size_t)NIMG * nch * CCHUNK + (nsq > 0 ? 32768 : 0) + (size_t)nbias * 4;
 }
@@ -621,6 +877,23 @@ extern "C" int sqdet_fire_chain_fwd(const void* sq_in, const void* stream_buf, c
   a.out_bytes = (unsigned)(px * next_s1x1 * 2);
   a.y_bytes = (unsigned)(px * (e1x1 + e3x3) * 2);
   hipStream_t st = as_stream(stream);
+  // large maps with a one-chunk squeeze: the persistent, weights-resident form ("dbg" 30 keeps the ring kernel for
+  // A/B, 31 takes the persistent form at any size -- tests)
+  if (!y && g.nch == 1 && (px > 100000 || tune(TUNE_DBG) == 31) && fire_chain_stream_shape(s1x1, e1x1, e3x3, next_s1x1) && tune(TUNE_DBG) != 30) {
+    ChainSArgs c;
+    c.sq_in = sq_in; c.sq_out = sq_out; c.stream = a.stream; c.b1 = b_e1; c.b3 = b_e3; c.bs2 = b_next_s;
+    c.N = n; c.H = h; c.W = w; c.S = s1x1; c.E1 = e1x1; c.E3 = e3x3; c.S2 = next_s1x1;
+    c.tiles_x = a.tiles_x; c.tiles_y = a.tiles_y;
+    const long nt = (long)n * a.tiles_x * a.tiles_y;
+    c.ntiles = (int)nt; c.nquads = (int)((nt + CS_TILES - 1) / CS_TILES);
+    c.nb1 = g.nb1; c.nb3 = g.nb3; c.in_bytes = a.in_bytes;
+    switch (g.nsq) {
+      case 1: return launch_chain_stream<1>(c, st);
+      case 2: return launch_chain_stream<2>(c, st);
+      case 3: return launch_chain_stream<3>(c, st);
+      default: break;
+    }
+  }
   if (g.nch == 1) return y ? dispatch_chain_nsq<1, true>(a, g.nsq, st) : dispatch_chain_nsq<1, false>(a, g.nsq, st);
   if (g.nch == 2) return y ? dispatch_chain_nsq<2, true>(a, g.nsq, st) : dispatch_chain_nsq<2, false>(a, g.nsq, st);
   return y ? dispatch_chain_nsq<3, true>(a, g.nsq, st) : dispatch_chain_nsq<3, false>(a, g.nsq, st);

@@ -93,6 +93,10 @@ int fire_stream_launch(const void* x, const void* ws, const float* bs, const voi
 int fire_stream_launch_ex(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
                           const float* b3, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
                           int pool, hipStream_t st, bool* handled);
+// the expand half of a fire module from its squeeze tensor (+ the 3x3/s2 SAME max-pool behind it when pool != 0)
+bool fire_expand_stream_eligible(int s, int e1, int e3, int dtype);
+int fire_expand_stream_launch(const void* sq_in, const void* w1, const float* b1, const void* w3, const float* b3, void* y,
+                              int n, int h, int w, int s, int e1, int e3, int dtype, int pool, hipStream_t st, bool* handled);
 int conv3x3_tile_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);
 int conv1x1_stream_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);
 

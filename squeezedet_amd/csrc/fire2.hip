@@ -92,7 +92,11 @@ struct FireSArgs {
 // the 3x3 takes 5 K-steps instead of 9 half-empty ones, 25 instead of 45 B-fragment reads, and its resident weights
 // 40 instead of 72 registers.  (The two taps' products are then summed inside one MFMA instead of two: equal to the
 // three-conv path up to float32 summation order, no longer bitwise.)
-template <typename T, int NCHX, int NTS, int NWAVES, int PF, bool POOL, int RS, bool PAIR = false>
+// SQIN: `x` IS the module's squeeze tensor [N,H,W,S] (produced by the chain kernel of the previous module, chain.hip):
+// phase A is a copy -- the prefetched 16-byte pieces go straight into the LDS squeeze tile (out-of-image pieces and the
+// channel padding arrive as zeros: exactly the SAME padding of the squeeze tensor) -- and the module reads 32-64 bytes
+// per pixel instead of 128-256 (NCHX = 1, NTS unused).
+template <typename T, int NCHX, int NTS, int NWAVES, int PF, bool POOL, int RS, bool PAIR = false, bool SQIN = false>
 __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs a) {   // 2 waves per SIMD: 256 VGPRs
   constexpr int KG = Tr<T>::KG;
   constexpr int NT3 = PAIR ? 5 : 9;                  // K-steps of the expand3x3
@@ -113,14 +117,16 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
 
   // ---- one-time set-up ------------------------------------------------------------------------
   {
-    const i32x4* src = reinterpret_cast<const i32x4*>(a.ws);
-    for (int i = threadIdx.x; i < NCHX * NTS * 64; i += NWAVES * 64) reinterpret_cast<i32x4*>(wsl)[i] = src[i];
+    if constexpr (!SQIN) {
+      const i32x4* src = reinterpret_cast<const i32x4*>(a.ws);
+      for (int i = threadIdx.x; i < NCHX * NTS * 64; i += NWAVES * 64) reinterpret_cast<i32x4*>(wsl)[i] = src[i];
+    }
     const i32x4* src1 = reinterpret_cast<const i32x4*>(a.w1);
     for (int i = threadIdx.x; i < NG * 4 * 64; i += NWAVES * 64) reinterpret_cast<i32x4*>(w1l)[i] = src1[i];
     // biases -> LDS [b1 (E) | b3 (E) | bs (S)]: read back with ds_read (lgkmcnt).  A global bias load inside
     // the tile loop would sit behind the prefetched input loads and the stores in the in-order vmcnt queue
     // and drain them every time it is waited for.
-    for (int i = threadIdx.x; i < 2 * a.E + a.S; i += NWAVES * 64)
+    for (int i = threadIdx.x; i < 2 * a.E + (SQIN ? 0 : a.S); i += NWAVES * 64)
       bl[i] = i < a.E ? a.b1[i] : (i < 2 * a.E ? a.b3[i - a.E] : a.bs[i - 2 * a.E]);
     // channel padding of the squeeze tile (S*sizeof(T) < 64 bytes) is zero in both buffers, forever
     const int s_pieces = a.S * (int)sizeof(T) / 16;
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
       const int iy = hy0 + r, ix = hx0 + c;
       inimg[mb] = allin || (tile_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W);
       const unsigned base = (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + g * KG) * (int)sizeof(T));
-      offs[mb] = (inimg[mb] && P < SHP) ? base : OOBL;
+      offs[mb] = (inimg[mb] && P < SHP && (!SQIN || g * KG < a.Cin)) ? base : OOBL;
     }
   };
   auto issue_loads = [&](int first, int last, i32x4 (&xq)[MB][NCHX]) {   // (Cin fills whole 64-byte chunks: stream_shape)
@@ -237,7 +243,19 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
     // the whole halo inside the image (3 tiles out of 4): no SAME-padding select on the squeeze tile
     const bool haloin = oy0 >= 1 && oy0 + Geo<POOL>::ROWS + 1 <= a.H && ox0 >= 1 && ox0 + SCOLS + 1 <= a.W;
     // ---------------- phase A: squeeze on the halo, from the prefetched fragments ----------------
-    {
+    if constexpr (SQIN) {
+      // the prefetched pieces ARE the squeeze tile: lane (j, g) holds piece g of halo pixel P
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int P = (wave + NWAVES * mb) * 16 + j;
+        if (P < SHP) {
+          const int hr = P / (SCOLS + 2);
+          const int PL = hr * LW + (P - hr * (SCOLS + 2));
+          *reinterpret_cast<i32x4*>(sqb + PL * 64 + ((g ^ ((PL >> 1) & 3)) << 4)) = xq[mb][0];
+        }
+      }
+      FT_MARK(0);
+    } else {
       f32x4 acc[MB][NTS];
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
@@ -498,7 +516,7 @@ bool fire_stream_eligible(int cin, int s, int e1, int e3, int dtype) {
   return stream_shape(cin, s, e1, e3, dtype, &a, &b, &c);
 }
 
-template <typename T, int NCHX, int NTS, int NWAVES, bool POOL, int RS>
+template <typename T, int NCHX, int NTS, int NWAVES, bool POOL, int RS, bool SQIN = false>
 static void launch_stream(const FireSArgs& a, hipStream_t st) {
   const size_t lds = 2 * (size_t)Geo<POOL>::TILE + (size_t)NCHX * NTS * 1024 + (size_t)(NWAVES / RS / 2) * 4 * 1024 + (size_t)(2 * a.E + a.S) * 4;
   // persistent: 8 waves per CU (the register-resident weights + prefetched input allow 2 per SIMD)
@@ -511,21 +529,21 @@ static void launch_stream(const FireSArgs& a, hipStream_t st) {
     if (a.S * (int)sizeof(T) == 32 && tune(TUNE_DBG) != 16) {
       if constexpr (2 * MBH * NCHX <= 16) {
         if (tune(TUNE_DBG) != 8) {
-          hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 2, POOL, RS, true>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
+          hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 2, POOL, RS, true, SQIN>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
           return;
         }
       }
-      hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 1, POOL, RS, true>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
+      hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 1, POOL, RS, true, SQIN>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
       return;
     }
   }
   if constexpr (2 * MBH * NCHX <= 16) {   // (these compile without spills; a spill in the tile loop drains vmcnt)
     if (tune(TUNE_DBG) != 8) {
-      hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 2, POOL, RS>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
+      hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 2, POOL, RS, false, SQIN>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
       return;
     }
   }
-  hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 1, POOL, RS>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
+  hipLaunchKernelGGL((fire_stream<T, NCHX, NTS, NWAVES, 1, POOL, RS, false, SQIN>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
 }
 
 template <typename T, bool POOL>
@@ -584,6 +602,47 @@ int fire_stream_launch_ex(const void* x, const void* ws, const float* bs, const 
   if (pool) ok = dtype == SQDET_F16 ? dispatch_stream<f16, true>(a, nchx, nts, nwaves, st) : dispatch_stream<float, true>(a, nchx, nts, nwaves, st);
   else ok = dtype == SQDET_F16 ? dispatch_stream<f16, false>(a, nchx, nts, nwaves, st) : dispatch_stream<float, false>(a, nchx, nts, nwaves, st);
   if (!ok) return SQDET_OK;
+  SQDET_CHECK_HIP(hipGetLastError());
+  *handled = true;
+  return SQDET_OK;
+}
+
+// ---- the expand half of a fire module from its SQUEEZE tensor (float16; the chain kernels of chain.hip produce it) ----
+bool fire_expand_stream_eligible(int s, int e1, int e3, int dtype) {
+  if (conv_algo() != 0 || e1 != e3 || dtype != SQDET_F16) return false;
+  const ConvGeom g1 = conv_geom(1, s, e1, dtype), g3 = conv_geom(3, s, e3, dtype);
+  if (g1.gather || g3.gather || g1.nchunk != 1 || g3.nchunk != 1 || g1.nt != 4 || g3.nt != 4) return false;
+  if (e1 % 64 != 0 || (g1.ngroups != 1 && g1.ngroups != 2)) return false;
+  return (s * 2) % 16 == 0 && s % 4 == 0;
+}
+
+// y = concat(relu(conv1x1(sq_in)), relu(conv3x3(sq_in))), or its 3x3/s2 SAME max-pool when pool != 0
+int fire_expand_stream_launch(const void* sq_in, const void* w1, const float* b1, const void* w3, const float* b3, void* y,
+                              int n, int h, int w, int s, int e1, int e3, int dtype, int pool, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (!fire_expand_stream_eligible(s, e1, e3, dtype)) return SQDET_OK;
+  FireSArgs a;
+  a.x = sq_in; a.y = y; a.ws = nullptr; a.w1 = w1; a.w3 = w3; a.bs = nullptr; a.b1 = b1; a.b3 = b3;
+  a.N = n; a.H = h; a.W = w; a.Cin = s; a.S = s; a.E = e1;
+  a.Hp = out_size(h, 3, 2, SQDET_PAD_SAME); a.Wp = out_size(w, 3, 2, SQDET_PAD_SAME);
+  a.ptp = pad_before(h, 3, 2, SQDET_PAD_SAME); a.plp = pad_before(w, 3, 2, SQDET_PAD_SAME);
+  if (pool) { a.tiles_x = (a.Wp + 6) / 7; a.tiles_y = (a.Hp + 3) / 4; }
+  else { a.tiles_x = (w + SCOLS - 1) / SCOLS; a.tiles_y = (h + 7) / 8; }
+  const long nt = (long)n * a.tiles_x * a.tiles_y;
+  if (nt > 0x3fffffffL) return SQDET_OK;
+  a.ntiles = (int)nt;
+  a.x_pieces = s * 2 / 16;
+  const long xb = (long)n * h * w * s * 2, yb = pool ? (long)n * a.Hp * a.Wp * 2 * e1 * 2 : (long)n * h * w * 2 * e1 * 2;
+  if (xb >= (1L << 31) || yb >= (1L << 31)) return SQDET_OK;
+  a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb;
+  const int nwaves = 4 * (e1 / 64);
+  if (pool) {
+    if (nwaves == 4) launch_stream<f16, 1, 1, 4, true, 2, true>(a, st);
+    else launch_stream<f16, 1, 1, 8, true, 2, true>(a, st);
+  } else {
+    if (nwaves == 4) launch_stream<f16, 1, 1, 4, false, 2, true>(a, st);
+    else launch_stream<f16, 1, 1, 8, false, 2, true>(a, st);
+  }
   SQDET_CHECK_HIP(hipGetLastError());
   *handled = true;
   return SQDET_OK;

@@ -32,6 +32,9 @@ int fire_stream_launch_ex(const void* x, const void* ws, const float* bs, const 
                           const float* b3, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
                           int pool, hipStream_t st, bool* handled);
 bool fire_chain_eligible(int s, int e1, int e3, int s2, int dtype);
+bool fire_expand_stream_eligible(int s, int e1, int e3, int dtype);
+int fire_expand_stream_launch(const void* sq_in, const void* w1, const float* b1, const void* w3, const float* b3, void* y,
+                              int n, int h, int w, int s, int e1, int e3, int dtype, int pool, hipStream_t st, bool* handled);
 int conv_algo();
 int tune(int which);
 }  // namespace sqdet
@@ -43,7 +46,8 @@ namespace {
 enum { BUF_INPUT = -1, BUF_PREDS = -2, BUF_A = 0, BUF_B = 1, BUF_S = 2, BUF_T = 3, NUM_BUFS = 4 };
 // L_STEM: conv(k, s2, Cin 3)+relu+maxpool(3, s2) in one launch; L_FIRE: squeeze + both expands in one launch;
 // L_CHAIN: both expands of a fire module + the squeeze of the NEXT module in one launch (sqdet_fire_chain_fwd)
-enum { L_CONV = 0, L_POOL = 1, L_STEM = 2, L_FIRE = 3, L_CHAIN = 4 };
+// L_EXPAND: both expands of a fire module from its squeeze tensor (+ the max-pool behind it): sqdet_fire_expand_fwd
+enum { L_CONV = 0, L_POOL = 1, L_STEM = 2, L_FIRE = 3, L_CHAIN = 4, L_EXPAND = 5 };
 
 struct Param {
   std::string name;
@@ -286,6 +290,14 @@ int run_layer_part(sqdet_net* net, const Layer& L, const void* input, void* pred
                                 L.fs2 > 0 ? nullptr : out, L.fs2 > 0 ? out : nullptr, nb, L.h, L.w, L.fs, L.fe1, L.fe3, L.fs2,
                                 net->dtype, reinterpret_cast<sqdet_stream_t>(st));
   }
+  if (L.type == L_EXPAND) {
+    const char* sq_in = reinterpret_cast<const char*>(buf_ptr(net, L.in_buf, input, preds)) + (size_t)n0 * L.h * L.w * L.fs * esz;
+    char* out = reinterpret_cast<char*>(buf_ptr(net, L.out_buf, input, preds)) + (size_t)n0 * L.ho * L.wo * (L.fe1 + L.fe3) * esz;
+    auto pk = [&](int i) { return (const void*)(net->param_mem + net->params[i].offset); };
+    auto pb = [&](int i) { return reinterpret_cast<const float*>(net->param_mem + net->params[i].offset); };
+    return sqdet_fire_expand_fwd(sq_in, pk(L.kp_1), pb(L.bp_1), pk(L.kp_3), pb(L.bp_3), out, nb, L.h, L.w, L.fs, L.fe1, L.fe3,
+                                 L.fire_pool, net->dtype, reinterpret_cast<sqdet_stream_t>(st));
+  }
   const int in_c = L.type == L_STEM ? 3 : L.cin;
   const void* x = reinterpret_cast<const char*>(buf_ptr(net, L.in_buf, input, preds)) + (size_t)n0 * L.h * L.w * in_c * esz;
   void* y = reinterpret_cast<char*>(buf_ptr(net, L.out_buf, input, preds)) +
@@ -423,11 +435,12 @@ void fuse_fire_pools(sqdet_net* net, size_t esz) {
   }
 }
 
-// Runs of fire modules on ONE feature map (SqueezeDet's fire6 .. fire11, nets/squeezeDet.py:58-69): the only reader of
-// a module's concat tensor is the next module's squeeze1x1, so the run becomes
+// Runs of fire modules on ONE feature map (SqueezeDet: fire2-3, fire4-5, fire6 .. fire11; nets/squeezeDet.py:46-69): the
+// only reader of a module's concat tensor is the next module's squeeze1x1, so a run becomes
 //   squeeze1x1 of the first module  ->  [expand of module i + squeeze of module i+1] ...  ->  expand of the last module
-// and only 48-96-channel squeeze tensors travel between the launches (sqdet_fire_chain_fwd; float16).  "fire_fuse" = 5
-// keeps the one-launch-per-module form.
+// and only 16-96-channel squeeze tensors travel between the launches (sqdet_fire_chain_fwd; float16).  The last module
+// keeps its pool when it has one (fire3+pool3, fire5+pool5: sqdet_fire_expand_fwd from the squeeze tensor).
+// "fire_fuse" = 5 keeps the one-launch-per-module form, 6 chains the late (<= 100000 pixel) maps only.
 void fuse_chains(sqdet_net* net, size_t esz) {
   if (conv_algo() != 0 || tune(3) == 2 || tune(3) == 5) return;
   const std::vector<Layer> in = net->layers;
@@ -435,19 +448,24 @@ void fuse_chains(sqdet_net* net, size_t esz) {
   for (size_t i = 0; i < in.size();) {
     size_t j = i;
     auto chainable = [&](size_t k) {
-      return k < in.size() && in[k].type == L_FIRE && !in[k].fire_pool && in[k].h == in[i].h && in[k].w == in[i].w &&
-             (long)net->batch * in[k].h * in[k].w <= 100000 && (k == i || in[k].in_buf == in[k - 1].out_buf);
+      return k < in.size() && in[k].type == L_FIRE && in[k].h == in[i].h && in[k].w == in[i].w &&
+             (tune(3) != 6 || (long)net->batch * in[k].h * in[k].w <= 100000) && (k == i || (in[k].in_buf == in[k - 1].out_buf && !in[k - 1].fire_pool));
     };
     while (chainable(j)) ++j;
-    // every member must be covered with its successor's squeeze (the last one with none)
+    // every member must be covered with its successor's squeeze; the last one by the expand-only chain form, or -- with
+    // a pool behind it -- by the streaming kernel's squeeze-tensor form
     bool ok = j - i >= 2;
-    for (size_t k = i; ok && k < j; ++k)
-      ok = fire_chain_eligible(in[k].fs, in[k].fe1, in[k].fe3, k + 1 < j ? in[k + 1].fs : 0, net->dtype);
+    for (size_t k = i; ok && k < j; ++k) {
+      if (k + 1 < j) ok = fire_chain_eligible(in[k].fs, in[k].fe1, in[k].fe3, in[k + 1].fs, net->dtype);
+      else ok = in[k].fire_pool ? fire_expand_stream_eligible(in[k].fs, in[k].fe1, in[k].fe3, net->dtype)
+                                : fire_chain_eligible(in[k].fs, in[k].fe1, in[k].fe3, 0, net->dtype);
+    }
     if (!ok) { out.push_back(in[i]); ++i; continue; }
     const double npix = (double)net->batch * in[i].h * in[i].w;
     Layer sq = in[i];   // the first module's squeeze as a plain conv
     sq.type = L_CONV;
-    sq.name = in[i].name + "/squeeze1x1";
+    sq.fire_pool = 0;
+    sq.name = in[i].name.substr(0, in[i].name.find('+')) + "/squeeze1x1";
     sq.out_buf = BUF_S;
     sq.cout = in[i].fs; sq.k = 1; sq.stride = 1; sq.pad_mode = SQDET_PAD_SAME; sq.relu = 1;
     sq.ho = in[i].h; sq.wo = in[i].w;
@@ -460,21 +478,34 @@ void fuse_chains(sqdet_net* net, size_t esz) {
     for (size_t k = i; k < j; ++k) {
       const Layer& f = in[k];
       const bool last = k + 1 == j;
+      const std::string fname = f.name.substr(0, f.name.find('+'));
       Layer c = f;
-      c.type = L_CHAIN;
       c.in_buf = sbuf;
+      const size_t selems_in = (size_t)net->batch * f.h * f.w * (size_t)f.fs;
+      if (selems_in > net->buf_elems[BUF_S]) net->buf_elems[BUF_S] = selems_in;
+      if (selems_in > net->buf_elems[BUF_T]) net->buf_elems[BUF_T] = selems_in;
+      if (last && f.fire_pool) {
+        c.type = L_EXPAND;     // expand + pool from the squeeze tensor; out_buf / ho / wo stay the fused layer's
+        c.name = fname + "/expand" + f.name.substr(f.name.find('+'));
+        c.flops = (2.0 * f.fs * f.fe1 + 18.0 * f.fs * f.fe3) * npix;
+        c.bytes = (npix * f.fs + (double)net->batch * f.ho * f.wo * (f.fe1 + f.fe3) + (double)f.fs * f.fe1 + 9.0 * f.fs * f.fe3) *
+                      (double)esz + 4.0 * (f.fe1 + f.fe3);
+        out.push_back(c);
+        break;
+      }
+      c.type = L_CHAIN;
       c.fs2 = last ? 0 : in[k + 1].fs;
       c.kp_s2 = last ? -1 : in[k + 1].kp_s;
       c.bp_s2 = last ? -1 : in[k + 1].bp_s;
       c.out_buf = last ? f.out_buf : (sbuf == BUF_S ? BUF_T : BUF_S);
-      c.name = last ? f.name + "/expand" : f.name + "/expand+" + in[k + 1].name + "/squeeze1x1";
+      c.name = last ? fname + "/expand" : fname + "/expand+" + in[k + 1].name.substr(0, in[k + 1].name.find('+')) + "/squeeze1x1";
       c.flops = (2.0 * f.fs * f.fe1 + 18.0 * f.fs * f.fe3 + 2.0 * (f.fe1 + f.fe3) * c.fs2) * npix;
       // algorithmic bytes: squeeze tensor in + (next squeeze tensor | concat tensor) out + the weights
       c.bytes = (npix * f.fs + npix * (last ? f.fe1 + f.fe3 : c.fs2) + (double)f.fs * f.fe1 + 9.0 * f.fs * f.fe3 +
                  (double)(f.fe1 + f.fe3) * c.fs2) * (double)esz + 4.0 * (f.fe1 + f.fe3 + c.fs2);
       c.chain_off = net->param_bytes;
       net->param_bytes = align_up(net->param_bytes + sqdet_fire_chain_stream_bytes(f.fs, f.fe1, f.fe3, c.fs2, net->dtype), 256);
-      const size_t selems = (size_t)net->batch * f.h * f.w * (size_t)(f.fs > c.fs2 ? f.fs : c.fs2);
+      const size_t selems = (size_t)net->batch * f.h * f.w * (size_t)c.fs2;
       if (selems > net->buf_elems[BUF_S]) net->buf_elems[BUF_S] = selems;
       if (selems > net->buf_elems[BUF_T]) net->buf_elems[BUF_T] = selems;
       out.push_back(c);
@@ -781,4 +812,18 @@ extern "C" int sqdet_fire_maxpool_fwd(const void* x, const void* w_s, const floa
                                 dtype, stream);
   if (rc != SQDET_OK) return rc;
   return maxpool_launch(fire_scratch, y, n, h, w, e1x1 + e3x3, 3, 2, SQDET_PAD_SAME, dtype, st);
+}
+
+extern "C" int sqdet_fire_expand_fwd(const void* sq_in, const void* w_e1, const float* b_e1, const void* w_e3, const float* b_e3,
+                                     void* y, int n, int h, int w, int s1x1, int e1x1, int e3x3, int pool, int dtype,
+                                     sqdet_stream_t stream) {
+  SQDET_REQUIRE(sq_in && w_e1 && b_e1 && w_e3 && b_e3 && y, "fire_expand_fwd: null pointer");
+  hipStream_t st = as_stream(stream);
+  bool handled = false;
+  int rc = fire_expand_stream_launch(sq_in, w_e1, b_e1, w_e3, b_e3, y, n, h, w, s1x1, e1x1, e3x3, dtype, pool, st, &handled);
+  if (rc != SQDET_OK || handled) return rc;
+  SQDET_UNSUPPORTED(pool != 0, "fire_expand_fwd: the pooled form needs a shape the streaming kernel covers");
+  rc = conv2d_launch(sq_in, w_e1, b_e1, y, n, h, w, s1x1, e1x1, 1, 1, SQDET_PAD_SAME, 1, dtype, e1x1 + e3x3, 0, st);
+  if (rc != SQDET_OK) return rc;
+  return conv2d_launch(sq_in, w_e3, b_e3, y, n, h, w, s1x1, e3x3, 3, 1, SQDET_PAD_SAME, 1, dtype, e1x1 + e3x3, e1x1, st);
 }

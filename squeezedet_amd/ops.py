@@ -144,6 +144,18 @@ def fire_maxpool(x, p_s, b_s, p_e1, b_e1, p_e3, b_e3):
     return y
 
 
+def fire_expand(sq_in, p_e1, b_e1, p_e3, b_e3, pool=False):
+    """Expand half of a fire module from its squeeze tensor (+ the 3x3/s2 SAME max-pool behind it): sqdet_fire_expand_fwd."""
+    n, h, w, s = [int(v) for v in sq_in.shape]
+    ctot = p_e1.cout + p_e3.cout
+    shape = (n, -(-h // 2), -(-w // 2), ctot) if pool else (n, h, w, ctot)
+    y = torch.empty(shape, dtype=sq_in.dtype, device=sq_in.device)
+    check(lib().sqdet_fire_expand_fwd(_dev(sq_in, "sq_in"), _dev(p_e1.data, "w_e1"), _dev(b_e1, "b_e1", torch.float32),
+                                      _dev(p_e3.data, "w_e3"), _dev(b_e3, "b_e3", torch.float32), _dev(y, "y"), n, h, w, s,
+                                      p_e1.cout, p_e3.cout, int(bool(pool)), dtype_code(sq_in.dtype), stream_ptr()), "sqdet_fire_expand_fwd")
+    return y
+
+
 class FireChainStream:
     """The packed weight stream of sqdet_fire_chain_fwd: expand1x1 + expand3x3 kernels of one fire module and,
     optionally, the squeeze1x1 kernel of the next one (float32 HWIO in, float16 stream out)."""

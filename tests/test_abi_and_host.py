@@ -64,10 +64,11 @@ def test_net_plan_tables_without_gpu(lib):
         return out
     assert lib.sqdet_net_create(C.byref(h), _lib.ARCH_SQUEEZEDET, _lib.F16, 32, 375, 1242, 3, 9) == 0
     names_default = layer_names()
-    assert names_default[0] == "conv1+pool1" and "fire2" in names_default and "fire4" in names_default
-    # ... and the two max-pools behind fire3 / fire5 are taken inside those launches
-    assert "fire3+pool3" in names_default and "fire5+pool5" in names_default and "pool3" not in names_default
-    assert names_default[5:] == ["fire6/squeeze1x1", "fire6/expand+fire7/squeeze1x1", "fire7/expand+fire8/squeeze1x1",
+    # every run of fire modules on one map is a chain: squeeze of the first, expand_i + squeeze_{i+1}, and the last
+    # module's expand -- with its pool where it has one (fire3+pool3, fire5+pool5 from their squeeze tensors)
+    assert names_default[:7] == ["conv1+pool1", "fire2/squeeze1x1", "fire2/expand+fire3/squeeze1x1", "fire3/expand+pool3",
+                                 "fire4/squeeze1x1", "fire4/expand+fire5/squeeze1x1", "fire5/expand+pool5"]
+    assert names_default[7:] == ["fire6/squeeze1x1", "fire6/expand+fire7/squeeze1x1", "fire7/expand+fire8/squeeze1x1",
                                  "fire8/expand+fire9/squeeze1x1", "fire9/expand+fire10/squeeze1x1",
                                  "fire10/expand+fire11/squeeze1x1", "fire11/expand", "conv12"]
     lib.sqdet_net_destroy(h)
@@ -78,6 +79,7 @@ def test_net_plan_tables_without_gpu(lib):
     assert lib.sqdet_set_option(b"fire_fuse", 0) == 0
     names_nochain = layer_names()
     assert "fire6" in names_nochain and "fire11" in names_nochain and len(names_nochain) == 34 - 2 * 10 - 2
+    assert "fire2" in names_nochain and "fire3+pool3" in names_nochain and "fire5+pool5" in names_nochain and "pool3" not in names_nochain
     lib.sqdet_net_destroy(h)
     assert lib.sqdet_net_create(C.byref(h), _lib.ARCH_SQUEEZEDET, _lib.F32, 2, 384, 1248, 3, 9) == 0
     assert not any("+fire" in n or n.endswith("/expand") for n in layer_names())

@@ -447,7 +447,7 @@ CHAIN_CASES = [("fire6-7", 48, 192, 48, 24, 78, 2), ("fire7-8", 48, 192, 64, 11,
                ("fire11-ragged", 96, 384, 0, 13, 21, 5), ("fire7-only", 48, 192, 0, 8, 16, 1), ("one-pixel", 64, 256, 64, 1, 1, 1),
                # the large early maps (one-chunk squeezes): fire2 -> 3, fire4 -> 5, fire5 -> (pool) fire6's width, expand only
                ("fire2-3", 16, 64, 16, 47, 83, 2), ("fire4-5", 32, 128, 32, 23, 40, 3), ("fire5-w48", 32, 128, 48, 9, 17, 1),
-               ("fire3-only", 16, 64, 0, 19, 33, 1)]
+               ("fire3-only", 16, 64, 0, 19, 33, 1), ("fire2-3-many-quads", 16, 64, 16, 94, 311, 3), ("fire4-5-odd", 32, 128, 32, 47, 156, 5)]
 
 
 @pytest.mark.parametrize("want_y", [False, True])
@@ -470,6 +470,14 @@ def test_fire_chain_parity(case, want_y):
     chain = ops.FireChainStream(w1.to(DEV), w3.to(DEV), ws.to(DEV) if s2 else None, tdt)
     sqd = sq.to(DEV).contiguous()
     y, so = ops.fire_chain(sqd, chain, b1.to(DEV), b3.to(DEV), bs.to(DEV) if s2 else None, want_y=want_y)
+    if s <= 32 and s2 and not want_y:
+        # one-chunk squeezes on large maps run the PERSISTENT, weights-resident kernel: force it here at test size
+        # ("dbg" 31) -- it must give the ring kernel's result bit for bit (both are checked against the separate convs)
+        ops.set_option("dbg", 31)
+        _, so_p = ops.fire_chain(sqd, chain, b1.to(DEV), b3.to(DEV), bs.to(DEV), want_y=False)
+        ops.set_option("dbg", 0)
+        torch.cuda.synchronize()
+        assert torch.equal(so_p, so), "persistent chain kernel differs from the ring kernel"
     # the separate launches
     p1, p3 = ops.pack_conv_weights(w1.to(DEV), tdt), ops.pack_conv_weights(w3.to(DEV), tdt)
     y_sep = torch.empty((N, H, W, 2 * e), dtype=tdt, device=DEV)
@@ -524,3 +532,29 @@ def test_fire_pool_full_size_fp16_vs_oracle(case):
     np.testing.assert_allclose(got, ref, rtol=2 ** -8, atol=2e-3)
     frac = float((got != ref).mean())
     assert frac < 0.05, "more than 5 %% of the pooled float16 values differ from the oracle's (%g)" % frac
+
+
+EXPAND_CASES = [("fire3", 128, 16, 64, 94, 311, 2, True), ("fire3-odd", 128, 16, 64, 19, 37, 3, True), ("fire5", 256, 32, 128, 47, 156, 2, True),
+                ("fire5-small", 256, 32, 128, 9, 15, 1, True), ("fire2-nopool", 64, 16, 64, 33, 30, 2, False), ("fire4-nopool", 128, 32, 128, 17, 20, 1, False),
+                ("fallback-nopool", 256, 48, 192, 13, 21, 1, False)]
+
+
+@pytest.mark.parametrize("case", EXPAND_CASES, ids=[c[0] for c in EXPAND_CASES])
+def test_fire_expand_from_squeeze_tensor(case):
+    """sqdet_fire_expand_fwd (the expand half of a fire module -- and the max-pool behind it -- from the module's squeeze
+    tensor, as the chained plan runs fire3+pool3 / fire5+pool5) BITWISE against the whole-module launches
+    sqdet_fire_fwd / sqdet_fire_maxpool_fwd on the same weights, whose squeeze conv produces that tensor."""
+    ops = _ops()
+    name, cin, s, e, H, W, N, pool = case
+    tdt = torch.float16
+    rs = np.random.RandomState(zlib.crc32(("expand" + name).encode()) % (2 ** 31))
+    mk = lambda k, ci, co: torch.from_numpy((rs.randn(k, k, ci, co) * (2.0 / (k * k * ci)) ** 0.5).astype(np.float32)).half().float()
+    ws, w1, w3 = mk(1, cin, s), mk(1, s, e), mk(3, s, e)
+    bs, b1, b3 = [torch.from_numpy(rs.uniform(-0.3, 0.3, c).astype(np.float32)).to(DEV) for c in (s, e, e)]
+    ps, p1, p3 = [ops.pack_conv_weights(w_.to(DEV), tdt) for w_ in (ws, w1, w3)]
+    x = torch.from_numpy(np.maximum(rs.randn(N, H, W, cin), 0).astype(np.float32)).to(DEV, tdt).contiguous()
+    sq = ops.conv2d_nhwc(x, ps, bs, 1, "SAME", True)
+    got = ops.fire_expand(sq, p1, b1, p3, b3, pool=pool)
+    want = ops.fire_maxpool(x, ps, bs, p1, b1, p3, b3) if pool else ops.fire(x, ps, bs, p1, b1, p3, b3)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape and torch.equal(got, want)

@@ -97,6 +97,16 @@ def main():
         t_chain = timeit(lambda: ops.fire_chain(sq, chain, bz[1], bz[2], bz[3]), args.iters)
         t_cy = timeit(lambda: ops.fire_chain(sq, chain, bz[1], bz[2], bz[3], want_y=True), args.iters)
         print("%-8s %10.4f %10.4f %10.4f %10.4f" % (name, t_fused, t_sq, t_chain, t_cy))
+    # the pooled modules from their squeeze tensor: fire3+pool3, fire5+pool5
+    print("%-12s %10s %10s" % ("module", "whole_ms", "from_sq_ms"))
+    for name, cin, s, e, h, w in (("fire3+pool3", 128, 16, 64, 94, 311), ("fire5+pool5", 256, 32, 128, 47, 156)):
+        x = torch.randn((args.batch, h, w, cin), generator=g).clamp_(min=0).to(dev, dt)
+        ps, p1, p3 = [ops.pack_conv_weights(w_, dt) for w_ in (mkw(1, cin, s), mkw(1, s, e), mkw(3, s, e))]
+        bz = [torch.zeros(n_, device=dev) for n_ in (s, e, e)]
+        sq = ops.conv2d_nhwc(x, ps, bz[0], 1, "SAME", True)
+        t_whole = timeit(lambda: ops.fire_maxpool(x, ps, bz[0], p1, bz[1], p3, bz[2]), args.iters)
+        t_sq = timeit(lambda: ops.fire_expand(sq, p1, bz[1], p3, bz[2], pool=True), args.iters)
+        print("%-12s %10.4f %10.4f" % (name, t_whole, t_sq))
 
 
 if __name__ == "__main__":
