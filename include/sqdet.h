@@ -45,7 +45,7 @@ const char* sqdet_last_error(void);
  * default), 1 = generic implicit-GEMM kernels only (also env SQDET_CONV_ALGO=generic).
  * "fire_fuse": 0 = plan heuristic (default), 1 = one launch per fire module wherever the kernels cover it, 2 = never
  * fuse, 3 = no streaming kernel, 4 = fire modules and the pools behind them stay apart, 5 = no fire-module chains, 6 = chains on
- * the late (small) maps only. */
+ * the late (small) maps only, 7 = a run's first module as squeeze conv + chain launch instead of one streaming launch. */
 int sqdet_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------ conv --
@@ -143,6 +143,17 @@ int sqdet_fire_maxpool_fwd(const void* x, const void* w_s, const float* b_s, con
 int sqdet_fire_expand_fwd(const void* sq_in, const void* w_e1, const float* b_e1, const void* w_e3, const float* b_e3,
                           void* y, int n, int h, int w, int s1x1, int e1x1, int e3x3, int pool, int dtype,
                           sqdet_stream_t stream);
+
+/* A whole fire module from its input x [n,h,w,cin] whose concat tensor is replaced by the NEXT module's squeeze tensor
+ * sq_out [n,h,w,next_s1x1] = relu(conv1x1(fire(x), W_next_s) + b_next_s)  (fire2 -> fire3's squeeze, fire4 -> fire5's squeeze:
+ * nets/squeezeDet.py:46-53, 81-106): the streaming kernel keeps the module's rounded float16 results in an LDS tile and
+ * runs the next squeeze on it.  All kernels packed by sqdet_conv_pack_weights.  Bitwise sqdet_fire_fwd followed by the
+ * squeeze conv.  sqdet_fire_squeeze_next_supported: 1 when the shape is covered (float16, SqueezeDet's two pairs). */
+int sqdet_fire_squeeze_next_supported(int cin, int s1x1, int e1x1, int e3x3, int next_s1x1, int dtype);
+int sqdet_fire_squeeze_next_fwd(const void* x, const void* w_s, const float* b_s, const void* w_e1, const float* b_e1,
+                                const void* w_e3, const float* b_e3, const void* w_next_s, const float* b_next_s, void* sq_out,
+                                int n, int h, int w, int cin, int s1x1, int e1x1, int e3x3, int next_s1x1, int dtype,
+                                sqdet_stream_t stream);
 
 /* Fire-module CHAIN (float16): the expand half of one fire module and the squeeze of the NEXT module in one launch.
  * Replaces, for consecutive fire modules on one feature map (fire6 .. fire11, nets/squeezeDet.py:58-69), the pair

@@ -82,6 +82,11 @@ struct FireSArgs {
   int x_pieces;                // Cin*sizeof(T)/16
   unsigned x_bytes, y_bytes;   // tensor sizes (< 2^31: 32-bit buffer offsets)
   int Hp, Wp, ptp, plp;        // POOL: pooled output dims and the SAME pads (top / left) of the 3x3/s2 pool
+  // NTS2 > 0 (squeeze-out form): the NEXT module's squeeze1x1 (packed kernel, bias, S2 channels) and its output tensor
+  const void* ws2;
+  const float* bs2;
+  void* s_out;
+  int S2;
 };
 
 // RS = row split: the tile rows are divided among RS waves per cout pair (NWAVES = cout pairs x RS).  POOL: a wave
@@ -96,8 +101,14 @@ struct FireSArgs {
 // phase A is a copy -- the prefetched 16-byte pieces go straight into the LDS squeeze tile (out-of-image pieces and the
 // channel padding arrive as zeros: exactly the SAME padding of the squeeze tensor) -- and the module reads 32-64 bytes
 // per pixel instead of 128-256 (NCHX = 1, NTS unused).
-template <typename T, int NCHX, int NTS, int NWAVES, int PF, bool POOL, int RS, bool PAIR = false, bool SQIN = false>
+// NTS2 > 0 (not with POOL): the module's concat tensor is NOT written; the tile's rounded float16 results go to an LDS
+// tile in the B-fragment layout of the NEXT module's squeeze1x1 (lane group g of cout pair cp holds piece g of K chunk
+// coff/32 + cp), and after one more barrier the waves run that squeeze on the tile's 128 pixels (16-pixel block x NTS2
+// cout tiles per wave, chunks in ascending concat-channel order = the canonical accumulation order) and write the
+// S2-channel squeeze tensor: 32-64 bytes per pixel leave the kernel instead of 256-512.
+template <typename T, int NCHX, int NTS, int NWAVES, int PF, bool POOL, int RS, bool PAIR = false, bool SQIN = false, int NTS2 = 0>
 __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs a) {   // 2 waves per SIMD: 256 VGPRs
+  static_assert(NTS2 == 0 || !POOL, "the squeeze-out form has no pooled variant");
   constexpr int KG = Tr<T>::KG;
   constexpr int NT3 = PAIR ? 5 : 9;                  // K-steps of the expand3x3
   constexpr int KC = 4 * KG;
@@ -110,7 +121,10 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
   unsigned char* sq = lds;                           // [2][STILE]
   unsigned char* wsl = lds + 2 * STILE;              // squeeze weights [NCHX][NTS][64 lanes][16 B]
   unsigned char* w1l = wsl + NCHX * NTS * 1024;      // expand1x1 weights [E/16 tiles][64 lanes][16 B]
-  float* bl = reinterpret_cast<float*>(w1l + NG * 4 * 1024);   // biases
+  constexpr int NQC = NG * 4;                         // 64-byte K chunks of the concat tensor (2E / 32 channels)
+  unsigned char* ctile = w1l + NG * 4 * 1024;         // NTS2: [NQC chunks][128 pixels][4 x 16 B swizzled]
+  unsigned char* ws2l = ctile + (NTS2 ? NQC * 128 * 64 : 0);   // NTS2: next squeeze weights [NQC][NTS2][64 lanes][16 B]
+  float* bl = reinterpret_cast<float*>(ws2l + (NTS2 ? NQC * NTS2 * 1024 : 0));   // biases [b1 | b3 | bs | bs2]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // in an SGPR: what follows from it is wave-uniform
   const int j = lane & 15, g = lane >> 4;
@@ -128,6 +142,11 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
     // and drain them every time it is waited for.
     for (int i = threadIdx.x; i < 2 * a.E + (SQIN ? 0 : a.S); i += NWAVES * 64)
       bl[i] = i < a.E ? a.b1[i] : (i < 2 * a.E ? a.b3[i - a.E] : a.bs[i - 2 * a.E]);
+    if constexpr (NTS2 > 0) {
+      const i32x4* src2 = reinterpret_cast<const i32x4*>(a.ws2);
+      for (int i = threadIdx.x; i < NQC * NTS2 * 64; i += NWAVES * 64) reinterpret_cast<i32x4*>(ws2l)[i] = src2[i];
+      for (int i = threadIdx.x; i < a.S2; i += NWAVES * 64) bl[2 * a.E + a.S + i] = a.bs2[i];
+    }
     // channel padding of the squeeze tile (S*sizeof(T) < 64 bytes) is zero in both buffers, forever
     const int s_pieces = a.S * (int)sizeof(T) / 16;
     const int pad = 4 - s_pieces;
@@ -331,7 +350,11 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[t][e] = fmaxf(v[t][e], 0.f);
           }
-          if constexpr (sizeof(T) == 2) {
+          if constexpr (NTS2 > 0) {
+            const f16x8 h = {(f16)v[0][0], (f16)v[0][1], (f16)v[0][2], (f16)v[0][3], (f16)v[1][0], (f16)v[1][1], (f16)v[1][2], (f16)v[1][3]};
+            const int PLc = (m0 + m) * SCOLS + j;
+            *reinterpret_cast<i32x4*>(ctile + (coff / 32 + cp) * (128 * 64) + PLc * 64 + ((g ^ ((PLc >> 1) & 3)) << 4)) = __builtin_bit_cast(i32x4, h);
+          } else if constexpr (sizeof(T) == 2) {
             const f16x8 h = {(f16)v[0][0], (f16)v[0][1], (f16)v[0][2], (f16)v[0][3], (f16)v[1][0], (f16)v[1][1], (f16)v[1][2], (f16)v[1][3]};
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, h), ry, off, 0, 0);
           } else {
@@ -469,6 +492,38 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
       else epilogue(acc1, bl, 0, std::false_type{});
       FT_MARK(6);
     }
+    if constexpr (NTS2 > 0) {
+      // ---------------- phase C: the next module's squeeze1x1 on the tile (tile row = one 16-pixel block) ----------------
+      __syncthreads();                                    // the whole concat tile is in LDS
+      constexpr int BPW = 8 / NWAVES;                     // pixel blocks (tile rows) per wave
+      T* so = reinterpret_cast<T*>(a.s_out);
+#pragma unroll
+      for (int bb = 0; bb < BPW; ++bb) {
+        const int row = wave * BPW + bb;
+        f32x4 acc2[NTS2];
+#pragma unroll
+        for (int t = 0; t < NTS2; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int PLc = row * SCOLS + j;
+        const unsigned char* cb0 = ctile + PLc * 64 + ((g ^ ((PLc >> 1) & 3)) << 4);
+#pragma unroll
+        for (int q = 0; q < NQC; ++q) {
+          const i32x4 bfq = *reinterpret_cast<const i32x4*>(cb0 + q * (128 * 64));
+#pragma unroll
+          for (int t = 0; t < NTS2; ++t)
+            mma16<T>(acc2[t], *reinterpret_cast<const i32x4*>(ws2l + ((q * NTS2 + t) * 64 + lane) * 16), bfq);
+        }
+        const int oy = oy0 + row;
+        if (oy < a.H && ox < a.W) {
+          T* dst = so + ((size_t)(n * a.H + oy) * a.W + ox) * a.S2 + g * 4 * NTS2;
+#pragma unroll
+          for (int t = 0; t < NTS2; ++t) {
+            f32x4 v = acc2[t] + *reinterpret_cast<const f32x4*>(bl + 2 * a.E + a.S + g * 4 * NTS2 + t * 4);
+            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            store4<T>(dst + t * 4, v);
+          }
+        }
+      }
+    }
   };
 
   prep_loads(tile, tile < band_end, inimgs[0]);
@@ -583,6 +638,7 @@ int fire_stream_launch_ex(const void* x, const void* ws, const float* bs, const 
   if (!stream_shape(cin, s, e1, e3, dtype, &nchx, &nts, &nwaves)) return SQDET_OK;
   FireSArgs a;
   a.x = x; a.y = y; a.ws = ws; a.w1 = w1; a.w3 = w3; a.bs = bs; a.b1 = b1; a.b3 = b3;
+  a.ws2 = nullptr; a.bs2 = nullptr; a.s_out = nullptr; a.S2 = 0;
   a.N = n; a.H = h; a.W = w; a.Cin = cin; a.S = s; a.E = e1;
   a.Hp = out_size(h, 3, 2, SQDET_PAD_SAME); a.Wp = out_size(w, 3, 2, SQDET_PAD_SAME);
   a.ptp = pad_before(h, 3, 2, SQDET_PAD_SAME); a.plp = pad_before(w, 3, 2, SQDET_PAD_SAME);
@@ -607,6 +663,57 @@ int fire_stream_launch_ex(const void* x, const void* ws, const float* bs, const 
   return SQDET_OK;
 }
 
+// ---- whole fire module from x + the NEXT module's squeeze (float16): fire2 -> fire3's squeeze, fire4 -> fire5's ----
+// (instantiated for SqueezeDet's two such pairs: Cin 64 / S 16 / E 64 / S2 16 and Cin 128 / S 32 / E 128 / S2 32)
+bool fire_squeeze_next_eligible(int cin, int s, int e1, int e3, int s2, int dtype) {
+  if (dtype != SQDET_F16) return false;
+  int nchx, nts, nwaves;
+  if (!stream_shape(cin, s, e1, e3, dtype, &nchx, &nts, &nwaves)) return false;
+  return (nchx == 2 && nts == 1 && nwaves == 4 && s == 16 && s2 == 16) || (nchx == 4 && nts == 2 && nwaves == 8 && s2 == 32);
+}
+
+template <int NCHX, int NTS, int NWAVES, bool PAIR, int NTS2>
+static int launch_stream_sq(const FireSArgs& a, hipStream_t st) {
+  constexpr int NQ = (NWAVES / 2 / 2) * 4;
+  const size_t lds = 2 * (size_t)Geo<false>::TILE + (size_t)NCHX * NTS * 1024 + (size_t)(NWAVES / 2 / 2) * 4 * 1024 +
+                     (size_t)NQ * 128 * 64 + (size_t)NQ * NTS2 * 1024 + (size_t)(2 * a.E + a.S + a.S2) * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    SQDET_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_stream<f16, NCHX, NTS, NWAVES, 2, false, 2, PAIR, false, NTS2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  int grid = 256 * (8 / NWAVES);
+  if (grid > (a.ntiles + 7) / 8 * 8) grid = (a.ntiles + 7) / 8 * 8;
+  hipLaunchKernelGGL((fire_stream<f16, NCHX, NTS, NWAVES, 2, false, 2, PAIR, false, NTS2>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
+int fire_squeeze_next_launch(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
+                             const float* b3, const void* ws2, const float* bs2, void* s_out, int n, int h, int w, int cin,
+                             int s, int e1, int e3, int s2, int dtype, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (!fire_squeeze_next_eligible(cin, s, e1, e3, s2, dtype)) return SQDET_OK;
+  FireSArgs a;
+  a.x = x; a.y = nullptr; a.ws = ws; a.w1 = w1; a.w3 = w3; a.bs = bs; a.b1 = b1; a.b3 = b3;
+  a.ws2 = ws2; a.bs2 = bs2; a.s_out = s_out; a.S2 = s2;
+  a.N = n; a.H = h; a.W = w; a.Cin = cin; a.S = s; a.E = e1;
+  a.Hp = a.Wp = a.ptp = a.plp = 0;
+  a.tiles_x = (w + SCOLS - 1) / SCOLS; a.tiles_y = (h + 7) / 8;
+  const long nt = (long)n * a.tiles_x * a.tiles_y;
+  if (nt > 0x3fffffffL) return SQDET_OK;
+  a.ntiles = (int)nt;
+  a.x_pieces = cin * 2 / 16;
+  const long xb = (long)n * h * w * cin * 2;
+  if (xb >= (1L << 31)) return SQDET_OK;
+  a.x_bytes = (unsigned)xb; a.y_bytes = 0;
+  const int rc = s == 16 ? launch_stream_sq<2, 1, 4, true, 1>(a, st) : launch_stream_sq<4, 2, 8, false, 2>(a, st);
+  if (rc != SQDET_OK) return rc;
+  *handled = true;
+  return SQDET_OK;
+}
+
 // ---- the expand half of a fire module from its SQUEEZE tensor (float16; the chain kernels of chain.hip produce it) ----
 bool fire_expand_stream_eligible(int s, int e1, int e3, int dtype) {
   if (conv_algo() != 0 || e1 != e3 || dtype != SQDET_F16) return false;
@@ -623,6 +730,7 @@ int fire_expand_stream_launch(const void* sq_in, const void* w1, const float* b1
   if (!fire_expand_stream_eligible(s, e1, e3, dtype)) return SQDET_OK;
   FireSArgs a;
   a.x = sq_in; a.y = y; a.ws = nullptr; a.w1 = w1; a.w3 = w3; a.bs = nullptr; a.b1 = b1; a.b3 = b3;
+  a.ws2 = nullptr; a.bs2 = nullptr; a.s_out = nullptr; a.S2 = 0;
   a.N = n; a.H = h; a.W = w; a.Cin = s; a.S = s; a.E = e1;
   a.Hp = out_size(h, 3, 2, SQDET_PAD_SAME); a.Wp = out_size(w, 3, 2, SQDET_PAD_SAME);
   a.ptp = pad_before(h, 3, 2, SQDET_PAD_SAME); a.plp = pad_before(w, 3, 2, SQDET_PAD_SAME);

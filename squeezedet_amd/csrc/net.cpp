@@ -33,6 +33,10 @@ int fire_stream_launch_ex(const void* x, const void* ws, const float* bs, const 
                           int pool, hipStream_t st, bool* handled);
 bool fire_chain_eligible(int s, int e1, int e3, int s2, int dtype);
 bool fire_expand_stream_eligible(int s, int e1, int e3, int dtype);
+bool fire_squeeze_next_eligible(int cin, int s, int e1, int e3, int s2, int dtype);
+int fire_squeeze_next_launch(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
+                             const float* b3, const void* ws2, const float* bs2, void* s_out, int n, int h, int w, int cin,
+                             int s, int e1, int e3, int s2, int dtype, hipStream_t st, bool* handled);
 int fire_expand_stream_launch(const void* sq_in, const void* w1, const float* b1, const void* w3, const float* b3, void* y,
                               int n, int h, int w, int s, int e1, int e3, int dtype, int pool, hipStream_t st, bool* handled);
 int conv_algo();
@@ -47,7 +51,8 @@ enum { BUF_INPUT = -1, BUF_PREDS = -2, BUF_A = 0, BUF_B = 1, BUF_S = 2, BUF_T = 
 // L_STEM: conv(k, s2, Cin 3)+relu+maxpool(3, s2) in one launch; L_FIRE: squeeze + both expands in one launch;
 // L_CHAIN: both expands of a fire module + the squeeze of the NEXT module in one launch (sqdet_fire_chain_fwd)
 // L_EXPAND: both expands of a fire module from its squeeze tensor (+ the max-pool behind it): sqdet_fire_expand_fwd
-enum { L_CONV = 0, L_POOL = 1, L_STEM = 2, L_FIRE = 3, L_CHAIN = 4, L_EXPAND = 5 };
+// L_FIRESQ: a whole fire module from x whose output is the NEXT module's squeeze tensor (sqdet_fire_squeeze_next_fwd)
+enum { L_CONV = 0, L_POOL = 1, L_STEM = 2, L_FIRE = 3, L_CHAIN = 4, L_EXPAND = 5, L_FIRESQ = 6 };
 
 struct Param {
   std::string name;
@@ -290,6 +295,15 @@ int run_layer_part(sqdet_net* net, const Layer& L, const void* input, void* pred
                                 L.fs2 > 0 ? nullptr : out, L.fs2 > 0 ? out : nullptr, nb, L.h, L.w, L.fs, L.fe1, L.fe3, L.fs2,
                                 net->dtype, reinterpret_cast<sqdet_stream_t>(st));
   }
+  if (L.type == L_FIRESQ) {
+    const char* xin = reinterpret_cast<const char*>(buf_ptr(net, L.in_buf, input, preds)) + (size_t)n0 * L.h * L.w * L.cin * esz;
+    char* out = reinterpret_cast<char*>(buf_ptr(net, L.out_buf, input, preds)) + (size_t)n0 * L.h * L.w * L.fs2 * esz;
+    auto pk = [&](int i) { return (const void*)(net->param_mem + net->params[i].offset); };
+    auto pb = [&](int i) { return reinterpret_cast<const float*>(net->param_mem + net->params[i].offset); };
+    return sqdet_fire_squeeze_next_fwd(xin, pk(L.kp_s), pb(L.bp_s), pk(L.kp_1), pb(L.bp_1), pk(L.kp_3), pb(L.bp_3), pk(L.kp_s2),
+                                       pb(L.bp_s2), out, nb, L.h, L.w, L.cin, L.fs, L.fe1, L.fe3, L.fs2, net->dtype,
+                                       reinterpret_cast<sqdet_stream_t>(st));
+  }
   if (L.type == L_EXPAND) {
     const char* sq_in = reinterpret_cast<const char*>(buf_ptr(net, L.in_buf, input, preds)) + (size_t)n0 * L.h * L.w * L.fs * esz;
     char* out = reinterpret_cast<char*>(buf_ptr(net, L.out_buf, input, preds)) + (size_t)n0 * L.ho * L.wo * (L.fe1 + L.fe3) * esz;
@@ -462,6 +476,26 @@ void fuse_chains(sqdet_net* net, size_t esz) {
     }
     if (!ok) { out.push_back(in[i]); ++i; continue; }
     const double npix = (double)net->batch * in[i].h * in[i].w;
+    // the first module in ONE launch from x where the streaming kernel covers it (fire2, fire4): its squeeze, its expands
+    // and the second module's squeeze -- "fire_fuse" = 7 keeps squeeze conv + chain launch
+    size_t kfirst = i;
+    int sbuf0 = BUF_S;
+    if (tune(3) != 7 && !in[i].fire_pool && fire_squeeze_next_eligible(in[i].cin, in[i].fs, in[i].fe1, in[i].fe3, in[i + 1].fs, net->dtype)) {
+      const Layer& f = in[i];
+      Layer c = f;
+      c.type = L_FIRESQ;
+      c.fs2 = in[i + 1].fs; c.kp_s2 = in[i + 1].kp_s; c.bp_s2 = in[i + 1].bp_s;
+      c.out_buf = BUF_S;
+      c.name = f.name + "+" + in[i + 1].name.substr(0, in[i + 1].name.find('+')) + "/squeeze1x1";
+      c.flops = f.flops + 2.0 * (f.fe1 + f.fe3) * c.fs2 * npix;
+      c.bytes = (npix * f.cin + npix * c.fs2 + (double)f.cin * f.fs + (double)f.fs * f.fe1 + 9.0 * f.fs * f.fe3 +
+                 (double)(f.fe1 + f.fe3) * c.fs2) * (double)esz + 4.0 * (f.fs + f.fe1 + f.fe3 + c.fs2);
+      const size_t selems = (size_t)net->batch * f.h * f.w * (size_t)c.fs2;
+      if (selems > net->buf_elems[BUF_S]) net->buf_elems[BUF_S] = selems;
+      if (selems > net->buf_elems[BUF_T]) net->buf_elems[BUF_T] = selems;
+      out.push_back(c);
+      kfirst = i + 1;
+    }
     Layer sq = in[i];   // the first module's squeeze as a plain conv
     sq.type = L_CONV;
     sq.fire_pool = 0;
@@ -473,9 +507,9 @@ void fuse_chains(sqdet_net* net, size_t esz) {
     sq.kparam = in[i].kp_s; sq.bparam = in[i].bp_s;
     sq.flops = 2.0 * in[i].cin * in[i].fs * npix;
     sq.bytes = (npix * in[i].cin + npix * in[i].fs + (double)in[i].cin * in[i].fs) * (double)esz + 4.0 * in[i].fs;
-    out.push_back(sq);
-    int sbuf = BUF_S;
-    for (size_t k = i; k < j; ++k) {
+    if (kfirst == i) out.push_back(sq);
+    int sbuf = sbuf0;
+    for (size_t k = kfirst; k < j; ++k) {
       const Layer& f = in[k];
       const bool last = k + 1 == j;
       const std::string fname = f.name.substr(0, f.name.find('+'));
@@ -826,4 +860,21 @@ extern "C" int sqdet_fire_expand_fwd(const void* sq_in, const void* w_e1, const 
   rc = conv2d_launch(sq_in, w_e1, b_e1, y, n, h, w, s1x1, e1x1, 1, 1, SQDET_PAD_SAME, 1, dtype, e1x1 + e3x3, 0, st);
   if (rc != SQDET_OK) return rc;
   return conv2d_launch(sq_in, w_e3, b_e3, y, n, h, w, s1x1, e3x3, 3, 1, SQDET_PAD_SAME, 1, dtype, e1x1 + e3x3, e1x1, st);
+}
+
+extern "C" int sqdet_fire_squeeze_next_fwd(const void* x, const void* w_s, const float* b_s, const void* w_e1, const float* b_e1,
+                                           const void* w_e3, const float* b_e3, const void* w_next_s, const float* b_next_s,
+                                           void* sq_out, int n, int h, int w, int cin, int s1x1, int e1x1, int e3x3,
+                                           int next_s1x1, int dtype, sqdet_stream_t stream) {
+  SQDET_REQUIRE(x && w_s && b_s && w_e1 && b_e1 && w_e3 && b_e3 && w_next_s && b_next_s && sq_out, "fire_squeeze_next_fwd: null pointer");
+  bool handled = false;
+  const int rc = fire_squeeze_next_launch(x, w_s, b_s, w_e1, b_e1, w_e3, b_e3, w_next_s, b_next_s, sq_out, n, h, w, cin, s1x1, e1x1,
+                                          e3x3, next_s1x1, dtype, as_stream(stream), &handled);
+  if (rc != SQDET_OK) return rc;
+  SQDET_UNSUPPORTED(!handled, "fire_squeeze_next_fwd: shape not covered (see sqdet_fire_squeeze_next_supported)");
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_fire_squeeze_next_supported(int cin, int s1x1, int e1x1, int e3x3, int next_s1x1, int dtype) {
+  return fire_squeeze_next_eligible(cin, s1x1, e1x1, e3x3, next_s1x1, dtype) ? 1 : 0;
 }

@@ -156,6 +156,20 @@ def fire_expand(sq_in, p_e1, b_e1, p_e3, b_e3, pool=False):
     return y
 
 
+def fire_squeeze_next(x, p_s, b_s, p_e1, b_e1, p_e3, b_e3, p_next_s, b_next_s):
+    """A whole fire module from x, emitting the NEXT module's squeeze tensor instead of its concat tensor
+    (sqdet_fire_squeeze_next_fwd)."""
+    n, h, w, cin = [int(v) for v in x.shape]
+    so = torch.empty((n, h, w, p_next_s.cout), dtype=x.dtype, device=x.device)
+    check(lib().sqdet_fire_squeeze_next_fwd(_dev(x, "x"), _dev(p_s.data, "w_s"), _dev(b_s, "b_s", torch.float32),
+                                            _dev(p_e1.data, "w_e1"), _dev(b_e1, "b_e1", torch.float32),
+                                            _dev(p_e3.data, "w_e3"), _dev(b_e3, "b_e3", torch.float32),
+                                            _dev(p_next_s.data, "w_next_s"), _dev(b_next_s, "b_next_s", torch.float32), _dev(so, "sq_out"),
+                                            n, h, w, cin, p_s.cout, p_e1.cout, p_e3.cout, p_next_s.cout, dtype_code(x.dtype), stream_ptr()),
+          "sqdet_fire_squeeze_next_fwd")
+    return so
+
+
 class FireChainStream:
     """The packed weight stream of sqdet_fire_chain_fwd: expand1x1 + expand3x3 kernels of one fire module and,
     optionally, the squeeze1x1 kernel of the next one (float32 HWIO in, float16 stream out)."""

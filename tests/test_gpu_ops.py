@@ -558,3 +558,34 @@ def test_fire_expand_from_squeeze_tensor(case):
     want = ops.fire_maxpool(x, ps, bs, p1, b1, p3, b3) if pool else ops.fire(x, ps, bs, p1, b1, p3, b3)
     torch.cuda.synchronize()
     assert got.shape == want.shape and torch.equal(got, want)
+
+
+SQNEXT_CASES = [("fire2-3", 64, 16, 64, 16, 94, 311, 2), ("fire2-3-ragged", 64, 16, 64, 16, 19, 37, 3), ("fire4-5", 128, 32, 128, 32, 47, 156, 2),
+                ("fire4-5-small", 128, 32, 128, 32, 9, 15, 5)]
+
+
+@pytest.mark.parametrize("case", SQNEXT_CASES, ids=[c[0] for c in SQNEXT_CASES])
+def test_fire_squeeze_next_one_launch(case):
+    """sqdet_fire_squeeze_next_fwd (a whole fire module from x whose concat tensor is replaced by the NEXT module's squeeze
+    tensor: fire2 -> fire3's squeeze, fire4 -> fire5's, nets/squeezeDet.py:46-53) BITWISE against sqdet_fire_fwd followed
+    by the squeeze conv, and against the oracle in float16-storage mode."""
+    ops = _ops()
+    name, cin, s, e, s2, H, W, N = case
+    tdt = torch.float16
+    assert ops.lib().sqdet_fire_squeeze_next_supported(cin, s, e, e, s2, 1) == 1
+    rs = np.random.RandomState(zlib.crc32(("sqnext" + name).encode()) % (2 ** 31))
+    mk = lambda k, ci, co: torch.from_numpy((rs.randn(k, k, ci, co) * (2.0 / (k * k * ci)) ** 0.5).astype(np.float32)).half().float()
+    ws, w1, w3, wn = mk(1, cin, s), mk(1, s, e), mk(3, s, e), mk(1, 2 * e, s2)
+    bs, b1, b3, bn = [torch.from_numpy(rs.uniform(-0.3, 0.3, c).astype(np.float32)) for c in (s, e, e, s2)]
+    ps, p1, p3, pn = [ops.pack_conv_weights(w_.to(DEV), tdt) for w_ in (ws, w1, w3, wn)]
+    x = torch.from_numpy(np.maximum(rs.randn(N, H, W, cin), 0).astype(np.float32)).half()
+    xd = x.to(DEV).contiguous()
+    got = ops.fire_squeeze_next(xd, ps, bs.to(DEV), p1, b1.to(DEV), p3, b3.to(DEV), pn, bn.to(DEV))
+    y = ops.fire(xd, ps, bs.to(DEV), p1, b1.to(DEV), p3, b3.to(DEV))
+    want = ops.conv2d_nhwc(y, pn, bn.to(DEV), 1, "SAME", True)
+    torch.cuda.synchronize()
+    if s == 16:   # (the float16 S = 16 module pairs two taps per MFMA in BOTH launches: same kernel arithmetic)
+        pass
+    assert got.shape == want.shape and torch.equal(got, want), "squeeze-out form differs from fire -> squeeze conv"
+    ref = O.conv_layer(y.float().cpu(), wn, bn, 1, "SAME", True, storage="fp16")
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref.numpy(), rtol=2 ** -8, atol=2e-3)

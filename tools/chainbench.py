@@ -96,7 +96,9 @@ def main():
         chain = ops.FireChainStream(w1, w3, wn, dt)
         t_chain = timeit(lambda: ops.fire_chain(sq, chain, bz[1], bz[2], bz[3]), args.iters)
         t_cy = timeit(lambda: ops.fire_chain(sq, chain, bz[1], bz[2], bz[3], want_y=True), args.iters)
-        print("%-8s %10.4f %10.4f %10.4f %10.4f" % (name, t_fused, t_sq, t_chain, t_cy))
+        pn = ops.pack_conv_weights(wn, dt)
+        t_one = timeit(lambda: ops.fire_squeeze_next(x, ps, bz[0], p1, bz[1], p3, bz[2], pn, bz[3]), args.iters)
+        print("%-8s %10.4f %10.4f %10.4f %10.4f   one launch (x -> next squeeze): %.4f" % (name, t_fused, t_sq, t_chain, t_cy, t_one))
     # the pooled modules from their squeeze tensor: fire3+pool3, fire5+pool5
     print("%-12s %10s %10s" % ("module", "whole_ms", "from_sq_ms"))
     for name, cin, s, e, h, w in (("fire3+pool3", 128, 16, 64, 94, 311), ("fire5+pool5", 256, 32, 128, 47, 156)):
