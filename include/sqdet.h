@@ -45,7 +45,8 @@ const char* sqdet_last_error(void);
  * default), 1 = generic implicit-GEMM kernels only (also env SQDET_CONV_ALGO=generic).
  * "fire_fuse": 0 = plan heuristic (default), 1 = one launch per fire module wherever the kernels cover it, 2 = never
  * fuse, 3 = no streaming kernel, 4 = fire modules and the pools behind them stay apart, 5 = no fire-module chains, 6 = chains on
- * the late (small) maps only, 7 = a run's first module as squeeze conv + chain launch instead of one streaming launch. */
+ * the late (small) maps only, 7 = a run's first module as squeeze conv + chain launch instead of one streaming launch,
+ * 8 = no streaming expand + next-squeeze launches (a pooled module then ends its run). */
 int sqdet_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------ conv --
@@ -154,6 +155,14 @@ int sqdet_fire_squeeze_next_fwd(const void* x, const void* w_s, const float* b_s
                                 const void* w_e3, const float* b_e3, const void* w_next_s, const float* b_next_s, void* sq_out,
                                 int n, int h, int w, int cin, int s1x1, int e1x1, int e3x3, int next_s1x1, int dtype,
                                 sqdet_stream_t stream);
+
+/* The expand half of a module from its squeeze tensor (+ max_pool 3x3/s2/SAME when pool != 0) whose output is the NEXT
+ * module's squeeze tensor sq_out [n, h', w', next_s1x1] (h', w' = pooled dims when pool): fire3+pool3 -> fire4's squeeze,
+ * fire4 -> fire5's, fire5+pool5 -> fire6's (nets/squeezeDet.py:49-58).  Bitwise sqdet_fire_expand_fwd + the squeeze conv. */
+int sqdet_fire_expand_squeeze_next_supported(int s1x1, int e1x1, int e3x3, int next_s1x1, int pool, int dtype);
+int sqdet_fire_expand_squeeze_next_fwd(const void* sq_in, const void* w_e1, const float* b_e1, const void* w_e3, const float* b_e3,
+                                       const void* w_next_s, const float* b_next_s, void* sq_out, int n, int h, int w, int s1x1,
+                                       int e1x1, int e3x3, int next_s1x1, int pool, int dtype, sqdet_stream_t stream);
 
 /* Fire-module CHAIN (float16): the expand half of one fire module and the squeeze of the NEXT module in one launch.
  * Replaces, for consecutive fire modules on one feature map (fire6 .. fire11, nets/squeezeDet.py:58-69), the pair

@@ -36,6 +36,8 @@ SIGNATURES = {
     "sqdet_fire_expand_fwd": (ci, [vp] * 6 + [ci] * 8 + [vp]),
     "sqdet_fire_squeeze_next_supported": (ci, [ci] * 6),
     "sqdet_fire_squeeze_next_fwd": (ci, [vp] * 10 + [ci] * 9 + [vp]),
+    "sqdet_fire_expand_squeeze_next_supported": (ci, [ci] * 6),
+    "sqdet_fire_expand_squeeze_next_fwd": (ci, [vp] * 8 + [ci] * 9 + [vp]),
     "sqdet_fire_chain_stream_bytes": (sz, [ci] * 5),
     "sqdet_fire_chain_pack": (ci, [vp] * 4 + [ci] * 5 + [vp]),
     "sqdet_fire_chain_fwd": (ci, [vp] * 7 + [ci] * 8 + [vp]),

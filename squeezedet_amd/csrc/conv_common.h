@@ -102,6 +102,10 @@ bool fire_squeeze_next_eligible(int cin, int s, int e1, int e3, int s2, int dtyp
 int fire_squeeze_next_launch(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
                              const float* b3, const void* ws2, const float* bs2, void* s_out, int n, int h, int w, int cin,
                              int s, int e1, int e3, int s2, int dtype, hipStream_t st, bool* handled);
+bool fire_expand_squeeze_next_eligible(int s, int e1, int e3, int s2, int pool, int dtype);
+int fire_expand_squeeze_next_launch(const void* sq_in, const void* w1, const float* b1, const void* w3, const float* b3,
+                                    const void* ws2, const float* bs2, void* s_out, int n, int h, int w, int s, int e1, int e3,
+                                    int s2, int pool, int dtype, hipStream_t st, bool* handled);
 int conv3x3_tile_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);
 int conv1x1_stream_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);
 

@@ -101,14 +101,15 @@ struct FireSArgs {
 // phase A is a copy -- the prefetched 16-byte pieces go straight into the LDS squeeze tile (out-of-image pieces and the
 // channel padding arrive as zeros: exactly the SAME padding of the squeeze tensor) -- and the module reads 32-64 bytes
 // per pixel instead of 128-256 (NCHX = 1, NTS unused).
-// NTS2 > 0 (not with POOL): the module's concat tensor is NOT written; the tile's rounded float16 results go to an LDS
+// NTS2 > 0: the module's concat tensor (POOL: its pooled form) is NOT written; the tile's rounded float16 results go to an LDS
 // tile in the B-fragment layout of the NEXT module's squeeze1x1 (lane group g of cout pair cp holds piece g of K chunk
 // coff/32 + cp), and after one more barrier the waves run that squeeze on the tile's 128 pixels (16-pixel block x NTS2
 // cout tiles per wave, chunks in ascending concat-channel order = the canonical accumulation order) and write the
-// S2-channel squeeze tensor: 32-64 bytes per pixel leave the kernel instead of 256-512.
+// S2-channel squeeze tensor: 32-96 bytes per pixel leave the kernel instead of 256-512.  (POOL: the tile's 4 x 7 pooled
+// pixels fill two 16-pixel blocks, the last four positions unused.)
 template <typename T, int NCHX, int NTS, int NWAVES, int PF, bool POOL, int RS, bool PAIR = false, bool SQIN = false, int NTS2 = 0>
 __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs a) {   // 2 waves per SIMD: 256 VGPRs
-  static_assert(NTS2 == 0 || !POOL, "the squeeze-out form has no pooled variant");
+  static_assert(NTS2 == 0 || sizeof(T) == 2, "the squeeze-out form is float16 only");
   constexpr int KG = Tr<T>::KG;
   constexpr int NT3 = PAIR ? 5 : 9;                  // K-steps of the expand3x3
   constexpr int KC = 4 * KG;
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
   unsigned char* w1l = wsl + NCHX * NTS * 1024;      // expand1x1 weights [E/16 tiles][64 lanes][16 B]
   constexpr int NQC = NG * 4;                         // 64-byte K chunks of the concat tensor (2E / 32 channels)
   unsigned char* ctile = w1l + NG * 4 * 1024;         // NTS2: [NQC chunks][128 pixels][4 x 16 B swizzled]
-  unsigned char* ws2l = ctile + (NTS2 ? NQC * 128 * 64 : 0);   // NTS2: next squeeze weights [NQC][NTS2][64 lanes][16 B]
+  constexpr int CPIX = POOL ? 32 : 128;               // pixels of the concat tile
+  unsigned char* ws2l = ctile + (NTS2 ? NQC * CPIX * 64 : 0);   // NTS2: next squeeze weights [NQC][NTS2][64 lanes][16 B]
   float* bl = reinterpret_cast<float*>(ws2l + (NTS2 ? NQC * NTS2 * 1024 : 0));   // biases [b1 | b3 | bs | bs2]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // in an SGPR: what follows from it is wave-uniform
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
     if constexpr (NTS2 > 0) {
       const i32x4* src2 = reinterpret_cast<const i32x4*>(a.ws2);
       for (int i = threadIdx.x; i < NQC * NTS2 * 64; i += NWAVES * 64) reinterpret_cast<i32x4*>(ws2l)[i] = src2[i];
-      for (int i = threadIdx.x; i < a.S2; i += NWAVES * 64) bl[2 * a.E + a.S + i] = a.bs2[i];
+      for (int i = threadIdx.x; i < a.S2; i += NWAVES * 64) bl[2 * a.E + a.S + i] = a.bs2[i];   // (behind the unused bs slot when SQIN)
     }
     // channel padding of the squeeze tile (S*sizeof(T) < 64 bytes) is zero in both buffers, forever
     const int s_pieces = a.S * (int)sizeof(T) / 16;
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
           if constexpr (NTS2 > 0) {
             const f16x8 h = {(f16)v[0][0], (f16)v[0][1], (f16)v[0][2], (f16)v[0][3], (f16)v[1][0], (f16)v[1][1], (f16)v[1][2], (f16)v[1][3]};
             const int PLc = (m0 + m) * SCOLS + j;
-            *reinterpret_cast<i32x4*>(ctile + (coff / 32 + cp) * (128 * 64) + PLc * 64 + ((g ^ ((PLc >> 1) & 3)) << 4)) = __builtin_bit_cast(i32x4, h);
+            *reinterpret_cast<i32x4*>(ctile + (coff / 32 + cp) * (CPIX * 64) + PLc * 64 + ((g ^ ((PLc >> 1) & 3)) << 4)) = __builtin_bit_cast(i32x4, h);
           } else if constexpr (sizeof(T) == 2) {
             const f16x8 h = {(f16)v[0][0], (f16)v[0][1], (f16)v[0][2], (f16)v[0][3], (f16)v[1][0], (f16)v[1][1], (f16)v[1][2], (f16)v[1][3]};
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, h), ry, off, 0, 0);
@@ -397,6 +399,14 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
             const unsigned int s1 = (unsigned int)__builtin_amdgcn_update_dpp((int)NEG, (int)vm, 0x101, 0xf, 0xf, false);
             const unsigned int s2 = (unsigned int)__builtin_amdgcn_update_dpp((int)NEG, (int)vm, 0x102, 0xf, 0xf, false);
             o[r] = pmax<T>(pmax<T>(vm, pmax<T>(s1, s2)), 0u);        // 0u = +0.0 (packed): the ReLU
+          }
+          if constexpr (NTS2 > 0) {
+            if ((j & 1) == 0 && j <= 12) {          // pooled pixel (row rq*NQ + q, column j/2) of the tile's 4 x 7
+              const int PLc = (rq * NQ + q) * 7 + (j >> 1);
+              *reinterpret_cast<i32x4*>(ctile + (coff / 32 + cp) * (CPIX * 64) + PLc * 64 + ((g ^ ((PLc >> 1) & 3)) << 4)) =
+                  i32x4{(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
+            }
+            continue;
           }
           const unsigned off = (lane_ok && pr < a.Hp)
               ? (unsigned)(((((n * a.Hp + pr) * a.Wp + pc) * ctot) + coff + cb) * (int)sizeof(T)) : OOB;
@@ -495,26 +505,36 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
     if constexpr (NTS2 > 0) {
       // ---------------- phase C: the next module's squeeze1x1 on the tile (tile row = one 16-pixel block) ----------------
       __syncthreads();                                    // the whole concat tile is in LDS
-      constexpr int BPW = 8 / NWAVES;                     // pixel blocks (tile rows) per wave
+      constexpr int NBLK = POOL ? 2 : 8;                  // 16-pixel blocks of the concat tile (POOL: 28 pooled pixels)
       T* so = reinterpret_cast<T*>(a.s_out);
 #pragma unroll
-      for (int bb = 0; bb < BPW; ++bb) {
-        const int row = wave * BPW + bb;
+      for (int bb = 0; bb < (NBLK + NWAVES - 1) / NWAVES; ++bb) {
+        const int blk = wave + bb * NWAVES;
+        if (blk >= NBLK) break;
         f32x4 acc2[NTS2];
 #pragma unroll
         for (int t = 0; t < NTS2; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int PLc = row * SCOLS + j;
+        const int PLc = blk * SCOLS + j;
         const unsigned char* cb0 = ctile + PLc * 64 + ((g ^ ((PLc >> 1) & 3)) << 4);
 #pragma unroll
         for (int q = 0; q < NQC; ++q) {
-          const i32x4 bfq = *reinterpret_cast<const i32x4*>(cb0 + q * (128 * 64));
+          const i32x4 bfq = *reinterpret_cast<const i32x4*>(cb0 + q * (CPIX * 64));
 #pragma unroll
           for (int t = 0; t < NTS2; ++t)
             mma16<T>(acc2[t], *reinterpret_cast<const i32x4*>(ws2l + ((q * NTS2 + t) * 64 + lane) * 16), bfq);
         }
-        const int oy = oy0 + row;
-        if (oy < a.H && ox < a.W) {
-          T* dst = so + ((size_t)(n * a.H + oy) * a.W + ox) * a.S2 + g * 4 * NTS2;
+        int orow, ocol, OH, OW;
+        bool ok;
+        if constexpr (POOL) {
+          const int prow = PLc / 7, pcol = PLc - prow * 7;
+          orow = ty * 4 + prow; ocol = tx * 7 + pcol; OH = a.Hp; OW = a.Wp;
+          ok = PLc < 28 && orow < OH && ocol < OW;
+        } else {
+          orow = oy0 + blk; ocol = ox; OH = a.H; OW = a.W;
+          ok = orow < OH && ocol < OW;
+        }
+        if (ok) {
+          T* dst = so + ((size_t)(n * OH + orow) * OW + ocol) * a.S2 + g * 4 * NTS2;
 #pragma unroll
           for (int t = 0; t < NTS2; ++t) {
             f32x4 v = acc2[t] + *reinterpret_cast<const f32x4*>(bl + 2 * a.E + a.S + g * 4 * NTS2 + t * 4);
@@ -672,21 +692,57 @@ bool fire_squeeze_next_eligible(int cin, int s, int e1, int e3, int s2, int dtyp
   return (nchx == 2 && nts == 1 && nwaves == 4 && s == 16 && s2 == 16) || (nchx == 4 && nts == 2 && nwaves == 8 && s2 == 32);
 }
 
-template <int NCHX, int NTS, int NWAVES, bool PAIR, int NTS2>
+template <int NCHX, int NTS, int NWAVES, bool PAIR, int NTS2, bool POOL = false, bool SQIN = false>
 static int launch_stream_sq(const FireSArgs& a, hipStream_t st) {
   constexpr int NQ = (NWAVES / 2 / 2) * 4;
-  const size_t lds = 2 * (size_t)Geo<false>::TILE + (size_t)NCHX * NTS * 1024 + (size_t)(NWAVES / 2 / 2) * 4 * 1024 +
-                     (size_t)NQ * 128 * 64 + (size_t)NQ * NTS2 * 1024 + (size_t)(2 * a.E + a.S + a.S2) * 4;
+  const size_t lds = 2 * (size_t)Geo<POOL>::TILE + (size_t)NCHX * NTS * 1024 + (size_t)(NWAVES / 2 / 2) * 4 * 1024 +
+                     (size_t)NQ * (POOL ? 32 : 128) * 64 + (size_t)NQ * NTS2 * 1024 + (size_t)(2 * a.E + a.S + a.S2) * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    SQDET_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_stream<f16, NCHX, NTS, NWAVES, 2, false, 2, PAIR, false, NTS2>),
+    SQDET_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_stream<f16, NCHX, NTS, NWAVES, 2, POOL, 2, PAIR, SQIN, NTS2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
   int grid = 256 * (8 / NWAVES);
   if (grid > (a.ntiles + 7) / 8 * 8) grid = (a.ntiles + 7) / 8 * 8;
-  hipLaunchKernelGGL((fire_stream<f16, NCHX, NTS, NWAVES, 2, false, 2, PAIR, false, NTS2>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
+  hipLaunchKernelGGL((fire_stream<f16, NCHX, NTS, NWAVES, 2, POOL, 2, PAIR, SQIN, NTS2>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
   SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
+// the expand half of a module from its squeeze tensor (+ its pool) emitting the NEXT module's squeeze tensor -- SqueezeDet's
+// fire3+pool3 -> fire4's squeeze, fire4 -> fire5's, fire5+pool5 -> fire6's
+bool fire_expand_squeeze_next_eligible(int s, int e1, int e3, int s2, int pool, int dtype) {
+  if (!fire_expand_stream_eligible(s, e1, e3, dtype)) return false;
+  return (s == 16 && e1 == 64 && s2 == 32 && pool) || (s == 32 && e1 == 128 && s2 == 32 && !pool) || (s == 32 && e1 == 128 && s2 == 48 && pool);
+}
+
+int fire_expand_squeeze_next_launch(const void* sq_in, const void* w1, const float* b1, const void* w3, const float* b3,
+                                    const void* ws2, const float* bs2, void* s_out, int n, int h, int w, int s, int e1, int e3,
+                                    int s2, int pool, int dtype, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (!fire_expand_squeeze_next_eligible(s, e1, e3, s2, pool, dtype)) return SQDET_OK;
+  FireSArgs a;
+  a.x = sq_in; a.y = nullptr; a.ws = nullptr; a.w1 = w1; a.w3 = w3; a.bs = nullptr; a.b1 = b1; a.b3 = b3;
+  a.ws2 = ws2; a.bs2 = bs2; a.s_out = s_out; a.S2 = s2;
+  a.N = n; a.H = h; a.W = w; a.Cin = s; a.S = s; a.E = e1;
+  a.Hp = out_size(h, 3, 2, SQDET_PAD_SAME); a.Wp = out_size(w, 3, 2, SQDET_PAD_SAME);
+  a.ptp = pad_before(h, 3, 2, SQDET_PAD_SAME); a.plp = pad_before(w, 3, 2, SQDET_PAD_SAME);
+  if (pool) { a.tiles_x = (a.Wp + 6) / 7; a.tiles_y = (a.Hp + 3) / 4; }
+  else { a.tiles_x = (w + SCOLS - 1) / SCOLS; a.tiles_y = (h + 7) / 8; }
+  const long nt = (long)n * a.tiles_x * a.tiles_y;
+  if (nt > 0x3fffffffL) return SQDET_OK;
+  a.ntiles = (int)nt;
+  a.x_pieces = s * 2 / 16;
+  const long xb = (long)n * h * w * s * 2;
+  if (xb >= (1L << 31)) return SQDET_OK;
+  a.x_bytes = (unsigned)xb; a.y_bytes = 0;
+  int rc;
+  if (s == 16) rc = launch_stream_sq<1, 1, 4, true, 2, true, true>(a, st);
+  else if (!pool) rc = launch_stream_sq<1, 1, 8, false, 2, false, true>(a, st);
+  else rc = launch_stream_sq<1, 1, 8, false, 3, true, true>(a, st);
+  if (rc != SQDET_OK) return rc;
+  *handled = true;
   return SQDET_OK;
 }
 

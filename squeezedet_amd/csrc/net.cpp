@@ -34,6 +34,10 @@ int fire_stream_launch_ex(const void* x, const void* ws, const float* bs, const 
 bool fire_chain_eligible(int s, int e1, int e3, int s2, int dtype);
 bool fire_expand_stream_eligible(int s, int e1, int e3, int dtype);
 bool fire_squeeze_next_eligible(int cin, int s, int e1, int e3, int s2, int dtype);
+bool fire_expand_squeeze_next_eligible(int s, int e1, int e3, int s2, int pool, int dtype);
+int fire_expand_squeeze_next_launch(const void* sq_in, const void* w1, const float* b1, const void* w3, const float* b3,
+                                    const void* ws2, const float* bs2, void* s_out, int n, int h, int w, int s, int e1, int e3,
+                                    int s2, int pool, int dtype, hipStream_t st, bool* handled);
 int fire_squeeze_next_launch(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
                              const float* b3, const void* ws2, const float* bs2, void* s_out, int n, int h, int w, int cin,
                              int s, int e1, int e3, int s2, int dtype, hipStream_t st, bool* handled);
@@ -52,7 +56,8 @@ enum { BUF_INPUT = -1, BUF_PREDS = -2, BUF_A = 0, BUF_B = 1, BUF_S = 2, BUF_T = 
 // L_CHAIN: both expands of a fire module + the squeeze of the NEXT module in one launch (sqdet_fire_chain_fwd)
 // L_EXPAND: both expands of a fire module from its squeeze tensor (+ the max-pool behind it): sqdet_fire_expand_fwd
 // L_FIRESQ: a whole fire module from x whose output is the NEXT module's squeeze tensor (sqdet_fire_squeeze_next_fwd)
-enum { L_CONV = 0, L_POOL = 1, L_STEM = 2, L_FIRE = 3, L_CHAIN = 4, L_EXPAND = 5, L_FIRESQ = 6 };
+// L_EXPSQ: both expands (+ pool) of a module from its squeeze tensor, output = the NEXT module's squeeze tensor
+enum { L_CONV = 0, L_POOL = 1, L_STEM = 2, L_FIRE = 3, L_CHAIN = 4, L_EXPAND = 5, L_FIRESQ = 6, L_EXPSQ = 7 };
 
 struct Param {
   std::string name;
@@ -304,6 +309,15 @@ int run_layer_part(sqdet_net* net, const Layer& L, const void* input, void* pred
                                        pb(L.bp_s2), out, nb, L.h, L.w, L.cin, L.fs, L.fe1, L.fe3, L.fs2, net->dtype,
                                        reinterpret_cast<sqdet_stream_t>(st));
   }
+  if (L.type == L_EXPSQ) {
+    const char* sq_in = reinterpret_cast<const char*>(buf_ptr(net, L.in_buf, input, preds)) + (size_t)n0 * L.h * L.w * L.fs * esz;
+    char* out = reinterpret_cast<char*>(buf_ptr(net, L.out_buf, input, preds)) + (size_t)n0 * L.ho * L.wo * L.fs2 * esz;
+    auto pk = [&](int i) { return (const void*)(net->param_mem + net->params[i].offset); };
+    auto pb = [&](int i) { return reinterpret_cast<const float*>(net->param_mem + net->params[i].offset); };
+    return sqdet_fire_expand_squeeze_next_fwd(sq_in, pk(L.kp_1), pb(L.bp_1), pk(L.kp_3), pb(L.bp_3), pk(L.kp_s2), pb(L.bp_s2), out, nb,
+                                              L.h, L.w, L.fs, L.fe1, L.fe3, L.fs2, L.fire_pool, net->dtype,
+                                              reinterpret_cast<sqdet_stream_t>(st));
+  }
   if (L.type == L_EXPAND) {
     const char* sq_in = reinterpret_cast<const char*>(buf_ptr(net, L.in_buf, input, preds)) + (size_t)n0 * L.h * L.w * L.fs * esz;
     char* out = reinterpret_cast<char*>(buf_ptr(net, L.out_buf, input, preds)) + (size_t)n0 * L.ho * L.wo * (L.fe1 + L.fe3) * esz;
@@ -449,103 +463,127 @@ void fuse_fire_pools(sqdet_net* net, size_t esz) {
   }
 }
 
-// Runs of fire modules on ONE feature map (SqueezeDet: fire2-3, fire4-5, fire6 .. fire11; nets/squeezeDet.py:46-69): the
-// only reader of a module's concat tensor is the next module's squeeze1x1, so a run becomes
-//   squeeze1x1 of the first module  ->  [expand of module i + squeeze of module i+1] ...  ->  expand of the last module
-// and only 16-96-channel squeeze tensors travel between the launches (sqdet_fire_chain_fwd; float16).  The last module
-// keeps its pool when it has one (fire3+pool3, fire5+pool5: sqdet_fire_expand_fwd from the squeeze tensor).
-// "fire_fuse" = 5 keeps the one-launch-per-module form, 6 chains the late (<= 100000 pixel) maps only.
+// Runs of consecutive fire modules (SqueezeDet: fire2 .. fire11, nets/squeezeDet.py:46-69): the only reader of a module's
+// concat tensor -- pooled or not -- is the next module's squeeze1x1, so inside a run only 16-96-channel SQUEEZE tensors
+// travel between the launches (float16).  Per member, by what covers its shape:
+//   first module (input x):   one streaming launch, whole module + next squeeze (L_FIRESQ)  |  squeeze conv, then as below
+//   module from its squeeze:  streaming launch expand (+ pool) + next squeeze (L_EXPSQ: one-chunk squeezes)
+//                             |  ring chain launch expand + next squeeze (L_CHAIN; no pool)
+//   last module:              expand + pool from the squeeze tensor (L_EXPAND)  |  chain launch writing the concat tensor
+// "fire_fuse" = 5 keeps one launch per module, 6 chains the late (<= 100000 pixel) maps only, 7 never uses L_FIRESQ,
+// 8 never uses L_EXPSQ (a pooled module then ends its run).
 void fuse_chains(sqdet_net* net, size_t esz) {
   if (conv_algo() != 0 || tune(3) == 2 || tune(3) == 5) return;
   const std::vector<Layer> in = net->layers;
   std::vector<Layer> out;
+  const int dt = net->dtype;
+  auto base = [](const Layer& f) { return f.name.substr(0, f.name.find('+')); };
+  // how member k of a run could run when it has a successor (0 = it cannot: the run ends before / at it)
+  auto mid_impl = [&](const Layer& f, const Layer& nx, bool first) -> int {
+    if (first && tune(3) != 7 && !f.fire_pool && fire_squeeze_next_eligible(f.cin, f.fs, f.fe1, f.fe3, nx.fs, dt)) return L_FIRESQ;
+    if (tune(3) != 8 && fire_expand_squeeze_next_eligible(f.fs, f.fe1, f.fe3, nx.fs, f.fire_pool, dt)) return L_EXPSQ;
+    if (!f.fire_pool && fire_chain_eligible(f.fs, f.fe1, f.fe3, nx.fs, dt)) return L_CHAIN;
+    return 0;
+  };
+  auto last_impl = [&](const Layer& f) -> int {
+    if (f.fire_pool) return fire_expand_stream_eligible(f.fs, f.fe1, f.fe3, dt) ? L_EXPAND : 0;
+    return fire_chain_eligible(f.fs, f.fe1, f.fe3, 0, dt) ? L_CHAIN : 0;
+  };
   for (size_t i = 0; i < in.size();) {
-    size_t j = i;
-    auto chainable = [&](size_t k) {
-      return k < in.size() && in[k].type == L_FIRE && in[k].h == in[i].h && in[k].w == in[i].w &&
-             (tune(3) != 6 || (long)net->batch * in[k].h * in[k].w <= 100000) && (k == i || (in[k].in_buf == in[k - 1].out_buf && !in[k - 1].fire_pool));
+    if (in[i].type != L_FIRE) { out.push_back(in[i]); ++i; continue; }
+    // candidate run: consecutive fire modules, each reading its predecessor's (possibly pooled) output
+    size_t j = i + 1;
+    while (j < in.size() && in[j].type == L_FIRE && in[j].in_buf == in[j - 1].out_buf && in[j].h == in[j - 1].ho && in[j].w == in[j - 1].wo) ++j;
+    if (tune(3) == 6) {   // late maps only
+      if ((long)net->batch * in[i].h * in[i].w > 100000) { out.push_back(in[i]); ++i; continue; }
+    }
+    // longest prefix [i, e) every member of which has an implementation and whose final member is implemented as a LAST one
+    size_t e = i;
+    std::vector<int> impl;
+    bool ended_with_last = false;
+    for (size_t k = i; k < j; ++k) {
+      const int mi = k + 1 < j ? mid_impl(in[k], in[k + 1], k == i) : 0;
+      if (mi) { impl.push_back(mi); e = k + 1; continue; }
+      const int li = last_impl(in[k]);     // k ends the run: the candidate's last member, or nothing carries it further
+      if (li) { impl.push_back(li); e = k + 1; ended_with_last = true; }
+      break;
+    }
+    while (!impl.empty() && !ended_with_last) {   // the successor of a "mid" member cannot run at all: that member ends the run
+      const int li = last_impl(in[e - 1]);
+      if (li) { impl.back() = li; ended_with_last = true; }
+      else { impl.pop_back(); --e; }
+    }
+    if (e - i < 2) { out.push_back(in[i]); ++i; continue; }
+    int sbuf = BUF_S;      // where the current member's squeeze tensor lives
+    auto note_s = [&](const Layer& f, int ch, bool pooled) {
+      const size_t el = (size_t)net->batch * (pooled ? f.ho : f.h) * (pooled ? f.wo : f.w) * (size_t)ch;
+      if (el > net->buf_elems[BUF_S]) net->buf_elems[BUF_S] = el;
+      if (el > net->buf_elems[BUF_T]) net->buf_elems[BUF_T] = el;
     };
-    while (chainable(j)) ++j;
-    // every member must be covered with its successor's squeeze; the last one by the expand-only chain form, or -- with
-    // a pool behind it -- by the streaming kernel's squeeze-tensor form
-    bool ok = j - i >= 2;
-    for (size_t k = i; ok && k < j; ++k) {
-      if (k + 1 < j) ok = fire_chain_eligible(in[k].fs, in[k].fe1, in[k].fe3, in[k + 1].fs, net->dtype);
-      else ok = in[k].fire_pool ? fire_expand_stream_eligible(in[k].fs, in[k].fe1, in[k].fe3, net->dtype)
-                                : fire_chain_eligible(in[k].fs, in[k].fe1, in[k].fe3, 0, net->dtype);
-    }
-    if (!ok) { out.push_back(in[i]); ++i; continue; }
-    const double npix = (double)net->batch * in[i].h * in[i].w;
-    // the first module in ONE launch from x where the streaming kernel covers it (fire2, fire4): its squeeze, its expands
-    // and the second module's squeeze -- "fire_fuse" = 7 keeps squeeze conv + chain launch
-    size_t kfirst = i;
-    int sbuf0 = BUF_S;
-    if (tune(3) != 7 && !in[i].fire_pool && fire_squeeze_next_eligible(in[i].cin, in[i].fs, in[i].fe1, in[i].fe3, in[i + 1].fs, net->dtype)) {
-      const Layer& f = in[i];
-      Layer c = f;
-      c.type = L_FIRESQ;
-      c.fs2 = in[i + 1].fs; c.kp_s2 = in[i + 1].kp_s; c.bp_s2 = in[i + 1].bp_s;
-      c.out_buf = BUF_S;
-      c.name = f.name + "+" + in[i + 1].name.substr(0, in[i + 1].name.find('+')) + "/squeeze1x1";
-      c.flops = f.flops + 2.0 * (f.fe1 + f.fe3) * c.fs2 * npix;
-      c.bytes = (npix * f.cin + npix * c.fs2 + (double)f.cin * f.fs + (double)f.fs * f.fe1 + 9.0 * f.fs * f.fe3 +
-                 (double)(f.fe1 + f.fe3) * c.fs2) * (double)esz + 4.0 * (f.fs + f.fe1 + f.fe3 + c.fs2);
-      const size_t selems = (size_t)net->batch * f.h * f.w * (size_t)c.fs2;
-      if (selems > net->buf_elems[BUF_S]) net->buf_elems[BUF_S] = selems;
-      if (selems > net->buf_elems[BUF_T]) net->buf_elems[BUF_T] = selems;
-      out.push_back(c);
-      kfirst = i + 1;
-    }
-    Layer sq = in[i];   // the first module's squeeze as a plain conv
-    sq.type = L_CONV;
-    sq.fire_pool = 0;
-    sq.name = in[i].name.substr(0, in[i].name.find('+')) + "/squeeze1x1";
-    sq.out_buf = BUF_S;
-    sq.cout = in[i].fs; sq.k = 1; sq.stride = 1; sq.pad_mode = SQDET_PAD_SAME; sq.relu = 1;
-    sq.ho = in[i].h; sq.wo = in[i].w;
-    sq.y_cstride = in[i].fs; sq.y_coffset = 0;
-    sq.kparam = in[i].kp_s; sq.bparam = in[i].bp_s;
-    sq.flops = 2.0 * in[i].cin * in[i].fs * npix;
-    sq.bytes = (npix * in[i].cin + npix * in[i].fs + (double)in[i].cin * in[i].fs) * (double)esz + 4.0 * in[i].fs;
-    if (kfirst == i) out.push_back(sq);
-    int sbuf = sbuf0;
-    for (size_t k = kfirst; k < j; ++k) {
+    for (size_t k = i; k < e; ++k) {
       const Layer& f = in[k];
-      const bool last = k + 1 == j;
-      const std::string fname = f.name.substr(0, f.name.find('+'));
-      Layer c = f;
-      c.in_buf = sbuf;
-      const size_t selems_in = (size_t)net->batch * f.h * f.w * (size_t)f.fs;
-      if (selems_in > net->buf_elems[BUF_S]) net->buf_elems[BUF_S] = selems_in;
-      if (selems_in > net->buf_elems[BUF_T]) net->buf_elems[BUF_T] = selems_in;
-      if (last && f.fire_pool) {
-        c.type = L_EXPAND;     // expand + pool from the squeeze tensor; out_buf / ho / wo stay the fused layer's
-        c.name = fname + "/expand" + f.name.substr(f.name.find('+'));
-        c.flops = (2.0 * f.fs * f.fe1 + 18.0 * f.fs * f.fe3) * npix;
-        c.bytes = (npix * f.fs + (double)net->batch * f.ho * f.wo * (f.fe1 + f.fe3) + (double)f.fs * f.fe1 + 9.0 * f.fs * f.fe3) *
-                      (double)esz + 4.0 * (f.fe1 + f.fe3);
-        out.push_back(c);
-        break;
+      const bool last = k + 1 == e;
+      const int im = impl[k - i];
+      const double npix = (double)net->batch * f.h * f.w;
+      const double npix_out = (double)net->batch * f.ho * f.wo;
+      const double wexp = (double)f.fs * f.fe1 + 9.0 * f.fs * f.fe3;
+      if (k == i && im != L_FIRESQ) {     // the first module's squeeze as a plain conv
+        Layer sq = f;
+        sq.type = L_CONV;
+        sq.fire_pool = 0;
+        sq.name = base(f) + "/squeeze1x1";
+        sq.out_buf = BUF_S;
+        sq.cout = f.fs; sq.k = 1; sq.stride = 1; sq.pad_mode = SQDET_PAD_SAME; sq.relu = 1;
+        sq.ho = f.h; sq.wo = f.w;
+        sq.y_cstride = f.fs; sq.y_coffset = 0;
+        sq.kparam = f.kp_s; sq.bparam = f.bp_s;
+        sq.flops = 2.0 * f.cin * f.fs * npix;
+        sq.bytes = (npix * f.cin + npix * f.fs + (double)f.cin * f.fs) * (double)esz + 4.0 * f.fs;
+        note_s(f, f.fs, false);
+        out.push_back(sq);
       }
-      c.type = L_CHAIN;
-      c.fs2 = last ? 0 : in[k + 1].fs;
+      Layer c = f;
+      c.type = im;
+      const int fs2 = last ? 0 : in[k + 1].fs;
+      c.fs2 = fs2;
       c.kp_s2 = last ? -1 : in[k + 1].kp_s;
       c.bp_s2 = last ? -1 : in[k + 1].bp_s;
+      const std::string nxs = last ? std::string() : "+" + base(in[k + 1]) + "/squeeze1x1";
+      const std::string pool_s = f.fire_pool ? f.name.substr(f.name.find('+')) : std::string();
+      if (im == L_FIRESQ) {
+        c.out_buf = BUF_S;
+        c.name = base(f) + nxs;
+        c.flops = f.flops + 2.0 * (f.fe1 + f.fe3) * fs2 * npix;
+        c.bytes = (npix * f.cin + npix * fs2 + (double)f.cin * f.fs + wexp + (double)(f.fe1 + f.fe3) * fs2) * (double)esz +
+                  4.0 * (f.fs + f.fe1 + f.fe3 + fs2);
+        note_s(f, fs2, false);
+        out.push_back(c);
+        sbuf = BUF_S;
+        continue;
+      }
+      c.in_buf = sbuf;
+      if (im == L_EXPAND) {     // (last member with a pool: its pooled concat tensor goes where the fused layer's went)
+        c.name = base(f) + "/expand" + pool_s;
+        c.flops = (2.0 * f.fs * f.fe1 + 18.0 * f.fs * f.fe3) * npix;
+        c.bytes = (npix * f.fs + npix_out * (f.fe1 + f.fe3) + wexp) * (double)esz + 4.0 * (f.fe1 + f.fe3);
+        out.push_back(c);
+        continue;
+      }
       c.out_buf = last ? f.out_buf : (sbuf == BUF_S ? BUF_T : BUF_S);
-      c.name = last ? fname + "/expand" : fname + "/expand+" + in[k + 1].name.substr(0, in[k + 1].name.find('+')) + "/squeeze1x1";
-      c.flops = (2.0 * f.fs * f.fe1 + 18.0 * f.fs * f.fe3 + 2.0 * (f.fe1 + f.fe3) * c.fs2) * npix;
+      c.name = base(f) + "/expand" + pool_s + nxs;
+      c.flops = (2.0 * f.fs * f.fe1 + 18.0 * f.fs * f.fe3) * npix + 2.0 * (f.fe1 + f.fe3) * fs2 * npix_out;
       // algorithmic bytes: squeeze tensor in + (next squeeze tensor | concat tensor) out + the weights
-      c.bytes = (npix * f.fs + npix * (last ? f.fe1 + f.fe3 : c.fs2) + (double)f.fs * f.fe1 + 9.0 * f.fs * f.fe3 +
-                 (double)(f.fe1 + f.fe3) * c.fs2) * (double)esz + 4.0 * (f.fe1 + f.fe3 + c.fs2);
-      c.chain_off = net->param_bytes;
-      net->param_bytes = align_up(net->param_bytes + sqdet_fire_chain_stream_bytes(f.fs, f.fe1, f.fe3, c.fs2, net->dtype), 256);
-      const size_t selems = (size_t)net->batch * f.h * f.w * (size_t)c.fs2;
-      if (selems > net->buf_elems[BUF_S]) net->buf_elems[BUF_S] = selems;
-      if (selems > net->buf_elems[BUF_T]) net->buf_elems[BUF_T] = selems;
+      c.bytes = (npix * f.fs + npix_out * (last ? f.fe1 + f.fe3 : fs2) + wexp + (double)(f.fe1 + f.fe3) * fs2) * (double)esz +
+                4.0 * (f.fe1 + f.fe3 + fs2);
+      if (im == L_CHAIN) {
+        c.chain_off = net->param_bytes;
+        net->param_bytes = align_up(net->param_bytes + sqdet_fire_chain_stream_bytes(f.fs, f.fe1, f.fe3, fs2, dt), 256);
+      }
+      if (!last) note_s(f, fs2, f.fire_pool != 0);
       out.push_back(c);
       sbuf = c.out_buf;
     }
-    i = j;
+    i = e;
   }
   net->layers.swap(out);
 }
@@ -877,4 +915,21 @@ extern "C" int sqdet_fire_squeeze_next_fwd(const void* x, const void* w_s, const
 
 extern "C" int sqdet_fire_squeeze_next_supported(int cin, int s1x1, int e1x1, int e3x3, int next_s1x1, int dtype) {
   return fire_squeeze_next_eligible(cin, s1x1, e1x1, e3x3, next_s1x1, dtype) ? 1 : 0;
+}
+
+extern "C" int sqdet_fire_expand_squeeze_next_supported(int s1x1, int e1x1, int e3x3, int next_s1x1, int pool, int dtype) {
+  return fire_expand_squeeze_next_eligible(s1x1, e1x1, e3x3, next_s1x1, pool, dtype) ? 1 : 0;
+}
+
+extern "C" int sqdet_fire_expand_squeeze_next_fwd(const void* sq_in, const void* w_e1, const float* b_e1, const void* w_e3,
+                                                  const float* b_e3, const void* w_next_s, const float* b_next_s, void* sq_out,
+                                                  int n, int h, int w, int s1x1, int e1x1, int e3x3, int next_s1x1, int pool,
+                                                  int dtype, sqdet_stream_t stream) {
+  SQDET_REQUIRE(sq_in && w_e1 && b_e1 && w_e3 && b_e3 && w_next_s && b_next_s && sq_out, "fire_expand_squeeze_next_fwd: null pointer");
+  bool handled = false;
+  const int rc = fire_expand_squeeze_next_launch(sq_in, w_e1, b_e1, w_e3, b_e3, w_next_s, b_next_s, sq_out, n, h, w, s1x1, e1x1, e3x3,
+                                                 next_s1x1, pool, dtype, as_stream(stream), &handled);
+  if (rc != SQDET_OK) return rc;
+  SQDET_UNSUPPORTED(!handled, "fire_expand_squeeze_next_fwd: shape not covered (see sqdet_fire_expand_squeeze_next_supported)");
+  return SQDET_OK;
 }

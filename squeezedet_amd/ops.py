@@ -170,6 +170,20 @@ def fire_squeeze_next(x, p_s, b_s, p_e1, b_e1, p_e3, b_e3, p_next_s, b_next_s):
     return so
 
 
+def fire_expand_squeeze_next(sq_in, p_e1, b_e1, p_e3, b_e3, p_next_s, b_next_s, pool=False):
+    """Expand half of a module from its squeeze tensor (+ pool) emitting the NEXT module's squeeze tensor
+    (sqdet_fire_expand_squeeze_next_fwd)."""
+    n, h, w, s = [int(v) for v in sq_in.shape]
+    shape = (n, -(-h // 2), -(-w // 2), p_next_s.cout) if pool else (n, h, w, p_next_s.cout)
+    so = torch.empty(shape, dtype=sq_in.dtype, device=sq_in.device)
+    check(lib().sqdet_fire_expand_squeeze_next_fwd(_dev(sq_in, "sq_in"), _dev(p_e1.data, "w_e1"), _dev(b_e1, "b_e1", torch.float32),
+                                                   _dev(p_e3.data, "w_e3"), _dev(b_e3, "b_e3", torch.float32),
+                                                   _dev(p_next_s.data, "w_next_s"), _dev(b_next_s, "b_next_s", torch.float32),
+                                                   _dev(so, "sq_out"), n, h, w, s, p_e1.cout, p_e3.cout, p_next_s.cout, int(bool(pool)),
+                                                   dtype_code(sq_in.dtype), stream_ptr()), "sqdet_fire_expand_squeeze_next_fwd")
+    return so
+
+
 class FireChainStream:
     """The packed weight stream of sqdet_fire_chain_fwd: expand1x1 + expand3x3 kernels of one fire module and,
     optionally, the squeeze1x1 kernel of the next one (float32 HWIO in, float16 stream out)."""

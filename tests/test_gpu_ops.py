@@ -589,3 +589,29 @@ def test_fire_squeeze_next_one_launch(case):
     assert got.shape == want.shape and torch.equal(got, want), "squeeze-out form differs from fire -> squeeze conv"
     ref = O.conv_layer(y.float().cpu(), wn, bn, 1, "SAME", True, storage="fp16")
     np.testing.assert_allclose(got.float().cpu().numpy(), ref.numpy(), rtol=2 ** -8, atol=2e-3)
+
+
+EXPSQ_CASES = [("fire3p-4", 16, 64, 32, 94, 311, 2, True), ("fire3p-4-odd", 16, 64, 32, 19, 37, 3, True), ("fire4-5", 32, 128, 32, 47, 156, 2, False),
+               ("fire4-5-small", 32, 128, 32, 9, 15, 5, False), ("fire5p-6", 32, 128, 48, 47, 156, 2, True), ("fire5p-6-even", 32, 128, 48, 20, 28, 1, True)]
+
+
+@pytest.mark.parametrize("case", EXPSQ_CASES, ids=[c[0] for c in EXPSQ_CASES])
+def test_fire_expand_squeeze_next(case):
+    """sqdet_fire_expand_squeeze_next_fwd (expand half of a module from its squeeze tensor, its pool, and the NEXT module's
+    squeeze in one streaming launch: fire3+pool3 -> fire4's squeeze, fire4 -> fire5's, fire5+pool5 -> fire6's) BITWISE
+    against sqdet_fire_expand_fwd followed by the squeeze conv."""
+    ops = _ops()
+    name, s, e, s2, H, W, N, pool = case
+    tdt = torch.float16
+    assert ops.lib().sqdet_fire_expand_squeeze_next_supported(s, e, e, s2, int(pool), 1) == 1
+    rs = np.random.RandomState(zlib.crc32(("expsq" + name).encode()) % (2 ** 31))
+    mk = lambda k, ci, co: torch.from_numpy((rs.randn(k, k, ci, co) * (2.0 / (k * k * ci)) ** 0.5).astype(np.float32)).half().float()
+    w1, w3, wn = mk(1, s, e), mk(3, s, e), mk(1, 2 * e, s2)
+    b1, b3, bn = [torch.from_numpy(rs.uniform(-0.3, 0.3, c).astype(np.float32)).to(DEV) for c in (e, e, s2)]
+    p1, p3, pn = [ops.pack_conv_weights(w_.to(DEV), tdt) for w_ in (w1, w3, wn)]
+    sq = torch.from_numpy(np.maximum(rs.randn(N, H, W, s), 0).astype(np.float32)).to(DEV, tdt).contiguous()
+    got = ops.fire_expand_squeeze_next(sq, p1, b1, p3, b3, pn, bn, pool=pool)
+    y = ops.fire_expand(sq, p1, b1, p3, b3, pool=pool)
+    want = ops.conv2d_nhwc(y, pn, bn, 1, "SAME", True)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape and torch.equal(got, want)
