@@ -215,6 +215,17 @@ int sqdet_filter_prediction(const float* boxes, const float* probs, const int64_
                             int32_t* out_count, int n, int num_anchors, int classes, int top_n, int max_out,
                             double nms_thresh, float prob_thresh, sqdet_stream_t stream);
 
+/* interpret_output + filter_prediction in ONE launch for the top-N branch (0 < top_n <= 64 < A <= 20480: every reference
+ * config): the scores of all anchors are computed on the fly, boxes and classes are decoded for the <= top_n selected
+ * anchors only -- det_boxes / det_class (0.47 MB per image in the reference's sess.run) never exist.  Same float
+ * expressions as sqdet_interpret_output, same selection / NMS as sqdet_filter_prediction: identical outputs.
+ * scratch_probs: float32 [n, A] device scratch (det_probs; read back only when more than 2048 anchors tie at the top-N
+ * boundary).  Outputs as sqdet_filter_prediction. */
+int sqdet_detect_filter(const void* preds, const float* anchors, float* scratch_probs, float* out_boxes, float* out_probs,
+                        int32_t* out_cls, int32_t* out_index, int32_t* out_count, int n, int gh, int gw, int apg, int classes,
+                        float img_w, float img_h, float exp_thresh, int top_n, int max_out, double nms_thresh, int dtype,
+                        sqdet_stream_t stream);
+
 /* ------------------------------------------------------------ training --
  * Replaces the gradient half of the reference's TF graph for the trainable convs (stride 1,
  * SAME: every conv but the frozen conv1, nets/squeezeDet.py:40-42), the loss graph

@@ -43,6 +43,7 @@ SIGNATURES = {
     "sqdet_fire_chain_fwd": (ci, [vp] * 7 + [ci] * 8 + [vp]),
     "sqdet_interpret_output": (ci, [vp] * 7 + [ci] * 5 + [cf, cf, cf, ci, vp]),
     "sqdet_filter_prediction": (ci, [vp] * 8 + [ci] * 5 + [cd, cf, vp]),
+    "sqdet_detect_filter": (ci, [vp] * 8 + [ci] * 5 + [cf, cf, cf, ci, ci, cd, ci, vp]),
     "sqdet_conv_pack_weights_bwd_data": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "sqdet_conv2d_nhwc_bwd_data": (ci, [vp, vp, vp] + [ci] * 10 + [vp]),
     "sqdet_conv2d_bwd_filter_workspace_bytes": (sz, [ci] * 6),

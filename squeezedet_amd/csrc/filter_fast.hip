@@ -76,11 +76,17 @@ __device__ unsigned long long slow_select(const float* probs, int A, int top_n, 
   return prefix;
 }
 
-__global__ __launch_bounds__(FT) void filter_topn_fast(FilterArgs a) {
+// FUSED (T = the storage type of preds): interpret_output is done here -- every thread computes the scores of its anchors
+// from preds (and leaves them in the scratch a.probs for the mass-tie fallback); wave 0 decodes boxes and classes of the
+// <= 64 selected anchors only.  Same float expressions as interpret_kernel (postproc.h): identical picks and outputs.
+template <bool FUSED, typename T>
+__global__ __launch_bounds__(FT) void filter_topn_fast(FilterArgs a, DecodeArgs d) {
   __shared__ FastLds s;
   const int img = blockIdx.x;
   const int tid = threadIdx.x;
-  const float* probs = a.probs + (size_t)img * a.A;
+  float* probs_w = const_cast<float*>(a.probs) + (size_t)img * a.A;
+  const float* probs = probs_w;
+  const T* pimg = FUSED ? reinterpret_cast<const T*>(d.preds) + (size_t)img * d.cells * d.apg * (d.C + 5) : nullptr;
   const float* boxes = a.boxes + (size_t)img * a.A * 4;
   const int64_t* cls = a.cls + (size_t)img * a.A;
   float* ob = a.out_boxes + (size_t)img * a.max_out * 4;
@@ -96,7 +102,18 @@ __global__ __launch_bounds__(FT) void filter_topn_fast(FilterArgs a) {
 #pragma unroll
   for (int e = 0; e < FMAXE; ++e) {
     const int i = tid + e * FT;
-    key[e] = i < a.A ? order_key32(probs[i]) : 0u;
+    if constexpr (FUSED) {
+      key[e] = 0u;
+      if (i < a.A) {
+        const int cell = i / d.apg, k = i - cell * d.apg;
+        int bc;
+        const float sc = decode_score<T>(pimg + (size_t)cell * d.apg * (d.C + 5), k, d.apg, d.C, &bc);
+        probs_w[i] = sc;
+        key[e] = order_key32(sc);
+      }
+    } else {
+      key[e] = i < a.A ? order_key32(probs[i]) : 0u;
+    }
     mx = key[e] > mx ? key[e] : mx;
   }
   // maximum of every group of 8 consecutive threads (128 disjoint groups of <= 160 anchors)
@@ -138,14 +155,15 @@ __global__ __launch_bounds__(FT) void filter_topn_fast(FilterArgs a) {
   if (C > FCAP) {
     // too many ties at the boundary: exact radix select over all anchors, then re-compact
     __shared__ int hist[256], scan[256], misc[4];
-    const unsigned long long T = slow_select(probs, a.A, M, hist, scan, misc);
+    if constexpr (FUSED) { __threadfence_block(); __syncthreads(); }   // the scores this block just wrote
+    const unsigned long long TH = slow_select(probs, a.A, M, hist, scan, misc);
     if (tid == 0) s.count = 0;
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < FMAXE; ++e) {
       const int i = tid + e * FT;
       const unsigned long long k64 = ((unsigned long long)key[e] << 32) | (unsigned int)i;
-      if (i < a.A && k64 >= T) {
+      if (i < a.A && k64 >= TH) {
         const int slot = atomicAdd(&s.count, 1);
         if (slot < FCAP) s.cand[slot] = k64;
       }
@@ -168,10 +186,19 @@ __global__ __launch_bounds__(FT) void filter_topn_fast(FilterArgs a) {
   const int r = tid;
   int idx = 0, c = -1;
   f32x4 bj = {0.f, 0.f, 0.f, 0.f};
+  float pj = 0.f;
   if (w0 && r < M) {
     idx = (int)(s.sel[r] & 0xffffffffull);
-    bj = *reinterpret_cast<const f32x4*>(boxes + (size_t)idx * 4);
-    c = (int)cls[idx];
+    if constexpr (FUSED) {
+      const int cell = idx / d.apg, k = idx - cell * d.apg;
+      const T* p = pimg + (size_t)cell * d.apg * (d.C + 5);
+      pj = decode_score<T>(p, k, d.apg, d.C, &c);
+      bj = decode_box<T>(p, k, d.apg, d.C, *reinterpret_cast<const f32x4*>(d.anchors + (size_t)idx * 4), d.w1, d.h1, d.thr, d.slope);
+    } else {
+      bj = *reinterpret_cast<const f32x4*>(boxes + (size_t)idx * 4);
+      c = (int)cls[idx];
+      pj = probs[idx];
+    }
     s.box[r] = bj;
     s.cls[r] = c;
   }
@@ -196,7 +223,7 @@ __global__ __launch_bounds__(FT) void filter_topn_fast(FilterArgs a) {
   }
   if (keep) {
     *reinterpret_cast<f32x4*>(ob + (size_t)pos * 4) = bj;
-    op[pos] = probs[idx];
+    op[pos] = pj;
     oc[pos] = c;
     oi[pos] = idx;
   }
@@ -212,7 +239,17 @@ __global__ __launch_bounds__(FT) void filter_topn_fast(FilterArgs a) {
 int filter_topn_fast_launch(const FilterArgs& a, int n, hipStream_t st, bool* handled) {
   *handled = false;
   if (!a.use_topn || a.top_n > 64 || a.A > FT * FMAXE) return SQDET_OK;
-  hipLaunchKernelGGL(filter_topn_fast, dim3(n), dim3(FT), 0, st, a);
+  hipLaunchKernelGGL((filter_topn_fast<false, float>), dim3(n), dim3(FT), 0, st, a, DecodeArgs{});
+  SQDET_CHECK_HIP(hipGetLastError());
+  *handled = true;
+  return SQDET_OK;
+}
+
+int detect_topn_fused_launch(const FilterArgs& a, const DecodeArgs& d, int n, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (!a.use_topn || a.top_n > 64 || a.A > FT * FMAXE) return SQDET_OK;
+  if (d.dtype == SQDET_F16) hipLaunchKernelGGL((filter_topn_fast<true, f16>), dim3(n), dim3(FT), 0, st, a, d);
+  else hipLaunchKernelGGL((filter_topn_fast<true, float>), dim3(n), dim3(FT), 0, st, a, d);
   SQDET_CHECK_HIP(hipGetLastError());
   *handled = true;
   return SQDET_OK;

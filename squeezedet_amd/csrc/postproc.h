@@ -43,6 +43,64 @@ __device__ __forceinline__ float iou_center(const f32x4& bj, const f32x4& bi) {
   return inter / uni;
 }
 
+// ---- interpret_output arithmetic, shared by interpret_kernel (postproc.hip) and the fused decode + filter kernel
+// (filter_fast.hip); both translation units are compiled with -ffp-contract=off ----
+struct DecodeArgs {
+  const void* preds;      // [n, cells, apg*(C+5)] in dtype storage
+  const float* anchors;   // [A,4] float32
+  int cells, apg, C, dtype;
+  float w1, h1, thr, slope;
+};
+
+// score = max_c(softmax(class logits)_c * sigmoid(conf)), class = first argmax (nn_skeleton.py:150-170, 274-283)
+template <typename T>
+__device__ __forceinline__ float decode_score(const T* p, int k, int apg, int C, int* bestc_out) {
+  const T* lg = p + k * C;
+  float mx = (float)lg[0];
+  for (int c = 1; c < C; ++c) mx = fmaxf(mx, (float)lg[c]);
+  float sum = expf((float)lg[0] - mx);
+  for (int c = 1; c < C; ++c) sum = sum + expf((float)lg[c] - mx);
+  const float inv = 1.0f / sum;
+  const float conf = 1.0f / (1.0f + expf(-(float)p[apg * C + k]));
+  float best = 0.f;
+  int bestc = 0;
+  for (int c = 0; c < C; ++c) {
+    const float pr = (expf((float)lg[c] - mx) * inv) * conf;
+    if (c == 0 || pr > best) { best = pr; bestc = c; }
+  }
+  *bestc_out = bestc;
+  return best;
+}
+
+// box deltas -> (cx, cy, w, h): stretching, safe_exp, trimming, bbox_transform_inv (nn_skeleton.py:173-233, utils/util.py:167-231)
+template <typename T>
+__device__ __forceinline__ f32x4 decode_box(const T* p, int k, int apg, int C, const f32x4& an, float w1, float h1, float thr, float slope) {
+  const T* dl = p + apg * (C + 1) + 4 * k;
+  const float dx = (float)dl[0], dy = (float)dl[1], dw = (float)dl[2], dh = (float)dl[3];
+  const float cx = an[0] + dx * an[2];
+  const float cy = an[1] + dy * an[3];
+  const float ew = dw > thr ? slope * ((dw - thr) + 1.0f) : expf(dw);
+  const float eh = dh > thr ? slope * ((dh - thr) + 1.0f) : expf(dh);
+  const float bw = an[2] * ew;
+  const float bh = an[3] * eh;
+  float xmin = cx - bw / 2.0f, ymin = cy - bh / 2.0f, xmax = cx + bw / 2.0f, ymax = cy + bh / 2.0f;
+  xmin = fminf(fmaxf(0.0f, xmin), w1);
+  ymin = fminf(fmaxf(0.0f, ymin), h1);
+  xmax = fmaxf(fminf(w1, xmax), 0.0f);
+  ymax = fmaxf(fminf(h1, ymax), 0.0f);
+  const float w2 = xmax - xmin + 1.0f;
+  const float h2 = ymax - ymin + 1.0f;
+  f32x4 ob;
+  ob[0] = xmin + 0.5f * w2;
+  ob[1] = ymin + 0.5f * h2;
+  ob[2] = w2;
+  ob[3] = h2;
+  return ob;
+}
+
 int filter_topn_fast_launch(const FilterArgs& a, int n, hipStream_t st, bool* handled);
+// interpret_output + filter_prediction (top-N branch) in ONE launch: scores computed on the fly, boxes decoded for the
+// selected anchors only; a.probs = scratch [n, A] (scores, read back by the mass-tie fallback), a.boxes / a.cls unused
+int detect_topn_fused_launch(const FilterArgs& a, const DecodeArgs& d, int n, hipStream_t st, bool* handled);
 
 }  // namespace sqdet

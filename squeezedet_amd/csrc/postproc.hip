@@ -28,50 +28,23 @@ __global__ __launch_bounds__(256) void interpret_kernel(const T* __restrict__ pr
     const int a = (int)(idx - (long)b * A);
     const int cell = a / apg, k = a - cell * apg;
     const T* p = preds + ((size_t)b * cells + cell) * ch;
-    // class probabilities: softmax over channels [k*C, k*C+C)   (nn_skeleton.py:150-160)
-    const T* lg = p + k * C;
-    float mx = (float)lg[0];
-    for (int c = 1; c < C; ++c) mx = fmaxf(mx, (float)lg[c]);
-    float sum = expf((float)lg[0] - mx);
-    for (int c = 1; c < C; ++c) sum = sum + expf((float)lg[c] - mx);
-    const float inv = 1.0f / sum;
-    // confidence: sigmoid of channel apg*C + k   (nn_skeleton.py:163-170)
-    const float conf = 1.0f / (1.0f + expf(-(float)p[apg * C + k]));
-    // score = max_c(class_prob * conf), class = first argmax   (nn_skeleton.py:274-283)
-    float best = 0.f;
-    int bestc = 0;
-    for (int c = 0; c < C; ++c) {
-      const float pc = expf((float)lg[c] - mx) * inv;
-      if (pcp) pcp[idx * C + c] = pc;
-      const float pr = pc * conf;
-      if (c == 0 || pr > best) { best = pr; bestc = c; }
+    // class probabilities: softmax over channels [k*C, k*C+C) (nn_skeleton.py:150-160); confidence: sigmoid of channel
+    // apg*C + k (:163-170); score = max_c(class_prob * conf), class = first argmax (:274-283) -- decode_score, postproc.h
+    int bestc;
+    const float best = decode_score<T>(p, k, apg, C, &bestc);
+    if (pcp || pconf) {   // the optional per-class outputs: the same expressions again
+      const T* lg = p + k * C;
+      float mx = (float)lg[0];
+      for (int c = 1; c < C; ++c) mx = fmaxf(mx, (float)lg[c]);
+      float sum = expf((float)lg[0] - mx);
+      for (int c = 1; c < C; ++c) sum = sum + expf((float)lg[c] - mx);
+      const float inv = 1.0f / sum;
+      if (pcp) for (int c = 0; c < C; ++c) pcp[idx * C + c] = expf((float)lg[c] - mx) * inv;
+      if (pconf) pconf[idx] = 1.0f / (1.0f + expf(-(float)p[apg * C + k]));
     }
-    if (pconf) pconf[idx] = conf;
-    // box deltas: channels apg*(C+1) + 4k + {0..3}   (nn_skeleton.py:173-177)
-    const T* dl = p + apg * (C + 1) + 4 * k;
-    const float dx = (float)dl[0], dy = (float)dl[1], dw = (float)dl[2], dh = (float)dl[3];
+    // box deltas -> box: stretching, safe_exp, trimming, bbox_transform_inv -- decode_box, postproc.h
     const f32x4 an = *reinterpret_cast<const f32x4*>(anchors + (size_t)a * 4);
-    // stretching (nn_skeleton.py:192-201); safe_exp (utils/util.py:219-231)
-    const float cx = an[0] + dx * an[2];
-    const float cy = an[1] + dy * an[3];
-    const float ew = dw > thr ? slope * ((dw - thr) + 1.0f) : expf(dw);
-    const float eh = dh > thr ? slope * ((dh - thr) + 1.0f) : expf(dh);
-    const float bw = an[2] * ew;
-    const float bh = an[3] * eh;
-    // trimming (nn_skeleton.py:214-233, utils/util.py:167-179)
-    float xmin = cx - bw / 2.0f, ymin = cy - bh / 2.0f, xmax = cx + bw / 2.0f, ymax = cy + bh / 2.0f;
-    xmin = fminf(fmaxf(0.0f, xmin), w1);
-    ymin = fminf(fmaxf(0.0f, ymin), h1);
-    xmax = fmaxf(fminf(w1, xmax), 0.0f);
-    ymax = fmaxf(fminf(h1, ymax), 0.0f);
-    // bbox_transform_inv (utils/util.py:181-196)
-    const float w2 = xmax - xmin + 1.0f;
-    const float h2 = ymax - ymin + 1.0f;
-    f32x4 ob;
-    ob[0] = xmin + 0.5f * w2;
-    ob[1] = ymin + 0.5f * h2;
-    ob[2] = w2;
-    ob[3] = h2;
+    const f32x4 ob = decode_box<T>(p, k, apg, C, an, w1, h1, thr, slope);
     *reinterpret_cast<f32x4*>(det_boxes + idx * 4) = ob;
     det_probs[idx] = best;
     det_class[idx] = (int64_t)bestc;
@@ -309,5 +282,30 @@ extern "C" int sqdet_filter_prediction(const float* boxes, const float* probs, c
   const size_t lds = (size_t)cap * 32 + 4096 + (size_t)cap * 8;
   hipLaunchKernelGGL(filter_kernel, dim3(n), dim3(256), lds, as_stream(stream), a);
   SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_detect_filter(const void* preds, const float* anchors, float* scratch_probs, float* out_boxes,
+                                   float* out_probs, int32_t* out_cls, int32_t* out_index, int32_t* out_count, int n, int gh,
+                                   int gw, int apg, int classes, float img_w, float img_h, float exp_thresh, int top_n,
+                                   int max_out, double nms_thresh, int dtype, sqdet_stream_t stream) {
+  SQDET_REQUIRE(preds && anchors && scratch_probs && out_boxes && out_probs && out_cls && out_index && out_count,
+                "detect_filter: null pointer");
+  SQDET_REQUIRE(n > 0 && gh > 0 && gw > 0 && apg > 0 && classes > 0 && max_out >= top_n, "detect_filter: bad dims");
+  SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "detect_filter: bad dtype %d", dtype);
+  const int A = gh * gw * apg;
+  FilterArgs a;
+  a.boxes = nullptr; a.probs = scratch_probs; a.cls = nullptr;
+  a.out_boxes = out_boxes; a.out_probs = out_probs; a.out_cls = out_cls; a.out_index = out_index; a.out_count = out_count;
+  a.A = A; a.C = classes; a.top_n = top_n; a.max_out = max_out; a.cap = 0;
+  a.use_topn = (top_n > 0 && top_n < A) ? 1 : 0;
+  a.nms_thresh = nms_thresh; a.prob_thresh = 0.f;
+  DecodeArgs d;
+  d.preds = preds; d.anchors = anchors; d.cells = gh * gw; d.apg = apg; d.C = classes; d.dtype = dtype;
+  d.w1 = img_w - 1.0f; d.h1 = img_h - 1.0f; d.thr = exp_thresh; d.slope = (float)exp((double)exp_thresh);
+  bool handled = false;
+  const int rc = detect_topn_fused_launch(a, d, n, as_stream(stream), &handled);
+  if (rc != SQDET_OK) return rc;
+  SQDET_UNSUPPORTED(!handled, "detect_filter: needs the top-N branch with 0 < top_n <= 64 < anchors <= 20480 (else interpret_output + filter_prediction)");
   return SQDET_OK;
 }

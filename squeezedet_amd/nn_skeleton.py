@@ -474,10 +474,15 @@ class ModelSkeleton:
             s["fwd_done"].record(cur)
             with torch.cuda.stream(self.post_stream):
                 self.post_stream.wait_event(s["fwd_done"])
-                ops.interpret_output(s["preds"], self.anchors_f32(), mc.CLASSES, mc.ANCHOR_PER_GRID, mc.IMAGE_WIDTH,
-                                     mc.IMAGE_HEIGHT, mc.EXP_THRESH, out=s["det"])
-                ops.filter_prediction(s["det"][0], s["det"][1], s["det"][2], mc.CLASSES, mc.TOP_N_DETECTION, mc.NMS_THRESH,
-                                      mc.PROB_THRESH, out=s["out"])
+                if ops.detect_filter_supported(mc.ANCHORS, mc.TOP_N_DETECTION) and os.environ.get("SQDET_SPLIT_POST") != "1":
+                    # decode + top-N + NMS in ONE launch: boxes / classes are decoded for the selected anchors only
+                    ops.detect_filter(s["preds"], self.anchors_f32(), mc.CLASSES, mc.ANCHOR_PER_GRID, mc.IMAGE_WIDTH, mc.IMAGE_HEIGHT,
+                                      mc.EXP_THRESH, mc.TOP_N_DETECTION, mc.NMS_THRESH, scratch=s["det"][1], out=s["out"])
+                else:
+                    ops.interpret_output(s["preds"], self.anchors_f32(), mc.CLASSES, mc.ANCHOR_PER_GRID, mc.IMAGE_WIDTH,
+                                         mc.IMAGE_HEIGHT, mc.EXP_THRESH, out=s["det"])
+                    ops.filter_prediction(s["det"][0], s["det"][1], s["det"][2], mc.CLASSES, mc.TOP_N_DETECTION, mc.NMS_THRESH,
+                                          mc.PROB_THRESH, out=s["out"])
                 if to_host:
                     if s["host"] is None:
                         s["host_flat"] = torch.empty(s["flat"].shape, dtype=torch.uint8).pin_memory()

@@ -293,6 +293,33 @@ def filter_prediction(boxes, probs, cls, classes, top_n, nms_thresh, prob_thresh
     return ob, op, oc, oi, cnt
 
 
+def detect_filter_supported(num_anchors, top_n):
+    return 0 < top_n <= 64 < num_anchors <= 20480
+
+
+def detect_filter(preds, anchors_f32, classes, anchors_per_grid, img_w, img_h, exp_thresh, top_n, nms_thresh, scratch=None, out=None):
+    """interpret_output + filter_prediction (top-N branch) in one launch (sqdet_detect_filter): preds [N,gh,gw,K*(C+5)] ->
+    the five filter_prediction outputs; det_boxes / det_class are never materialised."""
+    n, gh, gw, ch = [int(v) for v in preds.shape]
+    A = gh * gw * anchors_per_grid
+    dev = preds.device
+    scratch = torch.empty((n, A), dtype=torch.float32, device=dev) if scratch is None else scratch
+    M = int(top_n)
+    if out is not None:
+        ob, op, oc, oi, cnt = out
+    else:
+        ob = torch.empty((n, M, 4), dtype=torch.float32, device=dev)
+        op = torch.empty((n, M), dtype=torch.float32, device=dev)
+        oc = torch.empty((n, M), dtype=torch.int32, device=dev)
+        oi = torch.empty((n, M), dtype=torch.int32, device=dev)
+        cnt = torch.empty((n,), dtype=torch.int32, device=dev)
+    check(lib().sqdet_detect_filter(_dev(preds, "preds"), _dev(anchors_f32, "anchors", torch.float32), _dev(scratch, "scratch", torch.float32),
+                                    _dev(ob, "ob"), _dev(op, "op"), _dev(oc, "oc"), _dev(oi, "oi"), _dev(cnt, "cnt"), n, gh, gw,
+                                    int(anchors_per_grid), int(classes), float(img_w), float(img_h), float(exp_thresh), M, int(ob.shape[1]),
+                                    float(nms_thresh), dtype_code(preds.dtype), stream_ptr()), "sqdet_detect_filter")
+    return ob, op, oc, oi, cnt
+
+
 # ---------------------------------------------------------------- training (float32)
 class PackedConvBwd:
     """rot180(W)^T in fragment order: the kernel of the backward-data conv (sqdet_conv_pack_weights_bwd_data)."""

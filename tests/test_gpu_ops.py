@@ -615,3 +615,29 @@ def test_fire_expand_squeeze_next(case):
     want = ops.conv2d_nhwc(y, pn, bn, 1, "SAME", True)
     torch.cuda.synchronize()
     assert got.shape == want.shape and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("ties", [False, True], ids=["spread", "mass-ties"])
+def test_detect_filter_one_launch(dtype, ties):
+    """sqdet_detect_filter (interpret_output + the top-N branch of filter_prediction in one launch: scores on the fly, boxes
+    and classes decoded for the selected anchors only) gives EXACTLY what sqdet_interpret_output -> sqdet_filter_prediction
+    give -- also when thousands of anchors tie at the selection boundary (constant score map: the radix-select fallback
+    reads the scores back from the scratch)."""
+    ops = _ops()
+    mc = O.kitti_squeezeDet_config()
+    n, gh, gw, K, C = 3, 24, 78, mc.ANCHOR_PER_GRID, mc.CLASSES
+    tdt = torch.float16 if dtype == "fp16" else torch.float32
+    rs = np.random.RandomState(31 + ties)
+    preds = (rs.randn(n, gh, gw, K * (C + 5)) * 2.0).astype(np.float32)
+    if ties:
+        preds[1, :, :, :K * (C + 1)] = 0.25            # image 1: every anchor has the same score
+    pd = torch.from_numpy(preds).to(DEV, tdt).contiguous()
+    anchors = torch.from_numpy(np.asarray(mc.ANCHOR_BOX).astype(np.float32)).to(DEV)
+    boxes, probs, cls = ops.interpret_output(pd, anchors, C, K, mc.IMAGE_WIDTH, mc.IMAGE_HEIGHT, mc.EXP_THRESH)[:3]
+    want = ops.filter_prediction(boxes, probs, cls, C, mc.TOP_N_DETECTION, mc.NMS_THRESH, mc.PROB_THRESH)
+    got = ops.detect_filter(pd, anchors, C, K, mc.IMAGE_WIDTH, mc.IMAGE_HEIGHT, mc.EXP_THRESH, mc.TOP_N_DETECTION, mc.NMS_THRESH)
+    torch.cuda.synchronize()
+    for g_, w_ in zip(got, want):
+        assert torch.equal(g_, w_)
+    assert int(got[4].min()) >= 1
