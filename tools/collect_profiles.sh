@@ -1,0 +1,32 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): everything profiles/ needs for one build, into gpurun_out/$1/.
+#   gpurun -- 'bash tools/collect_profiles.sh r02_x'
+set -u
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+# 1. the bench lines (driver-style short run of the headline too)
+for c in sqdet_infer sqdetplus_infer sqdet_train_fp32 res50_train_fp16; do
+  python $R/bench.py --config $c > $OUT/bench_$c.json 2> $OUT/bench_$c.err
+done
+python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_sqdet_infer_20steps.json 2>> $OUT/bench_sqdet_infer.err
+python $R/bench.py --no-cpu-baseline --layer-table $OUT/layer_table.json > /dev/null 2>&1
+# 2. rocprofv3 kernel stats of the headline command
+rocprofv3 --kernel-trace --stats -d $OUT/kstats -o ks --output-format csv -- python $R/bench.py --no-cpu-baseline > $OUT/kstats.log 2>&1
+python $R/profiles/summarize.py $(find $OUT/kstats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline" >> $OUT/kstats.log 2>&1
+# 3. HBM (fabric) traffic per launch: FETCH_SIZE and WRITE_SIZE in separate passes
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch --output-format csv -- python $R/tools/pmc_forward.py > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o write --output-format csv -- python $R/tools/pmc_forward.py > $OUT/pmc_write.log 2>&1
+LAYERS=$(python -c "import json; print(','.join(l['layer'] for l in json.load(open('$OUT/layer_table.json'))['layers']))")
+cd $R && python profiles/pmc_traffic.py $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) $OUT/hbm_traffic_pmc.json "$LAYERS" > $OUT/pmc_traffic.log 2>&1
+# 4. SQ counters (two passes) of the forward
+cd /tmp
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/sq1 -o sq1 --output-format csv -- python $R/tools/pmc_forward.py > /dev/null 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/sq2 -o sq2 --output-format csv -- python $R/tools/pmc_forward.py > /dev/null 2>&1
+cd $R
+for f in $(find $OUT/sq1 $OUT/sq2 -name "*counter_collection.csv"); do python tools/pmc_summary.py $f sqdet; done > $OUT/sq_counters.txt 2>&1
+# keep the merge small: raw traces are not needed
+rm -rf $OUT/kstats $OUT/pmc_fetch $OUT/pmc_write $OUT/sq1 $OUT/sq2
+ls -la $OUT
