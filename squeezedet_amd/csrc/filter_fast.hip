@@ -6,14 +6,15 @@
 //
 //   1. every thread keeps its <= 20 anchors' 32-bit order-preserving prob keys in registers and
 //      publishes its maximum;
-//   2. L = the TOP_N-th largest of the 1024 thread maxima, found by an all-pairs rank in LDS.
-//      At least TOP_N anchors have key >= L, so every top-N anchor has key >= L;
+//   2. L = the TOP_N-th largest of the 128 maxima of 8-thread groups, found by an all-pairs rank in LDS (8 threads
+//      share one group's 128 comparisons).  At least TOP_N anchors have key >= L, so every top-N anchor has key >= L;
 //   3. the anchors with key >= L (typically ~TOP_N..4*TOP_N of 16848) are compacted into LDS as
 //      64-bit composite keys (prob key << 32 | anchor: all distinct);
 //   4. all-pairs rank among the candidates: rank r < TOP_N <=> selected, and r IS the position in
 //      the descending order -> no sort pass, no histogram atomics;
-//   5. wave 0 runs the non-greedy NMS on the <= 64 ranked boxes and emits them ordered by class,
-//      then descending prob.
+//   5. wave 0 decodes the <= 64 ranked boxes, all 16 waves share the 64 x 64 IoU pairs of the non-greedy NMS (the
+//      kernel is pure latency: one wave walking 63 dependent IoU chains was most of it), wave 0 emits the survivors
+//      ordered by class, then descending prob (positions from per-class ballots).
 // If more than FCAP anchors tie at >= L (e.g. a constant score map) the call falls back to the
 // generic radix-select kernel for that launch (decided on the device, uniformly per image).
 #include "postproc.h"
@@ -29,9 +30,9 @@ struct FastLds {
   unsigned int wmax[FT];
   unsigned long long cand[FCAP];
   unsigned long long sel[64];
+  unsigned long long supp;   // bit r: box r is suppressed by a higher-ranked same-class box
   f32x4 box[64];
   int cls[64];
-  int keep[64];
   unsigned int L;
   int count;
   int fallback;
@@ -76,16 +77,27 @@ __device__ unsigned long long slow_select(const float* probs, int A, int top_n, 
   return prefix;
 }
 
-// FUSED (T = the storage type of preds): interpret_output is done here -- every thread computes the scores of its anchors
-// from preds (and leaves them in the scratch a.probs for the mass-tie fallback); wave 0 decodes boxes and classes of the
-// <= 64 selected anchors only.  Same float expressions as interpret_kernel (postproc.h): identical picks and outputs.
+// FUSED (T = the storage type of preds): interpret_output is folded in -- a.probs holds the scores score_kernel<T> wrote
+// (one thread per anchor over the whole chip: computing them here would put 17 anchors x 5 expf per thread on ONE CU per
+// image, 27 us of a 58 us kernel); wave 0 decodes boxes and classes of the <= 64 selected anchors only.  Same float
+// expressions as interpret_kernel (postproc.h): identical picks and outputs.
+template <typename T>
+__global__ __launch_bounds__(256) void score_kernel(DecodeArgs d, float* __restrict__ probs, int A, int total) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int img = i / A, an = i - img * A;
+  const int cell = an / d.apg, k = an - cell * d.apg;
+  const T* p = reinterpret_cast<const T*>(d.preds) + ((size_t)img * d.cells + cell) * d.apg * (d.C + 5);
+  int bc;
+  probs[i] = decode_score<T>(p, k, d.apg, d.C, &bc);
+}
+
 template <bool FUSED, typename T>
 __global__ __launch_bounds__(FT) void filter_topn_fast(FilterArgs a, DecodeArgs d) {
   __shared__ FastLds s;
   const int img = blockIdx.x;
   const int tid = threadIdx.x;
-  float* probs_w = const_cast<float*>(a.probs) + (size_t)img * a.A;
-  const float* probs = probs_w;
+  const float* probs = a.probs + (size_t)img * a.A;
   const T* pimg = FUSED ? reinterpret_cast<const T*>(d.preds) + (size_t)img * d.cells * d.apg * (d.C + 5) : nullptr;
   const float* boxes = a.boxes + (size_t)img * a.A * 4;
   const int64_t* cls = a.cls + (size_t)img * a.A;
@@ -102,18 +114,7 @@ __global__ __launch_bounds__(FT) void filter_topn_fast(FilterArgs a, DecodeArgs 
 #pragma unroll
   for (int e = 0; e < FMAXE; ++e) {
     const int i = tid + e * FT;
-    if constexpr (FUSED) {
-      key[e] = 0u;
-      if (i < a.A) {
-        const int cell = i / d.apg, k = i - cell * d.apg;
-        int bc;
-        const float sc = decode_score<T>(pimg + (size_t)cell * d.apg * (d.C + 5), k, d.apg, d.C, &bc);
-        probs_w[i] = sc;
-        key[e] = order_key32(sc);
-      }
-    } else {
-      key[e] = i < a.A ? order_key32(probs[i]) : 0u;
-    }
+    key[e] = i < a.A ? order_key32(probs[i]) : 0u;
     mx = key[e] > mx ? key[e] : mx;
   }
   // maximum of every group of 8 consecutive threads (128 disjoint groups of <= 160 anchors)
@@ -127,16 +128,23 @@ __global__ __launch_bounds__(FT) void filter_topn_fast(FilterArgs a, DecodeArgs 
   if (tid == 0) { s.count = 0; s.fallback = 0; }
   __syncthreads();
 
-  // ---- 2. L = M-th largest of the 128 group maxima (all-pairs rank; ties broken by group id).
-  //         Each group maximum is a distinct anchor, so >= M anchors have key >= L.
-  if (tid < FG) {
-    const unsigned int mine = s.wmax[tid];
+  // ---- 2. L = M-th largest of the 128 group maxima (all-pairs rank; ties broken by group id): the 8 threads of group
+  //         tid>>3 each compare against 16 of the maxima.  Each group maximum is a distinct anchor, so >= M anchors have
+  //         key >= L.
+  {
+    const int g = tid >> 3, part = tid & 7;
+    const unsigned int mine = s.wmax[g];
     int rank = 0;
-    for (int t = 0; t < FG; ++t) {
+#pragma unroll
+    for (int u = 0; u < FG / 8; ++u) {
+      const int t = part * (FG / 8) + u;
       const unsigned int o = s.wmax[t];
-      rank += (o > mine || (o == mine && t < tid)) ? 1 : 0;
+      rank += (o > mine || (o == mine && t < g)) ? 1 : 0;
     }
-    if (rank == M - 1) s.L = mine;
+    rank += __shfl_xor(rank, 1);
+    rank += __shfl_xor(rank, 2);
+    rank += __shfl_xor(rank, 4);
+    if (part == 0 && rank == M - 1) s.L = mine;
   }
   __syncthreads();
   const unsigned int L = s.L;
@@ -155,7 +163,6 @@ __global__ __launch_bounds__(FT) void filter_topn_fast(FilterArgs a, DecodeArgs 
   if (C > FCAP) {
     // too many ties at the boundary: exact radix select over all anchors, then re-compact
     __shared__ int hist[256], scan[256], misc[4];
-    if constexpr (FUSED) { __threadfence_block(); __syncthreads(); }   // the scores this block just wrote
     const unsigned long long TH = slow_select(probs, a.A, M, hist, scan, misc);
     if (tid == 0) s.count = 0;
     __syncthreads();
@@ -172,54 +179,73 @@ __global__ __launch_bounds__(FT) void filter_topn_fast(FilterArgs a, DecodeArgs 
     C = s.count;  // == M
   }
 
-  // ---- 4. all-pairs rank among the candidates: rank < M <=> in the top-N, rank = position ----
-  for (int q = tid; q < C; q += FT) {
-    const unsigned long long mine = s.cand[q];
+  // ---- 4. all-pairs rank among the candidates: rank < M <=> in the top-N, rank = position.  8 threads per candidate,
+  //         each against every 8th key ----
+  for (int q0 = 0; q0 < C; q0 += FT / 8) {
+    const int q = q0 + (tid >> 3), part = tid & 7;
+    const unsigned long long mine = q < C ? s.cand[q] : 0ull;
     int rank = 0;
-    for (int t = 0; t < C; ++t) rank += s.cand[t] > mine ? 1 : 0;
-    if (rank < M) s.sel[rank] = mine;
+    for (int t = part; t < C; t += 8) rank += s.cand[t] > mine ? 1 : 0;
+    rank += __shfl_xor(rank, 1);
+    rank += __shfl_xor(rank, 2);
+    rank += __shfl_xor(rank, 4);
+    if (part == 0 && q < C && rank < M) s.sel[rank] = mine;
   }
   __syncthreads();
-  // ---- 5. wave 0: NMS + ordered output (the other waves stay alive and take part in the two barriers: a barrier
-  //         behind an early return is undefined in the HIP programming model) ----
-  const bool w0 = tid < 64;
-  const int r = tid;
+  // ---- 5. wave 0 decodes / fetches the <= 64 ranked boxes; the 64 x 64 IoU pairs of the NMS are dealt over all 16
+  //         waves (lane r of wave w: box r against boxes 4w..4w+3 -- one wave doing all 63 dependent IoU chains was 13 of
+  //         the kernel's 20 us); wave 0 emits the survivors ordered by class, then rank ----
+  const int r = tid & 63, wv = tid >> 6;
   int idx = 0, c = -1;
   f32x4 bj = {0.f, 0.f, 0.f, 0.f};
   float pj = 0.f;
-  if (w0 && r < M) {
-    idx = (int)(s.sel[r] & 0xffffffffull);
-    if constexpr (FUSED) {
-      const int cell = idx / d.apg, k = idx - cell * d.apg;
-      const T* p = pimg + (size_t)cell * d.apg * (d.C + 5);
-      pj = decode_score<T>(p, k, d.apg, d.C, &c);
-      bj = decode_box<T>(p, k, d.apg, d.C, *reinterpret_cast<const f32x4*>(d.anchors + (size_t)idx * 4), d.w1, d.h1, d.thr, d.slope);
-    } else {
-      bj = *reinterpret_cast<const f32x4*>(boxes + (size_t)idx * 4);
-      c = (int)cls[idx];
-      pj = probs[idx];
+  if (wv == 0) {
+    if (r < M) {
+      idx = (int)(s.sel[r] & 0xffffffffull);
+      if constexpr (FUSED) {
+        const int cell = idx / d.apg, k = idx - cell * d.apg;
+        const T* p = pimg + (size_t)cell * d.apg * (d.C + 5);
+        pj = decode_score<T>(p, k, d.apg, d.C, &c);
+        bj = decode_box<T>(p, k, d.apg, d.C, *reinterpret_cast<const f32x4*>(d.anchors + (size_t)idx * 4), d.w1, d.h1, d.thr, d.slope);
+      } else {
+        bj = *reinterpret_cast<const f32x4*>(boxes + (size_t)idx * 4);
+        c = (int)cls[idx];
+        pj = probs[idx];
+      }
     }
     s.box[r] = bj;
     s.cls[r] = c;
+    if (r == 0) s.supp = 0ull;
   }
   __syncthreads();
   // the reference's non-greedy NMS (utils/util.py:56-76): r is dropped iff ANY higher-ranked
   // same-class box has IoU > threshold (compared in float64, as under the reference's NumPy 1.12)
-  bool keep = w0 && r < M && c >= 0 && c < a.C;
-  for (int i = 0; i < r && keep; ++i) {
-    if (s.cls[i] != c) continue;
-    const float ov = iou_center(bj, s.box[i]);
-    if ((double)ov > a.nms_thresh) keep = false;
+  {
+    const f32x4 br = s.box[r];
+    const int cr = s.cls[r];
+    bool sup = false;
+#pragma unroll
+    for (int u = 0; u < 64 / (FT / 64); ++u) {
+      const int i = wv * (64 / (FT / 64)) + u;
+      const float ov = iou_center(br, s.box[i]);
+      if (i < r && r < M && s.cls[i] == cr && (double)ov > a.nms_thresh) sup = true;
+    }
+    const unsigned long long m = __ballot(sup);
+    if (r == 0 && m) atomicOr(&s.supp, m);
   }
-  if (w0) s.keep[r] = keep ? 1 : 0;
   __syncthreads();
-  if (!w0) return;
+  if (wv != 0) return;
+  const bool keep = r < M && c >= 0 && c < a.C && !((s.supp >> r) & 1ull);
   // output position: kept entries ordered by class, then rank (nn_skeleton.py:726-733)
-  int pos = 0, kept = 0;
-  for (int i = 0; i < M; ++i) {
-    const int ki = s.keep[i];
-    kept += ki;
-    if (ki && (s.cls[i] < c || (s.cls[i] == c && i < r))) ++pos;
+  const unsigned long long km = __ballot(keep);
+  const int kept = __popcll(km);
+  int pos = 0;
+  {
+    const unsigned long long below = r == 0 ? 0ull : (~0ull >> (64 - r));
+    for (int cc = 0; cc < a.C; ++cc) {   // uniform trip count
+      const unsigned long long mc = __ballot(c == cc) & km;
+      pos += cc < c ? __popcll(mc) : (cc == c ? __popcll(mc & below) : 0);
+    }
   }
   if (keep) {
     *reinterpret_cast<f32x4*>(ob + (size_t)pos * 4) = bj;
@@ -248,8 +274,15 @@ int filter_topn_fast_launch(const FilterArgs& a, int n, hipStream_t st, bool* ha
 int detect_topn_fused_launch(const FilterArgs& a, const DecodeArgs& d, int n, hipStream_t st, bool* handled) {
   *handled = false;
   if (!a.use_topn || a.top_n > 64 || a.A > FT * FMAXE) return SQDET_OK;
-  if (d.dtype == SQDET_F16) hipLaunchKernelGGL((filter_topn_fast<true, f16>), dim3(n), dim3(FT), 0, st, a, d);
-  else hipLaunchKernelGGL((filter_topn_fast<true, float>), dim3(n), dim3(FT), 0, st, a, d);
+  const int total = n * a.A;
+  float* scores = const_cast<float*>(a.probs);
+  if (d.dtype == SQDET_F16) {
+    hipLaunchKernelGGL((score_kernel<f16>), dim3((total + 255) / 256), dim3(256), 0, st, d, scores, a.A, total);
+    hipLaunchKernelGGL((filter_topn_fast<true, f16>), dim3(n), dim3(FT), 0, st, a, d);
+  } else {
+    hipLaunchKernelGGL((score_kernel<float>), dim3((total + 255) / 256), dim3(256), 0, st, d, scores, a.A, total);
+    hipLaunchKernelGGL((filter_topn_fast<true, float>), dim3(n), dim3(FT), 0, st, a, d);
+  }
   SQDET_CHECK_HIP(hipGetLastError());
   *handled = true;
   return SQDET_OK;

@@ -99,7 +99,7 @@ __device__ __forceinline__ f32x4 decode_box(const T* p, int k, int apg, int C, c
 }
 
 int filter_topn_fast_launch(const FilterArgs& a, int n, hipStream_t st, bool* handled);
-// interpret_output + filter_prediction (top-N branch) in ONE launch: scores computed on the fly, boxes decoded for the
+// interpret_output + filter_prediction (top-N branch): a chip-wide score kernel, then the filter kernel with boxes decoded for the
 // selected anchors only; a.probs = scratch [n, A] (scores, read back by the mass-tie fallback), a.boxes / a.cls unused
 int detect_topn_fused_launch(const FilterArgs& a, const DecodeArgs& d, int n, hipStream_t st, bool* handled);
 
