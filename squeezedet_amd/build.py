@@ -25,6 +25,7 @@ SOURCES = [
     ("conv1x1.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("stem.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("stem2.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    ("stem3.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("fire.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("fire2.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("chain.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),

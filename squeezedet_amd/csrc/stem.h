@@ -1,4 +1,4 @@
-// Arguments shared by the two fused-stem kernels (stem.hip: LDS conv tile; stem2.hip: in-register pool).
+// Arguments shared by the fused-stem kernels (stem.hip: LDS conv tile; stem2.hip: in-register pool; stem3.hip: persistent).
 #pragma once
 #include "conv_common.h"
 
@@ -20,5 +20,6 @@ struct StemArgs {
 };
 
 int stem_strip_launch(StemArgs a, int k, int dtype, hipStream_t st, bool* handled);
+int stem_pers_launch(StemArgs a, int k, int dtype, hipStream_t st, bool* handled);   // stem3.hip: fp16, 3x3, 64 couts
 
 }  // namespace sqdet

@@ -200,7 +200,11 @@ int stem_launch(const void* x, const void* w_packed, const float* bias, void* y,
   a.tiles_x = (a.Wp + SPW - 1) / SPW; a.tiles_y = (a.Hp + SPH - 1) / SPH;
   a.y_cstride = y_cstride; a.y_coffset = y_coffset;
   if (a.Hp <= 0 || a.Wp <= 0) return SQDET_OK;
-  if (tune(TUNE_STEM_ALGO) != 1) {  // default: the in-register-pool strip kernel (stem2.hip)
+  if (tune(TUNE_STEM_ALGO) == 0) {  // default for the fp16 3x3 stem: the persistent kernel (stem3.hip)
+    const int rc3 = stem_pers_launch(a, k, dtype, st, handled);
+    if (rc3 != SQDET_OK || *handled) return rc3;
+  }
+  if (tune(TUNE_STEM_ALGO) != 1) {  // otherwise the in-register-pool strip kernel (stem2.hip)
     const int rc2 = stem_strip_launch(a, k, dtype, st, handled);
     if (rc2 != SQDET_OK || *handled) return rc2;
   }

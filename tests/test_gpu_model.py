@@ -83,7 +83,24 @@ def test_native_plan_equals_builder_graph_and_oracle(dtype):
     p_plan = m.run([m.preds], {m.image_input: x}, use_plan=True)[0]
     p_graph = m.run([m.preds], {m.image_input: x}, use_plan=False)[0]
     torch.cuda.synchronize()
-    assert torch.equal(p_plan, p_graph), "native plan and op-by-op graph must run the same kernels"
+    if dtype == torch.float32:
+        assert torch.equal(p_plan, p_graph), "native plan and op-by-op graph must run the same kernels"
+    else:
+        # fp16: the plan's persistent stem (stem3.hip) sums the 27 im2col products in another order inside the MFMA than
+        # conv1 -> pool1 of the op-by-op graph: 1-ulp flips in ~6e-5 of pool1's elements, which reach preds as the same
+        # noise any fp16 rounding difference does (observed 2e-3 of the largest value; the oracle check below allows
+        # 5e-3); with the strip stem (stem_algo = 2) the two paths are bitwise equal as before
+        d = (p_plan.float() - p_graph.float()).abs().max().item()
+        scale = p_graph.float().abs().max().item()
+        assert d <= 4e-3 * scale + 1e-4, "plan vs graph: %g of %g" % (d, scale)
+        from squeezedet_amd import ops
+        ops.set_option("stem_algo", 2)
+        try:
+            p_strip = m.run([m.preds], {m.image_input: x}, use_plan=True)[0]
+            torch.cuda.synchronize()
+        finally:
+            ops.set_option("stem_algo", 0)
+        assert torch.equal(p_strip, p_graph), "native plan (strip stem) and op-by-op graph must run the same kernels"
     ref = O.forward("squeezeDet", params, x, storage)
     _check_layers(p_plan, ref, dtype, "preds")
 

@@ -411,7 +411,9 @@ def test_cpu_tensors_are_rejected():
 
 
 STEM_CASES = [(2, 37, 53, 3, 64, "SAME", "SAME"), (1, 375, 1242, 3, 64, "SAME", "SAME"), (1, 384, 1248, 3, 64, "SAME", "SAME"),
-              (1, 64, 80, 3, 64, "SAME", "SAME"), (1, 75, 131, 7, 96, "VALID", "VALID"), (1, 375, 1242, 7, 96, "VALID", "VALID")]
+              (1, 64, 80, 3, 64, "SAME", "SAME"), (1, 75, 131, 7, 96, "VALID", "VALID"), (1, 375, 1242, 7, 96, "VALID", "VALID"),
+              # the persistent fp16 stem (even W >= 236): several images, ragged last tiles, VALID conv padding
+              (3, 45, 250, 3, 64, "SAME", "SAME"), (2, 100, 236, 3, 64, "VALID", "SAME"), (5, 19, 480, 3, 64, "SAME", "VALID")]
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
@@ -435,7 +437,21 @@ def test_fused_stem_conv_pool_parity(case, dtype):
     y2 = ops.maxpool_nhwc(ops.conv2d_nhwc(xd, packed, bd, 2, cpad, True), 3, 2, ppad)
     torch.cuda.synchronize()
     assert tuple(y.shape) == ref.shape
-    assert torch.equal(y, y2), "fused stem differs from conv -> pool"
+    if dtype == "fp16" and k == 3 and W % 2 == 0 and W * 6 >= 1408:
+        # the persistent fp16 stem (stem3.hip) walks the 27 im2col products in a different K order inside the MFMA:
+        # float32 summation order -> identical after fp16 rounding except for a 1-ulp flip in < 1e-3 of the elements
+        # (observed 6e-5); every other path is bitwise
+        ulps = (y.view(torch.int16).int() - y2.view(torch.int16).int()).abs()
+        gap = (y.float() - y2.float()).abs()
+        # (next to zero -- a cancelling sum behind the ReLU -- the ulp is tiny and the float32 noise is not: absolute bound)
+        assert bool(((ulps <= 1) | (gap <= 2e-5)).all()) and float((ulps != 0).float().mean()) < 1e-3, \
+            "persistent stem vs conv -> pool: %d ulps, %g" % (int(ulps.max()), float(gap.max()))
+        ops.set_option("stem_algo", 2)
+        y3 = ops.stem_conv_pool(xd, packed, bd, cpad, ppad)
+        ops.set_option("stem_algo", 0)
+        assert torch.equal(y3, y2), "strip stem differs from conv -> pool"
+    else:
+        assert torch.equal(y, y2), "fused stem differs from conv -> pool"
     tol = dict(rtol=1e-3, atol=1e-4) if dtype == "fp32" else dict(rtol=2 ** -9, atol=1e-3)
     np.testing.assert_allclose(y.float().cpu().numpy(), ref, **tol)
 
