@@ -23,6 +23,7 @@ SOURCES = [
     ("conv.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("conv3x3.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("conv1x1.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    ("gemm1x1.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("stem.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("stem2.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("stem3.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),

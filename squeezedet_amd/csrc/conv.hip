@@ -288,7 +288,8 @@ int conv2d_launch(const void* x, const void* w_packed, const float* bias, void* 
 }
 
 // x_cstride / x_coffset: the input is channels [x_coffset, x_coffset+cin) of rows x_cstride wide;
-// accum: y += conv(x) instead of y = conv(x).  Both are served by the generic kernel only.
+// accum: y += conv(x) instead of y = conv(x).  Channel slices are served by the generic kernel only; accumulating 1x1 /
+// stride-1 convs over a whole tensor also by conv1x1_tile.
 int conv2d_launch_ex(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
                      int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
                      int x_cstride, int x_coffset, int accum, hipStream_t st) {
@@ -329,6 +330,10 @@ int conv2d_launch_ex(const void* x, const void* w_packed, const float* bias, voi
     rc = conv3x3_tile_launch(a, g, dtype, st, &handled);
     if (rc != SQDET_OK || handled) return rc;
     rc = conv1x1_stream_launch(a, g, dtype, st, &handled);
+    if (rc != SQDET_OK || handled) return rc;
+  }
+  if (bias != nullptr) {   // deep-K 1x1 (incl. the residual-accumulate form): workgroup GEMM tile, gemm1x1.hip
+    rc = conv1x1_tile_launch(a, g, dtype, st, &handled);
     if (rc != SQDET_OK || handled) return rc;
   }
   rc = dtype == SQDET_F16 ? dispatch_mt<f16>(a, g.nt, g.gather, st) : dispatch_mt<float>(a, g.nt, g.gather, st);

@@ -33,6 +33,7 @@ struct TileArgs {
   int nchunk;       // 64-byte K chunks per pixel (ceil)
   int pieces;       // 16-byte pieces per pixel actually present = Cin*sizeof(T)/16
   unsigned x_bytes; // size of the input tensor (split-K mode: 32-bit buffer offsets)
+  int stage_chunks; // cout-split mode: K-chunks of the halo tile resident in LDS at a time (deep K is walked in stages)
 };
 
 // Stage `nload` K-chunks starting at chunk c0 of the halo tile into LDS.
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
     for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const i32x4* wbase = reinterpret_cast<const i32x4*>(a.c.wp) + ((size_t)group * a.c.steps * a.nt_pack + n0) * 64 + lane;
-  const int nstages = SPLITK ? (a.nchunk + 3) / 4 : 1;
+  const int nstages = SPLITK ? (a.nchunk + 3) / 4 : (a.nchunk + a.stage_chunks - 1) / a.stage_chunks;
 
   if constexpr (SPLITK) {
     // Wave w walks chunk 4*stage + w of every stage, 9 taps each: one 5-KiB weight step per 40 MFMAs (~0.27 us of
@@ -215,8 +216,9 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
     }
   } else
   for (int stage = 0; stage < nstages; ++stage) {
-    const int c0 = SPLITK ? stage * 4 : 0;
-    const int nload = SPLITK ? (a.nchunk - c0 < 4 ? a.nchunk - c0 : 4) : a.nchunk;
+    const int sc = SPLITK ? 4 : a.stage_chunks;
+    const int c0 = stage * sc;
+    const int nload = a.nchunk - c0 < sc ? a.nchunk - c0 : sc;
     if (stage > 0) __syncthreads();  // everyone done reading the previous stage
     stage_tile<T>(a, lds, n, oy0, ox0, c0, nload);
     __syncthreads();
@@ -422,6 +424,7 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
   a.total_tiles = g.nt * g.ngroups;
   a.nchunk = g.nchunk;
   a.pieces = c.Cin * esz / 16;
+  a.stage_chunks = g.nchunk;
   if ((long)c.N * a.tiles_x * a.tiles_y > 0x7fffffffL) return SQDET_OK;
 
   int ntw = g.nt, mt = 2;
@@ -437,12 +440,15 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
     lds = 4 * (size_t)CHUNK_BYTES;                         // 46080 B
     const size_t red = (size_t)12 * (TROWS / 4) * 5 * 1024;   // 122880 B: reduce-scatter slots [owner][source]
     if (red > lds) lds = red;
-  } else if (g.nchunk <= 5) {
+  } else {
     // a wave owns one whole packed group; 2 groups per workgroup (waves 2 rows x 2 groups) when
     // there are several, else the 4 waves split the 8 tile rows
     // Measured on MI355X (tools/kbench.py, batch 32): MFMA-bound deep-K layers (fire10/11: 96 -> 384)
     // want MT = 8 (one A fragment from L1 feeds 8 MFMAs); the mid layers want whole-group waves.
-    lds = (size_t)g.nchunk * CHUNK_BYTES;                  // <= 57600 B
+    // up to 6 K-chunks (192 fp16 channels) the whole halo tile is resident; deeper K (SqueezeDet+ fire6-11: 9 / 12 chunks,
+    // ResNet50 res4 / res5: 8 / 16) is walked in stages of 4 chunks = 46 KB, three workgroups per CU hiding each other's staging
+    a.stage_chunks = g.nchunk <= 6 ? g.nchunk : 4;
+    lds = (size_t)a.stage_chunks * CHUNK_BYTES;
     if (g.nt == 6 && g.ngroups >= 2 && g.nchunk >= 3) {
       mt = 8; ntw = 3;
       grid_y = (a.total_tiles + 11) / 12;
@@ -454,8 +460,6 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
       const int wc = mt == 4 ? 2 : 1;
       grid_y = (g.ngroups + wc - 1) / wc;
     }
-  } else {
-    return SQDET_OK;
   }
   const bool ok = dtype == SQDET_F16 ? dispatch_tile<f16>(a, mt, ntw, splitk, grid_y, lds, st)
                                      : dispatch_tile<float>(a, mt, ntw, splitk, grid_y, lds, st);

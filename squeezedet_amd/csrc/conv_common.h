@@ -108,5 +108,6 @@ int fire_expand_squeeze_next_launch(const void* sq_in, const void* w1, const flo
                                     int s2, int pool, int dtype, hipStream_t st, bool* handled);
 int conv3x3_tile_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);
 int conv1x1_stream_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);
+int conv1x1_tile_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);   // gemm1x1.hip
 
 }  // namespace sqdet

@@ -1,0 +1,205 @@
+// 1x1 / stride-1 convolution with deep K as a workgroup-level GEMM tile (the squeeze / expand1x1 layers of SqueezeDet+,
+// every 1x1 of ResNet50's bottleneck blocks incl. the residual-accumulate ones; reference src/nn_skeleton.py:471-563 via
+// nets/squeezeDetPlus.py:81-106 and nets/resnet50_convDet.py:134-169).
+//
+// The generic conv_direct lets every wave fetch BOTH operands itself (8 KB per 16 MFMAs: the four SIMDs ask the CU's
+// 64 B/clk L1 for about twice what it delivers); conv1x1_stream keeps the weights in registers and only fits K <= 4
+// chunks.  Here a 256-thread workgroup owns 16*MB consecutive NHWC pixels (a 1x1 conv has no halo: "pixel" = row of the
+// [P, Cin] activation matrix) and up to 4*NTW cout tiles:
+//   * the activations of the tile are staged into LDS in stages of SC 64-byte K-chunks, laid out [chunk][pixel][4 x 16 B]
+//     with the 16-byte slot of lane group g stored at g ^ ((pixel>>1)&3) (conv3x3.hip's bank-conflict-free layout), so
+//     each activation byte crosses L2 -> CU once per workgroup and is read from LDS by the four waves;
+//   * a wave owns all MB pixel blocks x NTW cout tiles (MB*NTW accumulators) -- one 1-KiB weight fragment from L1 feeds MB
+//     MFMAs, one LDS B fragment NTW of them: (NTW + MB) KiB of operands per MB*NTW MFMAs;
+//   * weight fragments come straight from global one K-chunk ahead (register double buffer), across the staging barriers;
+//   * epilogue: bias (+ the residual already in y: ResNet's branch2c) + ReLU, 8*NTW contiguous bytes per lane.
+// Accumulation order = ascending K chunks, as in every other conv kernel here (bitwise-equal to conv_direct).
+#include "conv_common.h"
+
+namespace sqdet {
+namespace {
+
+struct G1Args {
+  ConvArgs c;
+  int nt_pack;       // tiles per packed cout group
+  int slices;        // wave slices = ngroups * (nt_pack / NTW)
+  int grid_y;        // workgroups per pixel tile = ceil(slices / 4)
+  int ptiles;        // pixel tiles
+  int pieces;        // 16-byte pieces per pixel = Cin * sizeof(T) / 16
+  int stage_chunks;  // K-chunks resident in LDS at a time
+};
+
+template <typename T, int MB, int NTW>
+__global__ __launch_bounds__(256) void conv1x1_tile(G1Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int TP = 16 * MB;            // pixels per tile
+  constexpr int CH = TP * 64;            // bytes of one K-chunk of the tile
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  // XCD-aware order: workgroup L runs on XCD L % 8; every XCD gets a contiguous band of pixel tiles, and the grid_y
+  // workgroups that share a pixel tile (different couts) are neighbours on the same XCD (the tile is fetched into ONE L2)
+  const int per_xcd = (a.ptiles + 7) / 8;
+  const int idx = (int)(blockIdx.x >> 3);
+  const int tl = idx / a.grid_y, ysl = idx - tl * a.grid_y;
+  const int tile = (int)(blockIdx.x & 7) * per_xcd + tl;
+  if (tl >= per_xcd || tile >= a.ptiles) return;
+  const int p0 = tile * TP;
+
+  const int slice = ysl * 4 + wave;
+  const bool active = slice < a.slices;
+  const int spg = a.nt_pack / NTW;       // slices per packed group
+  const int group = active ? slice / spg : 0;
+  const int n0 = active ? (slice - group * spg) * NTW : 0;
+
+  f32x4 acc[MB][NTW];
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const i32x4* wbase = reinterpret_cast<const i32x4*>(a.c.wp) + ((size_t)group * a.c.steps * a.nt_pack + n0) * 64 + lane;
+  auto wptr = [&](int c) { return wbase + (size_t)c * a.nt_pack * 64; };
+  i32x4 af[NTW], afn[NTW];
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) af[t] = wptr(0)[t * 64];
+  }
+
+  const unsigned char* x = reinterpret_cast<const unsigned char*>(a.c.x);
+  const int row_bytes = a.pieces * 16;
+  const int nchunk = a.c.nchunk;
+  for (int c0 = 0; c0 < nchunk; c0 += a.stage_chunks) {
+    const int nload = nchunk - c0 < a.stage_chunks ? nchunk - c0 : a.stage_chunks;
+    if (c0 > 0) __syncthreads();           // everyone is done reading the previous stage
+    {
+      // stage nload chunks of the tile: batches of 4 loads in flight per thread before the LDS stores
+      const int ppc = nload * 4, total = TP * ppc;
+      for (int base = threadIdx.x; base < total; base += 256 * 4) {
+        i32x4 v[4];
+        int off[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int id = base + u * 256;
+          const int P = id / ppc, q = id - P * ppc;
+          const int gq = c0 * 4 + q;
+          v[u] = i32x4{0, 0, 0, 0};
+          if (id < total && gq < a.pieces && p0 + P < a.c.P)
+            v[u] = *reinterpret_cast<const i32x4*>(x + (size_t)(p0 + P) * row_bytes + gq * 16);
+          off[u] = id < total ? (q >> 2) * CH + P * 64 + (((q & 3) ^ ((P >> 1) & 3)) << 4) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (off[u] >= 0) *reinterpret_cast<i32x4*>(lds + off[u]) = v[u];
+      }
+    }
+    __syncthreads();
+    if (!active) continue;
+#pragma unroll 1
+    for (int cl = 0; cl < nload; ++cl) {
+      const int c = c0 + cl;
+      if (c + 1 < nchunk) {
+        const i32x4* wp = wptr(c + 1);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) afn[t] = wp[t * 64];
+      }
+      const unsigned char* lc = lds + cl * CH + j * 64 + ((g ^ ((j >> 1) & 3)) << 4);   // pixel m*16 + j: (P>>1)&3 == (j>>1)&3
+      i32x4 bf[MB];
+#pragma unroll
+      for (int m = 0; m < MB; ++m) bf[m] = *reinterpret_cast<const i32x4*>(lc + m * 16 * 64);
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], af[t], bf[m]);
+      if (c + 1 < nchunk) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) af[t] = afn[t];
+      }
+    }
+  }
+  if (!active) return;
+
+  // epilogue: lane = pixel (block m, column j); couts group*16*NTp + g*4*NTp + n0*4 .. : 4*NTW consecutive
+  T* y = reinterpret_cast<T*>(a.c.y);
+  const int cb = group * 16 * a.nt_pack + g * 4 * a.nt_pack + n0 * 4;
+  f32x4 bias[NTW];
+  int nt_valid = 0;   // Cout is a multiple of 4: whole 4-cout pieces beyond Cout are skipped
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const bool ok = cb + t * 4 < a.c.Cout;
+    bias[t] = ok ? *reinterpret_cast<const f32x4*>(a.c.bias + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    nt_valid += ok ? 1 : 0;
+  }
+#pragma unroll
+  for (int m = 0; m < MB; ++m) {
+    const int p = p0 + m * 16 + j;
+    if (p >= a.c.P) continue;
+    T* dst = y + (size_t)p * a.c.y_cstride + a.c.y_coffset + cb;
+    f32x4 v[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      v[t] = acc[m][t] + bias[t];
+      if (a.c.accum && t < nt_valid) {
+        v[t][0] += (float)dst[t * 4 + 0]; v[t][1] += (float)dst[t * 4 + 1];
+        v[t][2] += (float)dst[t * 4 + 2]; v[t][3] += (float)dst[t * 4 + 3];
+      }
+      if (a.c.relu) {
+        v[t][0] = fmaxf(v[t][0], 0.f); v[t][1] = fmaxf(v[t][1], 0.f);
+        v[t][2] = fmaxf(v[t][2], 0.f); v[t][3] = fmaxf(v[t][3], 0.f);
+      }
+    }
+    store_couts<T, NTW>(dst, v, nt_valid);
+  }
+}
+
+template <typename T, int MB, int NTW>
+void launch_g1(const G1Args& a, size_t lds, hipStream_t st) {
+  const int per_xcd = (a.ptiles + 7) / 8;
+  const dim3 grid((unsigned)(per_xcd * a.grid_y * 8));
+  hipLaunchKernelGGL((conv1x1_tile<T, MB, NTW>), grid, dim3(256), lds, st, a);
+}
+
+template <typename T, int MB>
+bool dispatch_g1(const G1Args& a, int ntw, size_t lds, hipStream_t st) {
+  switch (ntw) {
+    case 1: launch_g1<T, MB, 1>(a, lds, st); return true;
+    case 2: launch_g1<T, MB, 2>(a, lds, st); return true;
+    case 3: launch_g1<T, MB, 3>(a, lds, st); return true;
+    case 4: launch_g1<T, MB, 4>(a, lds, st); return true;
+    case 5: launch_g1<T, MB, 5>(a, lds, st); return true;
+    default: return false;
+  }
+}
+
+}  // namespace
+
+// Eligibility + configuration.  *handled = false means "use the generic kernel".  Serves plain and residual-accumulate
+// (accum) 1x1 / stride-1 convolutions whose input is a whole tensor (no channel slice) with Cin a multiple of the lane chunk.
+int conv1x1_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (conv_algo() != 0) return SQDET_OK;
+  if (c.k != 1 || c.stride != 1 || g.gather || !c.bias) return SQDET_OK;
+  if (c.x_cstride != c.Cin || c.x_coffset != 0) return SQDET_OK;
+  const int esz = dtype == SQDET_F16 ? 2 : 4;
+  if ((c.Cin * esz) % 16 != 0) return SQDET_OK;
+  G1Args a;
+  a.c = c;
+  a.nt_pack = g.nt;
+  a.pieces = c.Cin * esz / 16;
+  const int ntw = g.nt <= 5 ? g.nt : g.nt / 2;            // 6-tile groups: two waves per group (accumulator budget)
+  a.slices = g.ngroups * (g.nt / ntw);
+  a.grid_y = (a.slices + 3) / 4;
+  // 128-pixel tiles unless that leaves the chip under-filled (the 24x78 maps at batch 8: 117 tiles)
+  int mb = 8;
+  if ((long)((c.P + 127) / 128) * a.grid_y < 768 || ntw == 5) mb = 4;
+  a.ptiles = (c.P + 16 * mb - 1) / (16 * mb);
+  a.stage_chunks = g.nchunk < 4 ? g.nchunk : 4;
+  const size_t lds = (size_t)a.stage_chunks * 16 * mb * 64;   // <= 32 KiB
+  const bool ok = dtype == SQDET_F16 ? (mb == 8 ? dispatch_g1<f16, 8>(a, ntw, lds, st) : dispatch_g1<f16, 4>(a, ntw, lds, st))
+                                     : (mb == 8 ? dispatch_g1<float, 8>(a, ntw, lds, st) : dispatch_g1<float, 4>(a, ntw, lds, st));
+  if (!ok) return SQDET_OK;
+  SQDET_CHECK_HIP(hipGetLastError());
+  *handled = true;
+  return SQDET_OK;
+}
+
+}  // namespace sqdet

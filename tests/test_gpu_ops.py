@@ -81,6 +81,18 @@ CONV_CASES = [
     ("e3_cin32_cout72", 1, 11, 19, 32, 72, 3, 1, "SAME", True),
     ("e3_cin16_cout32", 1, 10, 33, 16, 32, 3, 1, "SAME", True),
     ("e3_cin64_cout48", 1, 9, 17, 64, 48, 3, 1, "SAME", True),
+    # deep-K 1x1 as a workgroup GEMM tile (gemm1x1.hip): 3 / 4 / 5 cout tiles per wave, ragged last pixel tile, K staged in
+    # several 4-chunk stages, more slices than one workgroup's four waves (SqueezeDet+ squeeze / expand, ResNet50 1x1)
+    ("g1_k512_n384", 1, 22, 76, 512, 384, 1, 1, "SAME", True),
+    ("g1_k384_n256", 2, 9, 23, 384, 256, 1, 1, "SAME", True),
+    ("g1_k256_n72", 1, 13, 29, 256, 72, 1, 1, "SAME", False),
+    ("g1_k2048_n512", 1, 7, 9, 2048, 512, 1, 1, "SAME", True),
+    ("g1_k1024_n2048", 1, 5, 11, 1024, 2048, 1, 1, "SAME", False),
+    ("g1_k264_n40", 3, 11, 7, 264, 40, 1, 1, "SAME", True),
+    # 3x3 with K walked in 4-chunk LDS stages (SqueezeDet+ fire6-11: 9 / 12 chunks in fp16; ResNet50 res4 / res5)
+    ("e3_k288_n192", 1, 17, 30, 288, 192, 3, 1, "SAME", True),
+    ("e3_k384_n256", 2, 9, 19, 384, 256, 3, 1, "SAME", True),
+    ("e3_k512_n512", 1, 8, 16, 512, 512, 3, 1, "SAME", True),
 ]
 
 

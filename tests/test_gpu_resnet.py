@@ -40,8 +40,9 @@ def test_fold_batchnorm_kernel(with_bias):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
-@pytest.mark.parametrize("shape", [(1, 13, 17, 64, 256, 1), (2, 9, 11, 256, 1024, 1), (1, 8, 12, 32, 48, 3)],
-                         ids=["64->256", "256->1024", "3x3"])
+@pytest.mark.parametrize("shape", [(1, 13, 17, 64, 256, 1), (2, 9, 11, 256, 1024, 1), (1, 8, 12, 32, 48, 3),
+                                   (1, 24, 78, 512, 2048, 1), (3, 7, 5, 128, 512, 1)],
+                         ids=["64->256", "256->1024", "3x3", "512->2048", "128->512-ragged"])
 def test_conv_residual_add_epilogue(dtype, shape):
     """sqdet_conv2d_add_nhwc_fwd: y = relu(conv(x) + b + y), the residual add of resnet50_convDet.py:55."""
     from squeezedet_amd import ops
