@@ -9,8 +9,11 @@
 //   * the activations of the tile are staged into LDS in stages of SC 64-byte K-chunks, laid out [chunk][pixel][4 x 16 B]
 //     with the 16-byte slot of lane group g stored at g ^ ((pixel>>1)&3) (conv3x3.hip's bank-conflict-free layout), so
 //     each activation byte crosses L2 -> CU once per workgroup and is read from LDS by the four waves;
-//   * a wave owns all MB pixel blocks x NTW cout tiles (MB*NTW accumulators) -- one 1-KiB weight fragment from L1 feeds MB
-//     MFMAs, one LDS B fragment NTW of them: (NTW + MB) KiB of operands per MB*NTW MFMAs;
+//   * a wave owns MBW pixel blocks x NTW cout tiles (MBW*NTW accumulators) -- one 1-KiB weight fragment from L1 feeds MBW
+//     MFMAs, one LDS B fragment NTW of them: (NTW + MBW) KiB of operands per MBW*NTW MFMAs.  The four waves are laid out
+//     WR along the pixel blocks x 4/WR along the cout slices: WR = 1 when the conv has >= 4 slices (a slice = NTW cout
+//     tiles), 2 or 4 when it has fewer (ResNet50's 256 -> 64 reductions have ONE: without the pixel split three of the
+//     four waves only helped staging);
 //   * weight fragments come straight from global one K-chunk ahead (register double buffer), across the staging barriers;
 //   * epilogue: bias (+ the residual already in y: ResNet's branch2c) + ReLU, 8*NTW contiguous bytes per lane.
 // Accumulation order = ascending K chunks, as in every other conv kernel here (bitwise-equal to conv_direct).
@@ -23,15 +26,17 @@ struct G1Args {
   ConvArgs c;
   int nt_pack;       // tiles per packed cout group
   int slices;        // wave slices = ngroups * (nt_pack / NTW)
-  int grid_y;        // workgroups per pixel tile = ceil(slices / 4)
+  int grid_y;        // workgroups per pixel tile = ceil(slices / (4 / WR))
   int ptiles;        // pixel tiles
   int pieces;        // 16-byte pieces per pixel = Cin * sizeof(T) / 16
   int stage_chunks;  // K-chunks resident in LDS at a time
 };
 
-template <typename T, int MB, int NTW>
+template <typename T, int MBW, int NTW, int WR>
 __global__ __launch_bounds__(256) void conv1x1_tile(G1Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int MB = MBW * WR;           // pixel blocks per tile
+  constexpr int WS = 4 / WR;             // cout slices per workgroup
   constexpr int TP = 16 * MB;            // pixels per tile
   constexpr int CH = TP * 64;            // bytes of one K-chunk of the tile
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -45,15 +50,16 @@ __global__ __launch_bounds__(256) void conv1x1_tile(G1Args a) {
   if (tl >= per_xcd || tile >= a.ptiles) return;
   const int p0 = tile * TP;
 
-  const int slice = ysl * 4 + wave;
+  const int wr = wave % WR;              // this wave's pixel blocks: wr*MBW ..
+  const int slice = ysl * WS + wave / WR;
   const bool active = slice < a.slices;
   const int spg = a.nt_pack / NTW;       // slices per packed group
   const int group = active ? slice / spg : 0;
   const int n0 = active ? (slice - group * spg) * NTW : 0;
 
-  f32x4 acc[MB][NTW];
+  f32x4 acc[MBW][NTW];
 #pragma unroll
-  for (int m = 0; m < MB; ++m)
+  for (int m = 0; m < MBW; ++m)
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -102,12 +108,13 @@ __global__ __launch_bounds__(256) void conv1x1_tile(G1Args a) {
 #pragma unroll
         for (int t = 0; t < NTW; ++t) afn[t] = wp[t * 64];
       }
-      const unsigned char* lc = lds + cl * CH + j * 64 + ((g ^ ((j >> 1) & 3)) << 4);   // pixel m*16 + j: (P>>1)&3 == (j>>1)&3
-      i32x4 bf[MB];
+      // pixel (wr*MBW + m)*16 + j: (P>>1)&3 == (j>>1)&3
+      const unsigned char* lc = lds + cl * CH + (wr * MBW * 16 + j) * 64 + ((g ^ ((j >> 1) & 3)) << 4);
+      i32x4 bf[MBW];
 #pragma unroll
-      for (int m = 0; m < MB; ++m) bf[m] = *reinterpret_cast<const i32x4*>(lc + m * 16 * 64);
+      for (int m = 0; m < MBW; ++m) bf[m] = *reinterpret_cast<const i32x4*>(lc + m * 16 * 64);
 #pragma unroll
-      for (int m = 0; m < MB; ++m)
+      for (int m = 0; m < MBW; ++m)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], af[t], bf[m]);
       if (c + 1 < nchunk) {
@@ -130,8 +137,8 @@ __global__ __launch_bounds__(256) void conv1x1_tile(G1Args a) {
     nt_valid += ok ? 1 : 0;
   }
 #pragma unroll
-  for (int m = 0; m < MB; ++m) {
-    const int p = p0 + m * 16 + j;
+  for (int m = 0; m < MBW; ++m) {
+    const int p = p0 + (wr * MBW + m) * 16 + j;
     if (p >= a.c.P) continue;
     T* dst = y + (size_t)p * a.c.y_cstride + a.c.y_coffset + cb;
     f32x4 v[NTW];
@@ -151,23 +158,28 @@ __global__ __launch_bounds__(256) void conv1x1_tile(G1Args a) {
   }
 }
 
-template <typename T, int MB, int NTW>
+template <typename T, int MBW, int NTW, int WR>
 void launch_g1(const G1Args& a, size_t lds, hipStream_t st) {
   const int per_xcd = (a.ptiles + 7) / 8;
   const dim3 grid((unsigned)(per_xcd * a.grid_y * 8));
-  hipLaunchKernelGGL((conv1x1_tile<T, MB, NTW>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv1x1_tile<T, MBW, NTW, WR>), grid, dim3(256), lds, st, a);
 }
 
-template <typename T, int MB>
-bool dispatch_g1(const G1Args& a, int ntw, size_t lds, hipStream_t st) {
+template <typename T, int MBW, int WR>
+bool dispatch_ntw(const G1Args& a, int ntw, size_t lds, hipStream_t st) {
   switch (ntw) {
-    case 1: launch_g1<T, MB, 1>(a, lds, st); return true;
-    case 2: launch_g1<T, MB, 2>(a, lds, st); return true;
-    case 3: launch_g1<T, MB, 3>(a, lds, st); return true;
-    case 4: launch_g1<T, MB, 4>(a, lds, st); return true;
-    case 5: launch_g1<T, MB, 5>(a, lds, st); return true;
+    case 3: launch_g1<T, MBW, 3, WR>(a, lds, st); return true;
+    case 4: launch_g1<T, MBW, 4, WR>(a, lds, st); return true;
+    case 5: if constexpr (MBW <= 4) { launch_g1<T, MBW, 5, WR>(a, lds, st); return true; } return false;
     default: return false;
   }
+}
+
+template <typename T>
+bool dispatch_g1(const G1Args& a, int mbw, int wr, int ntw, size_t lds, hipStream_t st) {
+  if (wr == 1) return mbw == 8 ? dispatch_ntw<T, 8, 1>(a, ntw, lds, st) : dispatch_ntw<T, 4, 1>(a, ntw, lds, st);
+  if (wr == 2) return mbw == 4 ? dispatch_ntw<T, 4, 2>(a, ntw, lds, st) : dispatch_ntw<T, 2, 2>(a, ntw, lds, st);
+  return mbw == 4 ? dispatch_ntw<T, 4, 4>(a, ntw, lds, st) : dispatch_ntw<T, 2, 4>(a, ntw, lds, st);
 }
 
 }  // namespace
@@ -180,22 +192,24 @@ int conv1x1_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
   if (c.k != 1 || c.stride != 1 || g.gather || !c.bias) return SQDET_OK;
   if (c.x_cstride != c.Cin || c.x_coffset != 0) return SQDET_OK;
   const int esz = dtype == SQDET_F16 ? 2 : 4;
-  if ((c.Cin * esz) % 16 != 0) return SQDET_OK;
+  if ((c.Cin * esz) % 16 != 0 || g.nt < 3) return SQDET_OK;   // (1- and 2-tile groups, Cout <= 32: generic kernel)
   G1Args a;
   a.c = c;
   a.nt_pack = g.nt;
   a.pieces = c.Cin * esz / 16;
   const int ntw = g.nt <= 5 ? g.nt : g.nt / 2;            // 6-tile groups: two waves per group (accumulator budget)
   a.slices = g.ngroups * (g.nt / ntw);
-  a.grid_y = (a.slices + 3) / 4;
-  // 128-pixel tiles unless that leaves the chip under-filled (the 24x78 maps at batch 8: 117 tiles)
-  int mb = 8;
-  if ((long)((c.P + 127) / 128) * a.grid_y < 768 || ntw == 5) mb = 4;
-  a.ptiles = (c.P + 16 * mb - 1) / (16 * mb);
+  const int wr = a.slices >= 4 ? 1 : a.slices >= 2 ? 2 : 4;   // waves along the pixel blocks
+  a.grid_y = (a.slices + 4 / wr - 1) / (4 / wr);
+  // pixel blocks per wave: large tiles (128 pixels per wave column, 256 for the one-slice layout) unless that leaves the
+  // chip under-filled (the 24x78 maps at batch 8 are 15 k pixels)
+  int mbw = wr == 1 ? 8 : 4;
+  auto wgs = [&](int m) { return (long)((c.P + 16 * m * wr - 1) / (16 * m * wr)) * a.grid_y; };
+  if (wgs(mbw) < 768 || (wr == 1 && ntw == 5)) mbw /= 2;
+  a.ptiles = (c.P + 16 * mbw * wr - 1) / (16 * mbw * wr);
   a.stage_chunks = g.nchunk < 4 ? g.nchunk : 4;
-  const size_t lds = (size_t)a.stage_chunks * 16 * mb * 64;   // <= 32 KiB
-  const bool ok = dtype == SQDET_F16 ? (mb == 8 ? dispatch_g1<f16, 8>(a, ntw, lds, st) : dispatch_g1<f16, 4>(a, ntw, lds, st))
-                                     : (mb == 8 ? dispatch_g1<float, 8>(a, ntw, lds, st) : dispatch_g1<float, 4>(a, ntw, lds, st));
+  const size_t lds = (size_t)a.stage_chunks * 16 * mbw * wr * 64;   // <= 64 KiB
+  const bool ok = dtype == SQDET_F16 ? dispatch_g1<f16>(a, mbw, wr, ntw, lds, st) : dispatch_g1<float>(a, mbw, wr, ntw, lds, st);
   if (!ok) return SQDET_OK;
   SQDET_CHECK_HIP(hipGetLastError());
   *handled = true;

@@ -339,7 +339,8 @@ int run_layer_part(sqdet_net* net, const Layer& L, const void* input, void* pred
   }
   if (L.type == L_STEM) {
     const void* wp = net->param_mem + net->params[L.kparam].offset;
-    const float* b = reinterpret_cast<const float*>(net->param_mem + net->params[L.bparam].offset);
+    const float* b = reinterpret_cast<const float*>(
+        net->param_mem + (L.fold >= 0 ? net->folds[L.fold].fbias_off : net->params[L.bparam].offset));
     bool handled = false;
     const int rc = stem_launch(x, wp, b, y, nb, L.h, L.w, L.cout, L.k, L.pad_mode, L.pool_pad_mode, net->dtype,
                                L.y_cstride, L.y_coffset, st, &handled);
@@ -594,7 +595,7 @@ void fuse_stem(sqdet_net* net, size_t esz) {
   Layer& c = net->layers[0];
   const Layer& p = net->layers[1];
   if (c.type != L_CONV || p.type != L_POOL || c.cin != 3 || c.stride != 2 || !c.relu) return;
-  if (!((c.k == 3 && c.cout == 64) || (c.k == 7 && c.cout == 96))) return;
+  if (!((c.k == 3 && c.cout == 64) || (c.k == 7 && (c.cout == 96 || c.cout == 64)))) return;
   if (p.k != 3 || p.stride != 2 || p.in_buf != c.out_buf) return;
   Layer f = c;
   f.type = L_STEM;

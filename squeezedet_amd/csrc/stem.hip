@@ -186,7 +186,7 @@ int stem_launch(const void* x, const void* w_packed, const float* bias, void* y,
                 int conv_pad, int pool_pad, int dtype, int y_cstride, int y_coffset, hipStream_t st, bool* handled) {
   *handled = false;
   if (conv_algo() != 0) return SQDET_OK;
-  if (!((k == 3 && cout == 64) || (k == 7 && cout == 96))) return SQDET_OK;
+  if (!((k == 3 && cout == 64) || (k == 7 && (cout == 96 || cout == 64)))) return SQDET_OK;   // SqueezeDet, SqueezeDet+, ResNet50
   const ConvGeom g = conv_geom(k, 3, cout, dtype);
   if (!g.gather || g.ngroups != 1) return SQDET_OK;
   StemArgs a;
@@ -210,9 +210,9 @@ int stem_launch(const void* x, const void* w_packed, const float* bias, void* y,
   }
   int rc;
   if (dtype == SQDET_F16)
-    rc = k == 3 ? launch_stem<f16, 3, 4>(a, st) : launch_stem<f16, 7, 6>(a, st);
+    rc = k == 3 ? launch_stem<f16, 3, 4>(a, st) : cout == 96 ? launch_stem<f16, 7, 6>(a, st) : launch_stem<f16, 7, 4>(a, st);
   else
-    rc = k == 3 ? launch_stem<float, 3, 4>(a, st) : launch_stem<float, 7, 6>(a, st);
+    rc = k == 3 ? launch_stem<float, 3, 4>(a, st) : cout == 96 ? launch_stem<float, 7, 6>(a, st) : launch_stem<float, 7, 4>(a, st);
   if (rc != SQDET_OK) return rc;
   *handled = true;
   return SQDET_OK;
@@ -233,6 +233,6 @@ extern "C" int sqdet_stem_conv_pool_fwd(const void* x, const void* w_packed, con
   int rc = stem_launch(x, w_packed, bias, y, n, h, w, cout, k, conv_pad_mode, pool_pad_mode, dtype, cout, 0,
                        as_stream(stream), &handled);
   if (rc != SQDET_OK) return rc;
-  SQDET_UNSUPPORTED(!handled, "stem: only (k=3, cout=64) and (k=7, cout=96) stems are fused");
+  SQDET_UNSUPPORTED(!handled, "stem: only (k=3, cout=64) and (k=7, cout=96 or 64) stems are fused");
   return SQDET_OK;
 }

@@ -315,9 +315,11 @@ int stem_strip_launch(StemArgs a, int k, int dtype, hipStream_t st, bool* handle
   const bool aligned4 = dtype == SQDET_F32 || (a.W % 2 == 0 && a.plc % 2 == 0);
   int rc;
   if (dtype == SQDET_F16)
-    rc = k == 3 ? launch_strip<f16, 3, 4>(a, aligned4, st) : launch_strip<f16, 7, 6>(a, aligned4, st);
+    rc = k == 3 ? launch_strip<f16, 3, 4>(a, aligned4, st)
+                : a.Cout == 96 ? launch_strip<f16, 7, 6>(a, aligned4, st) : launch_strip<f16, 7, 4>(a, aligned4, st);
   else
-    rc = k == 3 ? launch_strip<float, 3, 4>(a, aligned4, st) : launch_strip<float, 7, 6>(a, aligned4, st);
+    rc = k == 3 ? launch_strip<float, 3, 4>(a, aligned4, st)
+                : a.Cout == 96 ? launch_strip<float, 7, 6>(a, aligned4, st) : launch_strip<float, 7, 4>(a, aligned4, st);
   if (rc != SQDET_OK) return rc;
   *handled = true;
   return SQDET_OK;
