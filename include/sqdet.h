@@ -215,7 +215,7 @@ int sqdet_filter_prediction(const float* boxes, const float* probs, const int64_
                             int32_t* out_count, int n, int num_anchors, int classes, int top_n, int max_out,
                             double nms_thresh, float prob_thresh, sqdet_stream_t stream);
 
-/* interpret_output + filter_prediction in ONE launch for the top-N branch (0 < top_n <= 64 < A <= 20480: every reference
+/* interpret_output + filter_prediction in ONE call (two launches: scores chip-wide, then one workgroup per image) for the top-N branch (0 < top_n <= 64 < A <= 20480: every reference
  * config): the scores of all anchors are computed on the fly, boxes and classes are decoded for the <= top_n selected
  * anchors only -- det_boxes / det_class (0.47 MB per image in the reference's sess.run) never exist.  Same float
  * expressions as sqdet_interpret_output, same selection / NMS as sqdet_filter_prediction: identical outputs.

@@ -475,7 +475,7 @@ class ModelSkeleton:
             with torch.cuda.stream(self.post_stream):
                 self.post_stream.wait_event(s["fwd_done"])
                 if ops.detect_filter_supported(mc.ANCHORS, mc.TOP_N_DETECTION) and os.environ.get("SQDET_SPLIT_POST") != "1":
-                    # decode + top-N + NMS in ONE launch: boxes / classes are decoded for the selected anchors only
+                    # decode + top-N + NMS in one call (score kernel + filter kernel): boxes / classes are decoded for the selected anchors only
                     ops.detect_filter(s["preds"], self.anchors_f32(), mc.CLASSES, mc.ANCHOR_PER_GRID, mc.IMAGE_WIDTH, mc.IMAGE_HEIGHT,
                                       mc.EXP_THRESH, mc.TOP_N_DETECTION, mc.NMS_THRESH, scratch=s["det"][1], out=s["out"])
                 else:

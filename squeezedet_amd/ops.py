@@ -298,7 +298,7 @@ def detect_filter_supported(num_anchors, top_n):
 
 
 def detect_filter(preds, anchors_f32, classes, anchors_per_grid, img_w, img_h, exp_thresh, top_n, nms_thresh, scratch=None, out=None):
-    """interpret_output + filter_prediction (top-N branch) in one launch (sqdet_detect_filter): preds [N,gh,gw,K*(C+5)] ->
+    """interpret_output + filter_prediction (top-N branch) in one call (sqdet_detect_filter): preds [N,gh,gw,K*(C+5)] ->
     the five filter_prediction outputs; det_boxes / det_class are never materialised."""
     n, gh, gw, ch = [int(v) for v in preds.shape]
     A = gh * gw * anchors_per_grid
