@@ -99,7 +99,7 @@ def test_host_graph_and_native_plan_tables():
     assert (gh.value, gw.value, ch.value) == (24, 78, 72)
     fl, by = C.c_double(), C.c_double()
     tot, nl = 0.0, lib.sqdet_net_num_layers(h)
-    assert nl == 1 + 1 + 3 + 13 * 3 + 1          # conv1, pool1, 3 projection shortcuts, 39 branch convs, conv5
+    assert nl == 1 + 3 + 13 * 3 + 1          # conv1+pool1 (one fused-stem launch), 3 projection shortcuts, 39 branch convs, conv5
     for i in range(nl):
         assert lib.sqdet_net_layer_info(h, i, name, 128, C.byref(fl), C.byref(by)) == 0
         tot += fl.value
