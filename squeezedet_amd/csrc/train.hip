@@ -401,15 +401,23 @@ __global__ __launch_bounds__(256) void opt_apply_kernel(const OptSeg* __restrict
   }
 }
 
-// out[0] = sum of x[0..n) in a fixed order (one workgroup: per-thread strided partial sums, then a tree over LDS):
-// num_objects = sum(input_mask), nn_skeleton.py:180, without a device -> host round trip
-__global__ __launch_bounds__(256) void sum_f32_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
-  __shared__ float red[256];
-  float s = 0.f;
-  for (size_t i = threadIdx.x; i < n; i += 256) s += x[i];
-  red[threadIdx.x] = s;
+// out[0] = sum of x[0..n) in a fixed order (one 1024-thread workgroup: per-thread strided partial sums over 16-byte
+// vectors with four independent accumulators -- the first version walked 1300 dependent 4-byte loads per thread, 300 us of a
+// 12 ms training step --, then a tree over LDS): num_objects = sum(input_mask), nn_skeleton.py:180, without a device -> host
+// round trip
+__global__ __launch_bounds__(1024) void sum_f32_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+  __shared__ float red[1024];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  const size_t nv = vec ? n / 4 : 0;
+  for (size_t i = threadIdx.x; i < nv; i += 1024) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+  }
+  for (size_t i = nv * 4 + threadIdx.x; i < n; i += 1024) s0 += x[i];
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
+  for (int w = 512; w > 0; w >>= 1) {
     if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
     __syncthreads();
   }
@@ -574,7 +582,7 @@ extern "C" int sqdet_maxpool_nhwc_bwd(const void* x, const void* dy, void* dx, i
 
 extern "C" int sqdet_sum_f32(const float* x, size_t count, float* out, sqdet_stream_t stream) {
   SQDET_REQUIRE(x && out && count > 0, "sum_f32: bad arguments");
-  hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(256), 0, as_stream(stream), x, count, out);
+  hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(1024), 0, as_stream(stream), x, count, out);
   SQDET_CHECK_HIP(hipGetLastError());
   return SQDET_OK;
 }

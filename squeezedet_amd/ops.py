@@ -100,6 +100,11 @@ def maxpool_nhwc(x, size, stride, padding="SAME"):
     return y
 
 
+def stem_supported(cout, k):
+    """Shapes the fused conv1 + pool1 launch covers (sqdet_stem_conv_pool_fwd): SqueezeDet, SqueezeDet+ and ResNet50 stems."""
+    return (k == 3 and cout == 64) or (k == 7 and cout in (64, 96))
+
+
 def stem_conv_pool(x, packed, bias, conv_padding="SAME", pool_padding="SAME"):
     """conv1 + pool1 fused: max_pool3x3/s2(relu(conv(x, stride 2) + b)) (nets/squeezeDet.py:40-44)."""
     n, h, w, cin = [int(v) for v in x.shape]

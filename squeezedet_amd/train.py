@@ -253,9 +253,27 @@ class SqueezeDetTrainer(_TrainerBase):
         saved = []
         cur = x
         drop_in = None
-        for item in self.layers:
+        skip_pool = None
+        for li, item in enumerate(self.layers):
+            if item[0] == "pool" and item[2] is skip_pool:
+                continue
             if item[0] == "conv":
                 node = item[2]
+                nxt = self.layers[li + 1] if li + 1 < len(self.layers) else None
+                if (li == 0 and not keep_activations and not m.trainable[node.name + "/kernels"] and nxt is not None
+                        and nxt[0] == "pool" and nxt[2].attrs["size"] == 3 and nxt[2].attrs["stride"] == 2
+                        and node.attrs["stride"] == 2 and node.attrs["relu"]
+                        and ops.stem_supported(int(P[node.name + "/kernels"].shape[3]), int(P[node.name + "/kernels"].shape[0]))):
+                    # frozen conv1 + pool1 (nets/squeezeDet.py:40-44): nothing below pool1's output is needed by the
+                    # backward, so the fused stem launch serves the training forward too
+                    y = ops.stem_conv_pool(cur, self._pack(node.name), P[node.name + "/biases"], node.attrs["padding"],
+                                           nxt[2].attrs["padding"])
+                    saved.append(("conv", node, cur, None))
+                    saved.append(("pool", nxt[2], None, y))
+                    acts[nxt[2].name] = y
+                    cur = y
+                    skip_pool = nxt[2]
+                    continue
                 if node.name == "conv12":
                     drop_in = cur
                     if dropout_mask is None:
