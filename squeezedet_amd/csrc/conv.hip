@@ -326,13 +326,15 @@ int conv2d_launch_ex(const void* x, const void* w_packed, const float* bias, voi
   SQDET_UNSUPPORTED(!plain && g.gather, "conv2d: channel-sliced / accumulating convs need Cin %% %d == 0", kg_);
   bool handled = false;
   int rc = SQDET_OK;
-  if (plain) {
+  if (plain || !g.gather) {   // (the tile kernels also take channel-sliced inputs, no bias and y += : the backward-data convs)
     rc = conv3x3_tile_launch(a, g, dtype, st, &handled);
     if (rc != SQDET_OK || handled) return rc;
+  }
+  if (plain) {
     rc = conv1x1_stream_launch(a, g, dtype, st, &handled);
     if (rc != SQDET_OK || handled) return rc;
   }
-  if (bias != nullptr) {   // deep-K 1x1 (incl. the residual-accumulate form): workgroup GEMM tile, gemm1x1.hip
+  if (!g.gather) {   // deep-K 1x1 (incl. the accumulating / sliced forms): workgroup GEMM tile, gemm1x1.hip
     rc = conv1x1_tile_launch(a, g, dtype, st, &handled);
     if (rc != SQDET_OK || handled) return rc;
   }

@@ -40,8 +40,10 @@ struct TileArgs {
 template <typename T>
 __device__ __forceinline__ void stage_tile(const TileArgs& a, unsigned char* lds, int n, int oy0, int ox0, int c0,
                                            int nload) {
-  const unsigned char* x = reinterpret_cast<const unsigned char*>(a.c.x);
-  const int row_bytes = a.pieces * 16;  // bytes per pixel in global memory
+  // the input may be a channel slice [x_coffset, x_coffset + Cin) of rows x_cstride channels wide (backward-data of a fire
+  // module reads the expand3x3 half of dY)
+  const unsigned char* x = reinterpret_cast<const unsigned char*>(a.c.x) + (size_t)a.c.x_coffset * sizeof(T);
+  const int row_bytes = a.c.x_cstride * (int)sizeof(T);  // bytes per pixel in global memory
   const int ppc = nload * 4;            // pieces per pixel in this stage
   const int total = HP * ppc;
   // batches of 4 loads in flight per thread before the LDS stores (a load->store loop would pay the
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     const bool ok = cb + t * 4 < a.c.Cout;
-    bias[t] = ok ? *reinterpret_cast<const f32x4*>(a.c.bias + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bias[t] = ok && a.c.bias ? *reinterpret_cast<const f32x4*>(a.c.bias + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     nt_valid += ok ? 1 : 0;
   }
 
@@ -356,6 +358,10 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
 #pragma unroll
       for (int t = 0; t < NTW; ++t) {
         v[t] = acc[m][t] + bias[t];
+        if (a.c.accum && t < nt_valid) {   // y += conv(x): d(squeeze) = dgrad_1x1(dY[:, :e1]) + dgrad_3x3(dY[:, e1:])
+          v[t][0] += (float)dst[t * 4 + 0]; v[t][1] += (float)dst[t * 4 + 1];
+          v[t][2] += (float)dst[t * 4 + 2]; v[t][3] += (float)dst[t * 4 + 3];
+        }
         if (a.c.relu) {
           v[t][0] = fmaxf(v[t][0], 0.f); v[t][1] = fmaxf(v[t][1], 0.f);
           v[t][2] = fmaxf(v[t][2], 0.f); v[t][3] = fmaxf(v[t][3], 0.f);
@@ -415,7 +421,8 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
   if (c.k != 3 || c.stride != 1 || c.pt != 1 || c.pl != 1 || g.gather) return SQDET_OK;
   if (c.Ho != c.H || c.Wo != c.W) return SQDET_OK;
   const int esz = dtype == SQDET_F16 ? 2 : 4;
-  if ((c.Cin * esz) % 16 != 0) return SQDET_OK;
+  if ((c.Cin * esz) % 16 != 0 || (c.x_cstride * esz) % 16 != 0 || (c.x_coffset * esz) % 16 != 0) return SQDET_OK;
+  const bool plain = c.x_cstride == c.Cin && c.x_coffset == 0 && !c.accum && c.bias;
   TileArgs a;
   a.c = c;
   a.tiles_x = (c.W + TCOLS - 1) / TCOLS;
@@ -433,7 +440,7 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
   int grid_y = 1;
   const long x_bytes = (long)c.N * c.H * c.W * c.Cin * esz;
   a.x_bytes = (unsigned)(x_bytes < 0x7fffffffL ? x_bytes : 0);
-  if (g.nt == 5 && g.ngroups == 1 && g.nchunk >= 8 && g.nchunk % 4 == 0 && x_bytes < 0x7fffffffL) {
+  if (plain && g.nt == 5 && g.ngroups == 1 && g.nchunk >= 8 && g.nchunk % 4 == 0 && x_bytes < 0x7fffffffL) {
     // ConvDet-like: few couts, deep K -> split K over the 4 waves, 4 chunks per stage
     splitk = true;
     mt = 8;

@@ -71,8 +71,10 @@ __global__ __launch_bounds__(256) void conv1x1_tile(G1Args a) {
     for (int t = 0; t < NTW; ++t) af[t] = wptr(0)[t * 64];
   }
 
-  const unsigned char* x = reinterpret_cast<const unsigned char*>(a.c.x);
-  const int row_bytes = a.pieces * 16;
+  // the input may be a channel slice [x_coffset, x_coffset + Cin) of rows x_cstride channels wide (backward-data of a fire
+  // module reads the expand1x1 half of dY)
+  const unsigned char* x = reinterpret_cast<const unsigned char*>(a.c.x) + (size_t)a.c.x_coffset * sizeof(T);
+  const int row_bytes = a.c.x_cstride * (int)sizeof(T);
   const int nchunk = a.c.nchunk;
   for (int c0 = 0; c0 < nchunk; c0 += a.stage_chunks) {
     const int nload = nchunk - c0 < a.stage_chunks ? nchunk - c0 : a.stage_chunks;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256) void conv1x1_tile(G1Args a) {
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     const bool ok = cb + t * 4 < a.c.Cout;
-    bias[t] = ok ? *reinterpret_cast<const f32x4*>(a.c.bias + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bias[t] = ok && a.c.bias ? *reinterpret_cast<const f32x4*>(a.c.bias + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     nt_valid += ok ? 1 : 0;
   }
 #pragma unroll
@@ -168,6 +170,8 @@ void launch_g1(const G1Args& a, size_t lds, hipStream_t st) {
 template <typename T, int MBW, int WR>
 bool dispatch_ntw(const G1Args& a, int ntw, size_t lds, hipStream_t st) {
   switch (ntw) {
+    case 1: if constexpr (WR == 4) { launch_g1<T, MBW, 1, WR>(a, lds, st); return true; } return false;
+    case 2: if constexpr (WR == 4) { launch_g1<T, MBW, 2, WR>(a, lds, st); return true; } return false;
     case 3: launch_g1<T, MBW, 3, WR>(a, lds, st); return true;
     case 4: launch_g1<T, MBW, 4, WR>(a, lds, st); return true;
     case 5: if constexpr (MBW <= 4) { launch_g1<T, MBW, 5, WR>(a, lds, st); return true; } return false;
@@ -189,10 +193,10 @@ bool dispatch_g1(const G1Args& a, int mbw, int wr, int ntw, size_t lds, hipStrea
 int conv1x1_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStream_t st, bool* handled) {
   *handled = false;
   if (conv_algo() != 0) return SQDET_OK;
-  if (c.k != 1 || c.stride != 1 || g.gather || !c.bias) return SQDET_OK;
-  if (c.x_cstride != c.Cin || c.x_coffset != 0) return SQDET_OK;
+  if (c.k != 1 || c.stride != 1 || g.gather) return SQDET_OK;
   const int esz = dtype == SQDET_F16 ? 2 : 4;
-  if ((c.Cin * esz) % 16 != 0 || g.nt < 3) return SQDET_OK;   // (1- and 2-tile groups, Cout <= 32: generic kernel)
+  if ((c.Cin * esz) % 16 != 0 || (c.x_cstride * esz) % 16 != 0 || (c.x_coffset * esz) % 16 != 0) return SQDET_OK;
+  if (g.nt < 3 && g.ngroups != 1) return SQDET_OK;          // 1- and 2-tile groups: only the one-slice layout (Cout <= 32)
   G1Args a;
   a.c = c;
   a.nt_pack = g.nt;
