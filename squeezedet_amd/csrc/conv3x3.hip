@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
   const i32x4* wbase = reinterpret_cast<const i32x4*>(a.c.wp) + ((size_t)group * a.c.steps * a.nt_pack + n0) * 64 + lane;
   const int nstages = SPLITK ? (a.nchunk + 3) / 4 : (a.nchunk + a.stage_chunks - 1) / a.stage_chunks;
 
+  i32x4 wq[3][NTW];   // cout-split mode: weight fragments of three consecutive steps
   if constexpr (SPLITK) {
     // Wave w walks chunk 4*stage + w of every stage, 9 taps each: one 5-KiB weight step per 40 MFMAs (~0.27 us of
     // the matrix pipe), and every weight byte is used once per workgroup, so each step's fragments come from L2
@@ -226,50 +227,64 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
     __syncthreads();
     if (!active) continue;
 
-    // chunks this wave walks in this stage
-    const int cl_begin = SPLITK ? wave : 0;
-    const int cl_end = SPLITK ? (wave < nload ? wave + 1 : wave) : nload;
-    // Flattened (chunk, tap) steps with the NEXT step's weight fragments prefetched from global
-    // while the current step's MFMAs run (register double buffer): the L1/L2 latency of the A
-    // operand is off the critical path.
-    const int nsteps = (cl_end - cl_begin) * 9;
-    auto wptr = [&](int s) {
-      const int cl = cl_begin + s / 9, t9 = s - (s / 9) * 9;
-      return wbase + (size_t)(t9 * a.nchunk + c0 + cl) * a.nt_pack * 64;
+    // Flattened (chunk, tap) steps of this stage.  The weight fragments run TWO steps ahead over three statically named
+    // register sets (step s uses set s % 3; a stage is a multiple of 9 = 3 x 3 steps, so the names line up across stages
+    // and nothing is copied), and the look-ahead crosses the staging barriers: with a one-step look-ahead a workgroup that
+    // is alone on its CU (the 22x76 / 24x78 maps at batch 8: 240 workgroups) paid the L2 latency at every step.
+    const int nsteps = nload * 9;
+    const int gs0 = c0 * 9;                       // global step index of this stage's first step
+    const int gsl = a.nchunk * 9 - 1;             // last step of the conv (loads past it are clamped: harmless re-reads)
+    auto wptr = [&](int gs) {
+      const int gq = gs < gsl ? gs : gsl;
+      const int ch = gq / 9, t9 = gq - ch * 9;
+      return wbase + (size_t)(t9 * a.nchunk + ch) * a.nt_pack * 64;
     };
-    i32x4 af[NTW], afn[NTW];
-    if (nsteps > 0) {
-      const i32x4* wp = wptr(0);
+    if (stage == 0) {
 #pragma unroll
-      for (int t = 0; t < NTW; ++t) af[t] = wp[t * 64];
-    }
-#pragma unroll 1
-    for (int s = 0; s < nsteps; ++s) {
-      if (s + 1 < nsteps) {
-        const i32x4* wp = wptr(s + 1);
+      for (int pp = 0; pp < 2; ++pp) {
+        const i32x4* wp = wptr(pp);
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) afn[t] = wp[t * 64];
+        for (int t = 0; t < NTW; ++t) wq[pp][t] = wp[t * 64];
       }
-      const int cl = cl_begin + s / 9, t9 = s - (s / 9) * 9;
+    }
+    // B fragments one step ahead as well (three sets, same rotation): the LDS latency of step s+1 hides under step s's MFMAs
+    auto bread = [&](int ss, i32x4 (&bf)[MT]) {
+      const int cl = ss / 9, t9 = ss - cl * 9;
       const int dy = t9 / 3, dx = t9 - dy * 3;
       // (16-byte pieces beyond Cin were zero-filled by stage_tile, so every read is unconditional)
       const unsigned char* lchunk = lds + cl * CHUNK_BYTES;
       const int P0 = (dy + m0) * (TCOLS + 2) + j + dx;   // halo pixel of this wave's first row at this tap
       const int h0 = P0 >> 1;
-      i32x4 bf[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         // pixel P = P0 + 18*m ; (P>>1)&3 == (h0 + 9m)&3 == (h0 + m)&3
         const int slot = g ^ ((h0 + m) & 3);
         bf[m] = *reinterpret_cast<const i32x4*>(lchunk + (P0 + (TCOLS + 2) * m) * 64 + (slot << 4));
       }
+    };
+    // (whole-tile waves, MT = 8: 96 more registers would cost the third resident workgroup -- measured slower -- so those
+    // read their fragments in the step itself)
+    constexpr bool BAHEAD = MT <= 4;
+    i32x4 bq[BAHEAD ? 3 : 1][MT];
+    if constexpr (BAHEAD) bread(0, bq[0]);
+#pragma unroll 1
+    for (int s = 0; s < nsteps; s += 3) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int u = 0; u < 3; ++u) {
+        {
+          const i32x4* wp = wptr(gs0 + s + u + 2);
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], af[t], bf[m]);
-      if (s + 1 < nsteps) {
+          for (int t = 0; t < NTW; ++t) wq[(u + 2) % 3][t] = wp[t * 64];
+        }
+        if constexpr (BAHEAD) {
+          if (s + u + 1 < nsteps) bread(s + u + 1, bq[(u + 1) % 3]);
+        } else {
+          bread(s + u, bq[0]);
+        }
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) af[t] = afn[t];
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], wq[u][t], bq[BAHEAD ? u : 0][m]);
       }
     }
   }
