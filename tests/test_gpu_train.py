@@ -411,6 +411,29 @@ def test_build_labels_vs_oracle(cfg):
     np.testing.assert_allclose(delta.cpu().numpy(), r_delta, rtol=1e-6, atol=1e-7)
 
 
+def test_build_labels_crowded_images_vs_oracle():
+    """Many boxes crowding the same anchors: the per-box candidates of the parallel first pass collide again and again and
+    the in-order resolution (labels_resolve_kernel) falls back to the sweep over the free anchors -- same picks as the
+    sequential reference loop (imdb.py:195-239)."""
+    ops = _ops()
+    mc = O.kitti_squeezeDet_config()
+    rs = np.random.RandomState(5)
+    B, M = 4, 32
+    gt = np.zeros((B, M, 4), np.float64)
+    cnt = np.array([32, 32, 17, 32], np.int32)
+    for b in range(B):
+        c = np.array([rs.uniform(200, 1000), rs.uniform(100, 280), rs.uniform(40, 200), rs.uniform(40, 150)])
+        gt[b] = c + rs.uniform(-3.0, 3.0, (M, 4)) * (1.0 if b else 0.0)      # image 0: 32 IDENTICAL boxes
+    gt[3, :, 0] -= 5000.0                                                      # image 3: all far outside (distance fallback, crowded)
+    cls = rs.randint(0, mc.CLASSES, size=(B, M)).astype(np.int32)
+    mask, delta, box, lab, aidx = ops.build_labels(mc.ANCHOR_BOX, gt, cls, cnt, mc.CLASSES, device=DEV)
+    torch.cuda.synchronize()
+    for b in range(B):
+        aidxs, _ = TO.assign_anchors(mc, gt[b, :cnt[b]])
+        assert aidx[b, :cnt[b]].cpu().tolist() == aidxs, "image %d" % b
+        assert int(mask[b].sum().item()) == cnt[b]
+
+
 def test_training_step_from_gpu_built_labels():
     """The trainer accepts the device tensors of build_labels directly (no host round trip of the labels)."""
     ops = _ops()
