@@ -245,6 +245,13 @@ int sqdet_conv_pack_weights_bwd_data(const float* w_hwio_f32, void* packed, int 
 int sqdet_conv2d_nhwc_bwd_data(const void* dy, const void* w_packed_bwd, void* dx, int n, int h, int w, int cin,
                                int cout, int k, int dtype, int dy_cstride, int dy_coffset, int accumulate,
                                sqdet_stream_t stream);
+/* The same with the ReLU backward of the layer below in the epilogue: dx is the gradient w.r.t. the ReLU output
+ * relu_of [n,h,w,cin] (the conv's input in the forward pass) and is zeroed where relu_of <= 0 -- after the
+ * accumulation when accumulate != 0 (tf.nn.relu's gradient, nn_skeleton.py:547 through tf.gradients) -- instead of a
+ * separate sqdet_relu_bwd pass over the tensor. */
+int sqdet_conv2d_nhwc_bwd_data_relu(const void* dy, const void* w_packed_bwd, void* dx, const void* relu_of, int n, int h,
+                                    int w, int cin, int cout, int k, int dtype, int dy_cstride, int dy_coffset,
+                                    int accumulate, sqdet_stream_t stream);
 
 /* Backward-filter (+ bias): dW[kh,kw,ci,co] = grad_scale * sum_pixels x@tap[ci]*dy[co] (+ weight_decay*W
  * when w_hwio_for_decay != NULL: the gradient of wd*l2_loss(W), nn_skeleton.py:66-69), dbias[co] =
@@ -271,6 +278,10 @@ int sqdet_convert_scale(const void* src, int src_dtype, void* dst, int dst_dtype
 /* tf.nn.max_pool gradient: dx[cell] = sum of dy over the windows whose first maximum the cell is. */
 int sqdet_maxpool_nhwc_bwd(const void* x, const void* dy, void* dx, int n, int h, int w, int c, int k, int stride,
                            int pad_mode, int dtype, sqdet_stream_t stream);
+/* The same for a pool whose input x is a ReLU output (every pool of the reference's nets): dx is also zeroed where
+ * x <= 0, i.e. the ReLU backward of the layer below is taken here instead of in a pass of its own. */
+int sqdet_maxpool_nhwc_bwd_relu(const void* x, const void* dy, void* dx, int n, int h, int w, int c, int k, int stride,
+                                int pad_mode, int dtype, sqdet_stream_t stream);
 
 /* Loss forward + backward.  Inputs as the reference's placeholders (nn_skeleton.py:86-97):
  * input_mask [B,A], box_delta_input [B,A,4], box_input [B,A,4] (cx,cy,w,h), labels [B,A,C];

@@ -46,12 +46,14 @@ SIGNATURES = {
     "sqdet_detect_filter": (ci, [vp] * 8 + [ci] * 5 + [cf, cf, cf, ci, ci, cd, ci, vp]),
     "sqdet_conv_pack_weights_bwd_data": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "sqdet_conv2d_nhwc_bwd_data": (ci, [vp, vp, vp] + [ci] * 10 + [vp]),
+    "sqdet_conv2d_nhwc_bwd_data_relu": (ci, [vp, vp, vp, vp] + [ci] * 10 + [vp]),
     "sqdet_conv2d_bwd_filter_workspace_bytes": (sz, [ci] * 6),
     "sqdet_conv2d_nhwc_bwd_filter": (ci, [vp, vp, vp, vp, vp, cf, cf, vp] + [ci] * 11 + [vp]),
     "sqdet_relu_bwd": (ci, [vp, vp, sz, ci, vp]),
     "sqdet_convert_scale": (ci, [vp, ci, vp, ci, cf, sz, vp]),
     "sqdet_scale_mask": (ci, [vp, vp, vp, cf, sz, ci, vp]),
     "sqdet_maxpool_nhwc_bwd": (ci, [vp, vp, vp] + [ci] * 8 + [vp]),
+    "sqdet_maxpool_nhwc_bwd_relu": (ci, [vp, vp, vp] + [ci] * 8 + [vp]),
     "sqdet_loss_workspace_bytes": (sz, []),
     "sqdet_loss_fwd_bwd": (ci, [vp] * 10 + [ci] * 5 + [cf] * 9 + [vp]),
     "sqdet_loss_fwd_bwd_dev": (ci, [vp] * 10 + [ci] * 5 + [cf] * 8 + [vp, vp]),

@@ -45,6 +45,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
           if (a.relu) {
             v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
           }
+          if (a.relu_of) {
+            const T* r = reinterpret_cast<const T*>(a.relu_of) + (size_t)pix[m] * a.y_cstride + a.y_coffset + c;
+            v[0] = (float)r[0] > 0.f ? v[0] : 0.f; v[1] = (float)r[1] > 0.f ? v[1] : 0.f;
+            v[2] = (float)r[2] > 0.f ? v[2] : 0.f; v[3] = (float)r[3] > 0.f ? v[3] : 0.f;
+          }
           store4<T>(dst, v);
         }
       }
@@ -279,6 +284,9 @@ static int dispatch_mt(ConvArgs& a, int nt, bool gather, hipStream_t st) {
 int conv2d_launch_ex(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
                      int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
                      int x_cstride, int x_coffset, int accum, hipStream_t st);
+int conv2d_launch_masked(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
+                         int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
+                         int x_cstride, int x_coffset, int accum, const void* relu_of, hipStream_t st);
 
 int conv2d_launch(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
                   int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
@@ -293,6 +301,14 @@ int conv2d_launch(const void* x, const void* w_packed, const float* bias, void* 
 int conv2d_launch_ex(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
                      int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
                      int x_cstride, int x_coffset, int accum, hipStream_t st) {
+  return conv2d_launch_masked(x, w_packed, bias, y, n, h, w, cin, cout, k, stride, pad_mode, relu, dtype, y_cstride, y_coffset,
+                              x_cstride, x_coffset, accum, nullptr, st);
+}
+
+// relu_of != NULL: y (after the optional accumulate) is zeroed where relu_of <= 0 (same layout as y): see ConvArgs
+int conv2d_launch_masked(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
+                         int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
+                         int x_cstride, int x_coffset, int accum, const void* relu_of, hipStream_t st) {
   SQDET_REQUIRE(x && w_packed && y, "conv2d: null pointer");  // bias == NULL means no bias (generic kernel)
   const int kg_ = dtype == SQDET_F16 ? 8 : 4;
   SQDET_UNSUPPORTED((x_cstride != cin || x_coffset != 0) &&
@@ -322,7 +338,8 @@ int conv2d_launch_ex(const void* x, const void* w_packed, const float* bias, voi
   a.nchunk = g.nchunk; a.steps = g.steps; a.ngroups = g.ngroups;
   a.y_cstride = y_cstride; a.y_coffset = y_coffset; a.relu = relu;
   a.x_cstride = x_cstride; a.x_coffset = x_coffset; a.accum = accum;
-  const bool plain = x_cstride == cin && x_coffset == 0 && !accum && bias != nullptr;
+  a.relu_of = relu_of;
+  const bool plain = x_cstride == cin && x_coffset == 0 && !accum && bias != nullptr && !relu_of;
   SQDET_UNSUPPORTED(!plain && g.gather, "conv2d: channel-sliced / accumulating convs need Cin %% %d == 0", kg_);
   bool handled = false;
   int rc = SQDET_OK;

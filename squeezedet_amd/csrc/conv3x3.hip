@@ -381,6 +381,11 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
           v[t][0] = fmaxf(v[t][0], 0.f); v[t][1] = fmaxf(v[t][1], 0.f);
           v[t][2] = fmaxf(v[t][2], 0.f); v[t][3] = fmaxf(v[t][3], 0.f);
         }
+        if (a.c.relu_of && t < nt_valid) {   // ReLU backward of the layer below (see ConvArgs)
+          const T* r = reinterpret_cast<const T*>(a.c.relu_of) + (dst - y) + t * 4;
+          v[t][0] = (float)r[0] > 0.f ? v[t][0] : 0.f; v[t][1] = (float)r[1] > 0.f ? v[t][1] : 0.f;
+          v[t][2] = (float)r[2] > 0.f ? v[t][2] : 0.f; v[t][3] = (float)r[3] > 0.f ? v[t][3] : 0.f;
+        }
       }
       store_couts<T, NTW>(dst, v, nt_valid);
     }
@@ -437,7 +442,7 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
   if (c.Ho != c.H || c.Wo != c.W) return SQDET_OK;
   const int esz = dtype == SQDET_F16 ? 2 : 4;
   if ((c.Cin * esz) % 16 != 0 || (c.x_cstride * esz) % 16 != 0 || (c.x_coffset * esz) % 16 != 0) return SQDET_OK;
-  const bool plain = c.x_cstride == c.Cin && c.x_coffset == 0 && !c.accum && c.bias;
+  const bool plain = c.x_cstride == c.Cin && c.x_coffset == 0 && !c.accum && c.bias && !c.relu_of;
   TileArgs a;
   a.c = c;
   a.tiles_x = (c.W + TCOLS - 1) / TCOLS;

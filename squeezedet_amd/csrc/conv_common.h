@@ -37,6 +37,9 @@ struct ConvArgs {
   // x_cstride channels wide, and the result may be ADDED to y (backward-data of a fire module:
   // d(squeeze) = dgrad_1x1(dY[:, :e1]) + dgrad_3x3(dY[:, e1:])).
   int x_cstride, x_coffset, accum;
+  // backward-data only: the result is the gradient w.r.t. a ReLU OUTPUT r (same layout as y); it is zeroed where r <= 0 --
+  // the ReLU backward of the layer below, taken in this conv's epilogue instead of a separate pass over the tensor
+  const void* relu_of;
 };
 
 template <typename T>

@@ -155,6 +155,11 @@ __global__ __launch_bounds__(256) void conv1x1_tile(G1Args a) {
         v[t][0] = fmaxf(v[t][0], 0.f); v[t][1] = fmaxf(v[t][1], 0.f);
         v[t][2] = fmaxf(v[t][2], 0.f); v[t][3] = fmaxf(v[t][3], 0.f);
       }
+      if (a.c.relu_of && t < nt_valid) {   // ReLU backward of the layer below (see ConvArgs)
+        const T* r = reinterpret_cast<const T*>(a.c.relu_of) + (dst - y) + t * 4;
+        v[t][0] = (float)r[0] > 0.f ? v[t][0] : 0.f; v[t][1] = (float)r[1] > 0.f ? v[t][1] : 0.f;
+        v[t][2] = (float)r[2] > 0.f ? v[t][2] : 0.f; v[t][3] = (float)r[3] > 0.f ? v[t][3] : 0.f;
+      }
     }
     store_couts<T, NTW>(dst, v, nt_valid);
   }

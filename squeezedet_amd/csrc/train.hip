@@ -19,6 +19,9 @@ namespace sqdet {
 int conv2d_launch_ex(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
                      int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
                      int x_cstride, int x_coffset, int accum, hipStream_t st);
+int conv2d_launch_masked(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
+                         int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
+                         int x_cstride, int x_coffset, int accum, const void* relu_of, hipStream_t st);
 
 // ------------------------------------------------------------------ backward-data weight packing
 // dgrad(dy)[ci] = sum_{tap,co} W[k-1-ty][k-1-tx][ci][co] * dy@tap[co]: a forward conv with
@@ -112,7 +115,7 @@ __global__ void convert_scale_kernel(const S* __restrict__ src, D* __restrict__ 
 // summation order of the generic kernel below, so the two agree bitwise.
 template <typename T>
 __global__ void maxpool3s2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
-                                      int N, int H, int W, int C, int pt, int pl, int Ho, int Wo, int BA, int BB) {
+                                      int N, int H, int W, int C, int pt, int pl, int Ho, int Wo, int BA, int BB, int relu) {
   typedef typename Vec16<T>::type V;
   constexpr int EV = 16 / sizeof(T);
   const int cvn = C / EV;
@@ -174,6 +177,11 @@ __global__ void maxpool3s2_bwd_kernel(const T* __restrict__ x, const T* __restri
         V o;
 #pragma unroll
         for (int e = 0; e < EV; ++e) o[e] = (T)g[du * 2 + dv][e];
+        if (relu) {   // x is a ReLU output: the ReLU backward of the layer below, here instead of a pass of its own
+          const V xv = *reinterpret_cast<const V*>(x + ((((size_t)n * H + iy) * W + ix) * C + cv * EV));
+#pragma unroll
+          for (int e = 0; e < EV; ++e) o[e] = xv[e] > (T)0 ? o[e] : (T)0;
+        }
         *reinterpret_cast<V*>(dx + ((((size_t)n * H + iy) * W + ix) * C + cv * EV)) = o;
       }
   }
@@ -183,7 +191,7 @@ __global__ void maxpool3s2_bwd_kernel(const T* __restrict__ x, const T* __restri
 // FIRST maximum (row-major scan, as tf.nn.max_pool's argmax) it is.
 template <typename T>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
-                                   int N, int H, int W, int C, int k, int stride, int pt, int pl, int Ho, int Wo) {
+                                   int N, int H, int W, int C, int k, int stride, int pt, int pl, int Ho, int Wo, int relu) {
   typedef typename Vec16<T>::type V;
   constexpr int EV = 16 / sizeof(T);
   const int cvn = C / EV;
@@ -229,6 +237,11 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict_
     V o;
 #pragma unroll
     for (int e = 0; e < EV; ++e) o[e] = (T)g[e];
+    if (relu) {
+      const V xv = *reinterpret_cast<const V*>(x + idx * EV);
+#pragma unroll
+      for (int e = 0; e < EV; ++e) o[e] = xv[e] > (T)0 ? o[e] : (T)0;
+    }
     *reinterpret_cast<V*>(dx + idx * EV) = o;
   }
 }
@@ -502,6 +515,14 @@ extern "C" int sqdet_conv2d_nhwc_bwd_data(const void* dy, const void* w_packed_b
                           dy_cstride, dy_coffset, accumulate, as_stream(stream));
 }
 
+extern "C" int sqdet_conv2d_nhwc_bwd_data_relu(const void* dy, const void* w_packed_bwd, void* dx, const void* relu_of, int n, int h,
+                                               int w, int cin, int cout, int k, int dtype, int dy_cstride, int dy_coffset,
+                                               int accumulate, sqdet_stream_t stream) {
+  SQDET_REQUIRE(k == 1 || k == 3, "conv2d_bwd_data: k must be 1 or 3 (stride 1, SAME)");
+  return conv2d_launch_masked(dy, w_packed_bwd, nullptr, dx, n, h, w, cout, cin, k, 1, SQDET_PAD_SAME, 0, dtype, cin, 0,
+                              dy_cstride, dy_coffset, accumulate, relu_of, as_stream(stream));
+}
+
 extern "C" int sqdet_relu_bwd(const void* y, void* dy_inout, size_t count, int dtype, sqdet_stream_t stream) {
   SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "relu_bwd: bad dtype");
   const size_t ev = 16 / dtype_size(dtype);
@@ -548,8 +569,21 @@ extern "C" int sqdet_convert_scale(const void* src, int src_dtype, void* dst, in
   return SQDET_OK;
 }
 
+static int maxpool_bwd_launch(const void* x, const void* dy, void* dx, int n, int h, int w, int c, int k, int stride,
+                              int pad_mode, int dtype, int relu, sqdet_stream_t stream);
+
 extern "C" int sqdet_maxpool_nhwc_bwd(const void* x, const void* dy, void* dx, int n, int h, int w, int c, int k,
                                       int stride, int pad_mode, int dtype, sqdet_stream_t stream) {
+  return maxpool_bwd_launch(x, dy, dx, n, h, w, c, k, stride, pad_mode, dtype, 0, stream);
+}
+
+extern "C" int sqdet_maxpool_nhwc_bwd_relu(const void* x, const void* dy, void* dx, int n, int h, int w, int c, int k,
+                                           int stride, int pad_mode, int dtype, sqdet_stream_t stream) {
+  return maxpool_bwd_launch(x, dy, dx, n, h, w, c, k, stride, pad_mode, dtype, 1, stream);
+}
+
+static int maxpool_bwd_launch(const void* x, const void* dy, void* dx, int n, int h, int w, int c, int k, int stride,
+                              int pad_mode, int dtype, int relu, sqdet_stream_t stream) {
   SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "maxpool_bwd: bad dtype");
   const int ev = 16 / (int)dtype_size(dtype);
   SQDET_REQUIRE(x && dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && c % ev == 0 && k > 0 && stride > 0,
@@ -561,10 +595,10 @@ extern "C" int sqdet_maxpool_nhwc_bwd(const void* x, const void* dy, void* dx, i
     const dim3 grid2(grid_for((size_t)n * BA * BB * (c / ev), 16384));
     if (dtype == SQDET_F16)
       hipLaunchKernelGGL(maxpool3s2_bwd_kernel<f16>, grid2, dim3(256), 0, as_stream(stream), (const f16*)x, (const f16*)dy,
-                         (f16*)dx, n, h, w, c, pt, pl, Ho, Wo, BA, BB);
+                         (f16*)dx, n, h, w, c, pt, pl, Ho, Wo, BA, BB, relu);
     else
       hipLaunchKernelGGL(maxpool3s2_bwd_kernel<float>, grid2, dim3(256), 0, as_stream(stream), (const float*)x,
-                         (const float*)dy, (float*)dx, n, h, w, c, pt, pl, Ho, Wo, BA, BB);
+                         (const float*)dy, (float*)dx, n, h, w, c, pt, pl, Ho, Wo, BA, BB, relu);
     SQDET_CHECK_HIP(hipGetLastError());
     return SQDET_OK;
   }
@@ -572,10 +606,10 @@ extern "C" int sqdet_maxpool_nhwc_bwd(const void* x, const void* dy, void* dx, i
   const dim3 grid(grid_for(total, 16384));
   if (dtype == SQDET_F16)
     hipLaunchKernelGGL(maxpool_bwd_kernel<f16>, grid, dim3(256), 0, as_stream(stream), (const f16*)x, (const f16*)dy, (f16*)dx,
-                       n, h, w, c, k, stride, pt, pl, Ho, Wo);
+                       n, h, w, c, k, stride, pt, pl, Ho, Wo, relu);
   else
     hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy,
-                       (float*)dx, n, h, w, c, k, stride, pt, pl, Ho, Wo);
+                       (float*)dx, n, h, w, c, k, stride, pt, pl, Ho, Wo, relu);
   SQDET_CHECK_HIP(hipGetLastError());
   return SQDET_OK;
 }

@@ -340,12 +340,21 @@ class PackedConvBwd:
                                                      self.cout, code, stream_ptr()), "sqdet_conv_pack_weights_bwd_data")
 
 
-def conv2d_bwd_data(dy, packed_bwd, dx=None, dy_coffset=0, accumulate=False):
-    """dx = conv(dy[..., dy_coffset:dy_coffset+cout], rot180(W)^T) (stride-1 SAME convs).  dy [N,H,W,Ctot]."""
+def conv2d_bwd_data(dy, packed_bwd, dx=None, dy_coffset=0, accumulate=False, relu_of=None):
+    """dx = conv(dy[..., dy_coffset:dy_coffset+cout], rot180(W)^T) (stride-1 SAME convs).  dy [N,H,W,Ctot].
+    relu_of [N,H,W,cin]: the ReLU output dx is the gradient of -- dx (after the accumulation) is zeroed where it is <= 0
+    (sqdet_conv2d_nhwc_bwd_data_relu: the ReLU backward of the layer below without a pass of its own)."""
     n, h, w, ctot = [int(v) for v in dy.shape]
     if dx is None:
         dx = torch.empty((n, h, w, packed_bwd.cin), dtype=dy.dtype, device=dy.device)
         accumulate = False
+    if relu_of is not None:
+        if tuple(relu_of.shape) != tuple(dx.shape) or relu_of.dtype != dx.dtype or not relu_of.is_contiguous():
+            raise _lib.SqdetError("conv2d_bwd_data: relu_of must be a contiguous tensor shaped like dx")
+        check(lib().sqdet_conv2d_nhwc_bwd_data_relu(_dev(dy, "dy"), _dev(packed_bwd.data, "packed"), _dev(dx, "dx"), _dev(relu_of, "relu_of"),
+                                                    n, h, w, packed_bwd.cin, packed_bwd.cout, packed_bwd.k, dtype_code(dy.dtype), ctot,
+                                                    int(dy_coffset), int(bool(accumulate)), stream_ptr()), "sqdet_conv2d_nhwc_bwd_data_relu")
+        return dx
     check(lib().sqdet_conv2d_nhwc_bwd_data(_dev(dy, "dy"), _dev(packed_bwd.data, "packed"), _dev(dx, "dx"), n, h, w,
                                            packed_bwd.cin, packed_bwd.cout, packed_bwd.k, dtype_code(dy.dtype), ctot,
                                            int(dy_coffset), int(bool(accumulate)), stream_ptr()), "sqdet_conv2d_nhwc_bwd_data")
@@ -425,11 +434,14 @@ def convert_scale(x, dtype, scale=1.0):
     return y
 
 
-def maxpool_bwd(x, dy, size, stride, padding="SAME"):
+def maxpool_bwd(x, dy, size, stride, padding="SAME", relu=False):
+    """tf.nn.max_pool's gradient; relu=True: x is a ReLU output and dx is also zeroed where x <= 0 (the ReLU backward of
+    the layer below, sqdet_maxpool_nhwc_bwd_relu)."""
     n, h, w, c = [int(v) for v in x.shape]
     dx = torch.empty_like(x)
-    check(lib().sqdet_maxpool_nhwc_bwd(_dev(x, "x"), _dev(dy, "dy", x.dtype), _dev(dx, "dx"), n, h, w, c, int(size), int(stride),
-                                       pad_code(padding), dtype_code(x.dtype), stream_ptr()), "sqdet_maxpool_nhwc_bwd")
+    fn = lib().sqdet_maxpool_nhwc_bwd_relu if relu else lib().sqdet_maxpool_nhwc_bwd
+    check(fn(_dev(x, "x"), _dev(dy, "dy", x.dtype), _dev(dx, "dx"), n, h, w, c, int(size), int(stride),
+             pad_code(padding), dtype_code(x.dtype), stream_ptr()), "sqdet_maxpool_nhwc_bwd")
     return dx
 
 

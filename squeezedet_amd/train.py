@@ -314,36 +314,57 @@ class SqueezeDetTrainer(_TrainerBase):
                 return m.trainable[rec[1].name + "/kernels"]
             return rec[0] == "fire"
         first_tr = min(i for i, r in enumerate(saved) if has_trainable(r))
+        # ReLU backward: every gradient w.r.t. a ReLU output is masked in the epilogue of the kernel that PRODUCES it (the
+        # backward-data conv or the max-pool backward above it) -- `masked` says g already carries the mask of the layer
+        # whose output it is the gradient of; the loss gradient of conv12 (no ReLU) and any other case fall back to relu_bwd
+        masked = False
+
+        def relu_src(rj):
+            """The ReLU output the record below ri produces (= the tensor dx is the gradient of), or None."""
+            r = saved[rj]
+            if r[0] == "fire":
+                return r[4]
+            if r[0] == "conv" and r[1].attrs["relu"] and r[3] is not None:
+                return r[3]
+            return None
         for ri in range(len(saved) - 1, first_tr - 1, -1):
             rec = saved[ri]
             need_dx = ri > first_tr     # nothing trainable (and no image gradient) below the first trainable layer
+            below = relu_src(ri - 1) if ri > 0 else None          # x of this layer, when it is a ReLU output
             if rec[0] == "conv":
                 _, node, xin, y = rec
                 name = node.name
-                if node.attrs["relu"]:
+                if node.attrs["relu"] and not masked:
                     ops.relu_bwd(y, g)
                 k = node.attrs["size"]
                 cin, cout = int(xin.shape[3]), int(y.shape[3])
                 ops.conv2d_bwd_filter(xin, g, k, cin, cout, dw=self.gview[name + "/kernels"], db=self.gview[name + "/biases"], grad_scale=gs)
+                masked = False
                 if need_dx:
-                    g = ops.conv2d_bwd_data(g, bwd(name))
                     if name == "conv12" and keep != 1.0:
+                        g = ops.conv2d_bwd_data(g, bwd(name))
                         g = ops.scale_mask(g, dm, 1.0 / keep)
+                    else:
+                        g = ops.conv2d_bwd_data(g, bwd(name), relu_of=below)
+                        masked = below is not None
             elif rec[0] == "pool":
                 _, node, xin, y = rec
-                g = ops.maxpool_bwd(xin, g, node.attrs["size"], node.attrs["stride"], node.attrs["padding"])
+                g = ops.maxpool_bwd(xin, g, node.attrs["size"], node.attrs["stride"], node.attrs["padding"], relu=below is not None)
+                masked = below is not None
             else:
                 _, (sq, e1, e3), xin, s, y = rec
                 ne1, ne3, ns = e1.shape[3], e3.shape[3], sq.shape[3]
-                ops.relu_bwd(y, g)      # both expand convs end in ReLU
+                if not masked:
+                    ops.relu_bwd(y, g)      # both expand convs end in ReLU
                 ops.conv2d_bwd_filter(s, g, 1, ns, ne1, dy_coffset=0, dw=self.gview[e1.name + "/kernels"], db=self.gview[e1.name + "/biases"], grad_scale=gs)
                 ops.conv2d_bwd_filter(s, g, 3, ns, ne3, dy_coffset=ne1, dw=self.gview[e3.name + "/kernels"], db=self.gview[e3.name + "/biases"], grad_scale=gs)
                 ds = ops.conv2d_bwd_data(g, bwd(e1.name), dy_coffset=0)
-                ops.conv2d_bwd_data(g, bwd(e3.name), dx=ds, dy_coffset=ne1, accumulate=True)
-                ops.relu_bwd(s, ds)
+                ops.conv2d_bwd_data(g, bwd(e3.name), dx=ds, dy_coffset=ne1, accumulate=True, relu_of=s)   # + the squeeze's ReLU backward
                 ops.conv2d_bwd_filter(xin, ds, 1, int(xin.shape[3]), ns, dw=self.gview[sq.name + "/kernels"], db=self.gview[sq.name + "/biases"], grad_scale=gs)
+                masked = False
                 if need_dx:
-                    g = ops.conv2d_bwd_data(ds, bwd(sq.name))
+                    g = ops.conv2d_bwd_data(ds, bwd(sq.name), relu_of=below)
+                    masked = below is not None
         out = collections.OrderedDict(class_loss=losses[0], conf_loss=losses[1], bbox_loss=losses[2], ious=ious, preds=preds,
                                       dpreds=dpreds, num_objects=num_objects)
         if keep_activations:

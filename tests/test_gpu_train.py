@@ -125,6 +125,39 @@ def test_relu_dropout_maxpool_backward():
         np.testing.assert_allclose(dx.cpu().numpy(), x.grad.numpy(), rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+def test_relu_backward_fused_into_the_producing_kernel(dtype):
+    """sqdet_conv2d_nhwc_bwd_data_relu / sqdet_maxpool_nhwc_bwd_relu: the ReLU backward of the layer below taken in the
+    epilogue of the kernel that produces the gradient (incl. after an accumulation) == the separate relu_bwd pass, bitwise;
+    every kernel family that serves a backward-data conv (generic, 1x1 tile, 3x3 tile; sliced dY, accumulate)."""
+    ops = _ops()
+    rs = np.random.RandomState(12)
+    for (N, H, W, cin, cout, k) in ((2, 13, 21, 32, 128, 1), (1, 24, 78, 96, 384, 3), (2, 9, 11, 16, 64, 3), (1, 17, 19, 48, 200, 1)):
+        dY = torch.from_numpy(rs.randn(N, H, W, 2 * cout).astype(np.float32)).to(DEV, dtype)
+        r = torch.from_numpy(np.maximum(rs.randn(N, H, W, cin), 0).astype(np.float32)).to(DEV, dtype)   # ~half zeros
+        pw = ops.PackedConvBwd(torch.from_numpy((rs.randn(k, k, cin, cout) * 0.1).astype(np.float32)).to(DEV), dtype)
+        p1 = ops.PackedConvBwd(torch.from_numpy((rs.randn(1, 1, cin, cout) * 0.1).astype(np.float32)).to(DEV), dtype)
+        # plain
+        a = ops.relu_bwd(r, ops.conv2d_bwd_data(dY, pw, dy_coffset=cout))
+        b = ops.conv2d_bwd_data(dY, pw, dy_coffset=cout, relu_of=r)
+        assert torch.equal(a, b), (cin, cout, k)
+        # accumulate: mask applies to the SUM
+        a = ops.conv2d_bwd_data(dY, p1, dy_coffset=0)
+        ops.conv2d_bwd_data(dY, pw, dx=a, dy_coffset=cout, accumulate=True)
+        a = ops.relu_bwd(r, a)
+        b = ops.conv2d_bwd_data(dY, p1, dy_coffset=0)
+        ops.conv2d_bwd_data(dY, pw, dx=b, dy_coffset=cout, accumulate=True, relu_of=r)
+        assert torch.equal(a, b), (cin, cout, k, "accumulate")
+    for (H, W, size, stride, pad) in ((47, 156, 3, 2, "SAME"), (20, 31, 3, 2, "VALID"), (13, 17, 3, 1, "SAME")):
+        x = torch.from_numpy(np.maximum(rs.randn(2, H, W, 16), 0).astype(np.float32)).to(DEV, dtype)
+        yp = ops.maxpool_nhwc(x, size, stride, pad)
+        g = torch.from_numpy(rs.randn(*yp.shape).astype(np.float32)).to(DEV, dtype)
+        a = ops.relu_bwd(x, ops.maxpool_bwd(x, g, size, stride, pad))
+        b = ops.maxpool_bwd(x, g, size, stride, pad, relu=True)
+        assert torch.equal(a, b), (H, W, size, stride, pad)
+    torch.cuda.synchronize()
+
+
 def test_float16_elementwise_backward_ops():
     """The activation-side backward kernels on float16 tensors (mixed-precision training): exact against the same
     arithmetic on the float16-rounded values."""
