@@ -119,6 +119,16 @@ int sqdet_maxpool_nhwc_fwd(const void* x, void* y, int n, int h, int w, int c, i
  * 96 filters, VALID/VALID).  x: [n,h,w,3]; y: [n,hp,wp,cout].  Only those two stems are fused. */
 int sqdet_stem_conv_pool_fwd(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w,
                              int cout, int k, int conv_pad_mode, int pool_pad_mode, int dtype, sqdet_stream_t stream);
+/* The same ending with the NEXT layer's squeeze1x1 (fire2/squeeze1x1 of SqueezeDet: 64 -> 16 couts, ReLU,
+ * nets/squeezeDet.py:46 via :95-97): pool1's tensor is never written, only the squeeze tensor sq_out [n, Hp, Wp, next_s]
+ * (120 MB -> 30 MB at batch 32).  float16, k = 3, cout = 64, even w; w_next_s_packed from sqdet_conv_pack_weights(1, cout,
+ * next_s).  Same values as the separate launches (the pooled pixels are rounded to float16 before the squeeze, the
+ * squeeze accumulates its two K-chunks in ascending order). */
+int sqdet_stem_conv_pool_squeeze_supported(int h, int w, int cout, int k, int conv_pad_mode, int pool_pad_mode, int next_s,
+                                           int dtype, int n);
+int sqdet_stem_conv_pool_squeeze_fwd(const void* x, const void* w_packed, const float* bias, const void* w_next_s_packed,
+                                     const float* b_next_s, void* sq_out, int n, int h, int w, int cout, int k,
+                                     int conv_pad_mode, int pool_pad_mode, int next_s, int dtype, sqdet_stream_t stream);
 
 /* ------------------------------------------------------------------ fire --
  * Replaces SqueezeDet._fire_layer (nets/squeezeDet.py:81-106):

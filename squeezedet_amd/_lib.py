@@ -31,6 +31,8 @@ SIGNATURES = {
     "sqdet_subsample_nhwc": (ci, [vp, vp] + [ci] * 6 + [vp]),
     "sqdet_maxpool_nhwc_fwd": (ci, [vp, vp] + [ci] * 8 + [vp]),
     "sqdet_stem_conv_pool_fwd": (ci, [vp, vp, vp, vp] + [ci] * 8 + [vp]),
+    "sqdet_stem_conv_pool_squeeze_supported": (ci, [ci] * 9),
+    "sqdet_stem_conv_pool_squeeze_fwd": (ci, [vp] * 6 + [ci] * 9 + [vp]),
     "sqdet_fire_fwd": (ci, [vp] * 9 + [ci] * 8 + [vp]),
     "sqdet_fire_maxpool_fwd": (ci, [vp] * 10 + [ci] * 8 + [vp]),
     "sqdet_fire_expand_fwd": (ci, [vp] * 6 + [ci] * 8 + [vp]),

@@ -724,10 +724,12 @@ static int launch_stream_sq(const FireSArgs& a, hipStream_t st) {
 }
 
 // the expand half of a module from its squeeze tensor (+ its pool) emitting the NEXT module's squeeze tensor -- SqueezeDet's
-// fire3+pool3 -> fire4's squeeze, fire4 -> fire5's, fire5+pool5 -> fire6's
+// fire2 -> fire3's squeeze (when the stem launch already produced fire2's squeeze tensor), fire3+pool3 -> fire4's squeeze,
+// fire4 -> fire5's, fire5+pool5 -> fire6's
 bool fire_expand_squeeze_next_eligible(int s, int e1, int e3, int s2, int pool, int dtype) {
   if (!fire_expand_stream_eligible(s, e1, e3, dtype)) return false;
-  return (s == 16 && e1 == 64 && s2 == 32 && pool) || (s == 32 && e1 == 128 && s2 == 32 && !pool) || (s == 32 && e1 == 128 && s2 == 48 && pool);
+  return (s == 16 && e1 == 64 && s2 == 32 && pool) || (s == 16 && e1 == 64 && s2 == 16 && !pool) ||
+         (s == 32 && e1 == 128 && s2 == 32 && !pool) || (s == 32 && e1 == 128 && s2 == 48 && pool);
 }
 
 int fire_expand_squeeze_next_launch(const void* sq_in, const void* w1, const float* b1, const void* w3, const float* b3,
@@ -751,7 +753,8 @@ int fire_expand_squeeze_next_launch(const void* sq_in, const void* w1, const flo
   if (xb >= (1L << 31)) return SQDET_OK;
   a.x_bytes = (unsigned)xb; a.y_bytes = 0;
   int rc;
-  if (s == 16) rc = launch_stream_sq<1, 1, 4, true, 2, true, true>(a, st);
+  if (s == 16 && !pool) rc = launch_stream_sq<1, 1, 4, true, 1, false, true>(a, st);   // fire2 (from the stem's squeeze tensor) -> fire3's squeeze
+  else if (s == 16) rc = launch_stream_sq<1, 1, 4, true, 2, true, true>(a, st);
   else if (!pool) rc = launch_stream_sq<1, 1, 8, false, 2, false, true>(a, st);
   else rc = launch_stream_sq<1, 1, 8, false, 3, true, true>(a, st);
   if (rc != SQDET_OK) return rc;

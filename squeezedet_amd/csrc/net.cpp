@@ -23,6 +23,10 @@ int maxpool_launch(const void* x, void* y, int n, int h, int w, int c, int k, in
                    hipStream_t st);
 int stem_launch(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cout, int k,
                 int conv_pad, int pool_pad, int dtype, int y_cstride, int y_coffset, hipStream_t st, bool* handled);
+int stem_squeeze_launch(const void* x, const void* w_packed, const float* bias, const void* ws2_packed, const float* bs2,
+                        void* s_out, int n, int h, int w, int cout, int k, int conv_pad, int pool_pad, int s2, int dtype,
+                        hipStream_t st, bool* handled);
+bool stem_squeeze_eligible(int h, int w, int cout, int k, int conv_pad, int pool_pad, int s2, int dtype, int n);
 int fire_fused_launch(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
                       const float* b3, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
                       hipStream_t st, bool* handled);
@@ -57,7 +61,8 @@ enum { BUF_INPUT = -1, BUF_PREDS = -2, BUF_A = 0, BUF_B = 1, BUF_S = 2, BUF_T = 
 // L_EXPAND: both expands of a fire module from its squeeze tensor (+ the max-pool behind it): sqdet_fire_expand_fwd
 // L_FIRESQ: a whole fire module from x whose output is the NEXT module's squeeze tensor (sqdet_fire_squeeze_next_fwd)
 // L_EXPSQ: both expands (+ pool) of a module from its squeeze tensor, output = the NEXT module's squeeze tensor
-enum { L_CONV = 0, L_POOL = 1, L_STEM = 2, L_FIRE = 3, L_CHAIN = 4, L_EXPAND = 5, L_FIRESQ = 6, L_EXPSQ = 7 };
+// L_STEMSQ: conv1 + pool1 + the first module's squeeze1x1 in the persistent stem launch (sqdet_stem_conv_pool_squeeze_fwd)
+enum { L_CONV = 0, L_POOL = 1, L_STEM = 2, L_FIRE = 3, L_CHAIN = 4, L_EXPAND = 5, L_FIRESQ = 6, L_EXPSQ = 7, L_STEMSQ = 8 };
 
 struct Param {
   std::string name;
@@ -326,6 +331,20 @@ int run_layer_part(sqdet_net* net, const Layer& L, const void* input, void* pred
     return sqdet_fire_expand_fwd(sq_in, pk(L.kp_1), pb(L.bp_1), pk(L.kp_3), pb(L.bp_3), out, nb, L.h, L.w, L.fs, L.fe1, L.fe3,
                                  L.fire_pool, net->dtype, reinterpret_cast<sqdet_stream_t>(st));
   }
+  if (L.type == L_STEMSQ) {
+    const void* x = reinterpret_cast<const char*>(buf_ptr(net, L.in_buf, input, preds)) + (size_t)n0 * L.h * L.w * 3 * esz;
+    void* so = reinterpret_cast<char*>(buf_ptr(net, L.out_buf, input, preds)) + (size_t)n0 * L.ho * L.wo * L.fs2 * esz;
+    const void* wp = net->param_mem + net->params[L.kparam].offset;
+    const float* b = reinterpret_cast<const float*>(net->param_mem + net->params[L.bparam].offset);
+    const void* ws = net->param_mem + net->params[L.kp_s2].offset;
+    const float* bs = reinterpret_cast<const float*>(net->param_mem + net->params[L.bp_s2].offset);
+    bool handled = false;
+    const int rc = stem_squeeze_launch(x, wp, b, ws, bs, so, nb, L.h, L.w, L.cout, L.k, L.pad_mode, L.pool_pad_mode, L.fs2,
+                                       net->dtype, st, &handled);
+    if (rc != SQDET_OK) return rc;
+    if (!handled) { set_error("net: stem + squeeze launch no longer eligible (options changed after net_create?)"); return SQDET_ESTATE; }
+    return SQDET_OK;
+  }
   const int in_c = L.type == L_STEM ? 3 : L.cin;
   const void* x = reinterpret_cast<const char*>(buf_ptr(net, L.in_buf, input, preds)) + (size_t)n0 * L.h * L.w * in_c * esz;
   void* y = reinterpret_cast<char*>(buf_ptr(net, L.out_buf, input, preds)) +
@@ -480,8 +499,16 @@ void fuse_chains(sqdet_net* net, size_t esz) {
   const int dt = net->dtype;
   auto base = [](const Layer& f) { return f.name.substr(0, f.name.find('+')); };
   // how member k of a run could run when it has a successor (0 = it cannot: the run ends before / at it)
+  // the first module right behind a fused stem: its squeeze1x1 moves INTO the stem launch (fuse_stem_squeeze below) when the
+  // module itself can then run from its squeeze tensor ("fire_fuse" = 9: not)
+  auto stem_takes_squeeze = [&](const Layer& f, const Layer& nx) {
+    return tune(3) != 9 && tune(3) != 8 && in.size() > 1 && &f == &in[1] && in[0].type == L_STEM && f.in_buf == in[0].out_buf && !f.fire_pool &&
+           stem_squeeze_eligible(in[0].h, in[0].w, in[0].cout, in[0].k, in[0].pad_mode, in[0].pool_pad_mode, f.fs, dt, net->batch) &&
+           fire_expand_squeeze_next_eligible(f.fs, f.fe1, f.fe3, nx.fs, 0, dt);
+  };
   auto mid_impl = [&](const Layer& f, const Layer& nx, bool first) -> int {
-    if (first && tune(3) != 7 && !f.fire_pool && fire_squeeze_next_eligible(f.cin, f.fs, f.fe1, f.fe3, nx.fs, dt)) return L_FIRESQ;
+    if (first && tune(3) != 7 && !f.fire_pool && !stem_takes_squeeze(f, nx) &&
+        fire_squeeze_next_eligible(f.cin, f.fs, f.fe1, f.fe3, nx.fs, dt)) return L_FIRESQ;
     if (tune(3) != 8 && fire_expand_squeeze_next_eligible(f.fs, f.fe1, f.fe3, nx.fs, f.fire_pool, dt)) return L_EXPSQ;
     if (!f.fire_pool && fire_chain_eligible(f.fs, f.fe1, f.fe3, nx.fs, dt)) return L_CHAIN;
     return 0;
@@ -589,6 +616,30 @@ void fuse_chains(sqdet_net* net, size_t esz) {
   net->layers.swap(out);
 }
 
+// L_STEM followed by the first chained module's squeeze1x1 (a plain 64 -> 16 conv emitted by fuse_chains) -> one L_STEMSQ
+// launch: pool1's tensor is never written.
+void fuse_stem_squeeze(sqdet_net* net, size_t esz) {
+  if (conv_algo() != 0 || tune(3) == 9 || net->layers.size() < 3) return;
+  const Layer& st = net->layers[0];
+  const Layer& sq = net->layers[1];
+  if (st.type != L_STEM || sq.type != L_CONV || sq.k != 1 || sq.stride != 1 || !sq.relu || sq.in_buf != st.out_buf) return;
+  if (sq.cin != st.cout || sq.y_cstride != sq.cout || sq.y_coffset != 0 || sq.accum || sq.fold >= 0) return;
+  if (net->layers[2].type != L_EXPSQ || net->layers[2].in_buf != sq.out_buf) return;
+  if (!stem_squeeze_eligible(st.h, st.w, st.cout, st.k, st.pad_mode, st.pool_pad_mode, sq.cout, net->dtype, net->batch)) return;
+  Layer f = st;
+  f.type = L_STEMSQ;
+  f.name = st.name + "+" + sq.name;
+  f.out_buf = sq.out_buf;
+  f.fs2 = sq.cout;
+  f.kp_s2 = sq.kparam; f.bp_s2 = sq.bparam;
+  f.flops = st.flops + sq.flops;
+  // algorithmic bytes: input + squeeze tensor + both weight sets
+  f.bytes = ((double)net->batch * st.h * st.w * 3 + (double)net->batch * st.ho * st.wo * sq.cout + (double)st.k * st.k * 3 * st.cout +
+             (double)st.cout * sq.cout) * (double)esz + 4.0 * (st.cout + sq.cout);
+  net->layers.erase(net->layers.begin() + 1);
+  net->layers[0] = f;
+}
+
 // conv1 + pool1 -> one L_STEM launch when the fused kernel applies (decided at plan creation).
 void fuse_stem(sqdet_net* net, size_t esz) {
   if (conv_algo() != 0 || net->layers.size() < 2) return;
@@ -664,6 +715,7 @@ extern "C" int sqdet_net_create(sqdet_net_t** out, int arch, int dtype, int batc
   fuse_fires(net, b.esz);
   fuse_fire_pools(net, b.esz);
   fuse_chains(net, b.esz);
+  fuse_stem_squeeze(net, b.esz);
   net->fold_scratch_off = net->param_bytes;
   net->param_bytes = align_up(net->param_bytes + net->fold_scratch_bytes, 256);
   size_t off = 0;

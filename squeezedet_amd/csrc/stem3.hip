@@ -41,7 +41,8 @@ constexpr int QRP = 44;                   // 16-byte pieces fetched per row (704
 constexpr int QPCS = QTR * QRP;           // pieces per tile (1188)
 constexpr int QNIT = (QPCS + 255) / 256;  // fetch rounds per thread (5)
 constexpr int QBIAS = QTR * QPB;          // LDS offset of the 64 float32 biases
-constexpr int QLDS = QBIAS + 256;
+constexpr int QSQW = QBIAS + 256;         // squeeze form: the next layer's 2 KiB of squeeze1x1 fragments + 16 biases
+constexpr int QLDS = QSQW + 2048 + 64;
 constexpr int QOOB = (int)0x80000000;
 
 __device__ __forceinline__ unsigned int pkmax16(unsigned int a, unsigned int b) {
@@ -49,10 +50,18 @@ __device__ __forceinline__ unsigned int pkmax16(unsigned int a, unsigned int b) 
   asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// the same followed by two idle cycles: in the squeeze form the result feeds an MFMA directly, and the wait states between
+// a VALU write and a matrix instruction reading it are only inserted for instructions the compiler emits itself
+__device__ __forceinline__ unsigned int pkmax16_then_idle(unsigned int a, unsigned int b) {
+  unsigned int r;
+  asm("v_pk_max_f16 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // NOT inline asm: the operands are MFMA results, and only for instructions it emits itself does the compiler insert the
 // wait states gfx950 needs between a matrix instruction and a VALU read of its result (an asm v_max3_f32 read stale registers)
 __device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
+template <bool SQ>
 __global__ __launch_bounds__(256, 4) void stem_pers(StemArgs a, int ntiles, int per_xcd, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -84,6 +93,13 @@ __global__ __launch_bounds__(256, 4) void stem_pers(StemArgs a, int ntiles, int 
     }
   }
   if (tid < 64) reinterpret_cast<float*>(lds + QBIAS)[tid] = a.bias[tid];
+  // SQ: the next layer's squeeze1x1 (64 -> 16): its two K-chunk fragments in the standard packing ARE what the MFMA wants
+  // here -- a lane's packed pooled registers o[0..3] / o[4..7] are channels 8g..8g+7 of K-chunk 0 / 1 (see the cout map above)
+  // (kept in LDS, not in registers: the tile loop has none to spare at 128 per wave)
+  if constexpr (SQ) {
+    if (tid < 128) reinterpret_cast<i32x4*>(lds + QSQW)[tid] = reinterpret_cast<const i32x4*>(a.ws2)[tid];
+    if (tid < 16) reinterpret_cast<float*>(lds + QSQW + 2048)[tid] = a.bs2[tid];
+  }
   const int cc = 2 * QSP * wave + j;                                  // conv column of this lane within the tile
   // gather addresses (bytes, patch row 0): groups 0..2 read dwords 0,1,2,4 of patch row dy = g at the lane's 12*cc;
   // group 3 reads dword 3 of rows 0,1,2 (its 4th dword is masked to zero)
@@ -106,7 +122,7 @@ __global__ __launch_bounds__(256, 4) void stem_pers(StemArgs a, int ntiles, int 
   const int G8 = gridDim.x >> 3;
   const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-      a.y, 0, (unsigned int)((size_t)a.N * a.Hp * a.Wp * a.y_cstride * 2), 0x00020000);
+      SQ ? a.s_out : a.y, 0, (unsigned int)((size_t)a.N * a.Hp * a.Wp * (SQ ? 16 : a.y_cstride) * 2), 0x00020000);
 
   // Tile loop: the registers pf hold the patch of the NEXT tile (fetched right after this tile's patch became visible in
   // LDS), so the global-memory latency hides behind the tile's compute.  (A double-buffered LDS variant that stages the
@@ -249,7 +265,8 @@ __global__ __launch_bounds__(256, 4) void stem_pers(StemArgs a, int ntiles, int 
           // lanes j+1, j+2 of the 16-lane row; lanes 14, 15 read zeros past the row end (bound_ctrl) and store nothing
           const unsigned int s1 = (unsigned int)__builtin_amdgcn_mov_dpp((int)o[i], 0x101, 0xf, 0xf, true);
           const unsigned int s2 = (unsigned int)__builtin_amdgcn_mov_dpp((int)o[i], 0x102, 0xf, 0xf, true);
-          o[i] = pkmax16(pkmax16(o[i], pkmax16(s1, s2)), 0u);        // 0u = +0.0 (packed): the ReLU
+          const unsigned int hm = pkmax16(o[i], pkmax16(s1, s2));
+          o[i] = SQ ? pkmax16_then_idle(hm, 0u) : pkmax16(hm, 0u);   // 0u = +0.0 (packed): the ReLU
         }
         if (q == QPR - 1) {
           // vmcnt retires in order: claim the prefetched patch HERE, behind the stores of the first pooled rows only --
@@ -260,6 +277,23 @@ __global__ __launch_bounds__(256, 4) void stem_pers(StemArgs a, int ntiles, int 
         // raw buffer stores: a lane without a pixel (odd j, beyond the strip / image, a pooled row below the map) stores
         // out of range = nowhere
         const bool st_ok = store_lane && py < a.Hp && !(dbg & 1);
+        if constexpr (SQ) {
+          // squeeze1x1 of the next layer on the pooled row: pixel = lane column j (the odd columns carry no pooled pixel and
+          // produce values nobody stores), K = the 64 pooled channels in two chunks, ascending; D row 4g + r = squeeze cout
+          const i32x4 sqw0 = reinterpret_cast<const i32x4*>(lds + QSQW)[lane], sqw1 = reinterpret_cast<const i32x4*>(lds + QSQW)[64 + lane];
+          const f32x4 sqb = *reinterpret_cast<const f32x4*>(lds + QSQW + 2048 + 16 * g);
+          f32x4 sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sqw0),
+              __builtin_bit_cast(f16x8, i32x4{(int)o[0], (int)o[1], (int)o[2], (int)o[3]}), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          sacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sqw1),
+              __builtin_bit_cast(f16x8, i32x4{(int)o[4], (int)o[5], (int)o[6], (int)o[7]}), sacc, 0, 0, 0);
+          sacc += sqb;
+          typedef f16 h4 __attribute__((ext_vector_type(4)));
+          const h4 hv = {(f16)fmaxf(sacc[0], 0.f), (f16)fmaxf(sacc[1], 0.f), (f16)fmaxf(sacc[2], 0.f), (f16)fmaxf(sacc[3], 0.f)};
+          const int so = st_ok ? (int)(((((unsigned)cn * a.Hp + py) * a.Wp + px) * 16 + 4 * g) * 2) : QOOB;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, hv), ry, so, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);   // pooled rows stay in order: overlapping them costs more registers than the wave has
+          continue;
+        }
         const int so = st_ok ? (int)((((unsigned)cn * a.Hp + py) * a.Wp + px) * a.y_cstride + a.y_coffset + cb) * 2 : QOOB;
         __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)o[0], (int)o[1], (int)o[2], (int)o[3]}, ry, so, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(i32x4{(int)o[4], (int)o[5], (int)o[6], (int)o[7]}, ry, st_ok ? so + 64 : QOOB, 0, 0);
@@ -288,7 +322,9 @@ int stem_pers_launch(StemArgs a, int k, int dtype, hipStream_t st, bool* handled
   const int per_xcd = (ntiles + 7) / 8;
   int grid = 1024;                                                   // 4 workgroups per CU, a multiple of 8
   if (per_xcd < grid / 8) grid = per_xcd * 8;
-  hipLaunchKernelGGL(stem_pers, dim3(grid), dim3(256), QLDS, st, a, ntiles, per_xcd, tune(TUNE_DBG) >= 100 ? tune(TUNE_DBG) - 100 : 0);
+  const int dbg = tune(TUNE_DBG) >= 100 ? tune(TUNE_DBG) - 100 : 0;
+  if (a.ws2) hipLaunchKernelGGL(stem_pers<true>, dim3(grid), dim3(256), QLDS, st, a, ntiles, per_xcd, dbg);
+  else hipLaunchKernelGGL(stem_pers<false>, dim3(grid), dim3(256), QLDS, st, a, ntiles, per_xcd, dbg);
   SQDET_CHECK_HIP(hipGetLastError());
   *handled = true;
   return SQDET_OK;

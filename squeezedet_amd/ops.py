@@ -120,6 +120,22 @@ def stem_conv_pool(x, packed, bias, conv_padding="SAME", pool_padding="SAME"):
     return y
 
 
+def stem_conv_pool_squeeze(x, packed, bias, p_next_s, b_next_s, conv_padding="SAME", pool_padding="SAME"):
+    """conv1 + pool1 + the next module's squeeze1x1 in one launch (sqdet_stem_conv_pool_squeeze_fwd): only the squeeze tensor
+    [N, Hp, Wp, next_s] is written."""
+    n, h, w, cin = [int(v) for v in x.shape]
+    if cin != 3 or packed.cin != 3 or x.dtype != packed.dtype:
+        raise _lib.SqdetError("stem_conv_pool_squeeze: needs a 3-channel input matching the packed kernel")
+    hc, wc = _out_size(h, packed.k, 2, conv_padding), _out_size(w, packed.k, 2, conv_padding)
+    hp, wp = _out_size(hc, 3, 2, pool_padding), _out_size(wc, 3, 2, pool_padding)
+    so = torch.empty((n, hp, wp, p_next_s.cout), dtype=x.dtype, device=x.device)
+    check(lib().sqdet_stem_conv_pool_squeeze_fwd(_dev(x, "x"), _dev(packed.data, "packed"), _dev(bias, "bias", torch.float32),
+                                                 _dev(p_next_s.data, "w_next_s"), _dev(b_next_s, "b_next_s", torch.float32), _dev(so, "sq_out"),
+                                                 n, h, w, packed.cout, packed.k, pad_code(conv_padding), pad_code(pool_padding),
+                                                 p_next_s.cout, dtype_code(x.dtype), stream_ptr()), "sqdet_stem_conv_pool_squeeze_fwd")
+    return so
+
+
 def fire(x, p_s, b_s, p_e1, b_e1, p_e3, b_e3):
     """SqueezeDet._fire_layer (nets/squeezeDet.py:81-106)."""
     n, h, w, cin = [int(v) for v in x.shape]

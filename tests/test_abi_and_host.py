@@ -64,8 +64,9 @@ def test_net_plan_tables_without_gpu(lib):
         return out
     assert lib.sqdet_net_create(C.byref(h), _lib.ARCH_SQUEEZEDET, _lib.F16, 32, 375, 1242, 3, 9) == 0
     names_default = layer_names()
-    # the ten fire modules are ONE run: between its launches only squeeze tensors travel (through the pools too)
-    assert names_default == ["conv1+pool1", "fire2+fire3/squeeze1x1", "fire3/expand+pool3+fire4/squeeze1x1", "fire4/expand+fire5/squeeze1x1",
+    # conv1 to fire11 is ONE run: between its launches only squeeze tensors travel (through the pools too) -- the stem launch
+    # ends with fire2's squeeze1x1
+    assert names_default == ["conv1+pool1+fire2/squeeze1x1", "fire2/expand+fire3/squeeze1x1", "fire3/expand+pool3+fire4/squeeze1x1", "fire4/expand+fire5/squeeze1x1",
                              "fire5/expand+pool5+fire6/squeeze1x1", "fire6/expand+fire7/squeeze1x1", "fire7/expand+fire8/squeeze1x1",
                              "fire8/expand+fire9/squeeze1x1", "fire9/expand+fire10/squeeze1x1", "fire10/expand+fire11/squeeze1x1",
                              "fire11/expand", "conv12"]
@@ -75,6 +76,12 @@ def test_net_plan_tables_without_gpu(lib):
         assert lib.sqdet_net_layer_info(h, i, None, 0, C.byref(tot_f), None) == 0
         fsum += tot_f.value
     assert abs(fsum / 32 / 1e9 - 10.492) < 0.01     # the chained plan does the same arithmetic: GFLOP / image @375x1242
+    lib.sqdet_net_destroy(h)
+    # "fire_fuse" = 9: the stem keeps to conv1 + pool1 and fire2 runs whole from pool1's tensor (the round-2 'b' plan)
+    assert lib.sqdet_set_option(b"fire_fuse", 9) == 0
+    assert lib.sqdet_net_create(C.byref(h), _lib.ARCH_SQUEEZEDET, _lib.F16, 32, 375, 1242, 3, 9) == 0
+    assert lib.sqdet_set_option(b"fire_fuse", 0) == 0
+    assert layer_names()[:3] == ["conv1+pool1", "fire2+fire3/squeeze1x1", "fire3/expand+pool3+fire4/squeeze1x1"]
     lib.sqdet_net_destroy(h)
     # "fire_fuse" = 8: no streaming expand + next-squeeze launches -- the pooled modules end their runs (round-2 midpoint plan)
     assert lib.sqdet_set_option(b"fire_fuse", 8) == 0

@@ -94,9 +94,10 @@ def test_native_plan_equals_builder_graph_and_oracle(dtype):
         scale = p_graph.float().abs().max().item()
         assert d <= 4e-3 * scale + 1e-4, "plan vs graph: %g of %g" % (d, scale)
         from squeezedet_amd import ops
-        ops.set_option("stem_algo", 2)
+        ops.set_option("stem_algo", 2)       # decided at plan creation: a second model whose plan keeps to the strip stem
         try:
-            p_strip = m.run([m.preds], {m.image_input: x}, use_plan=True)[0]
+            m2 = _model("squeezeDet", dtype, 2, (375, 1242))[0]
+            p_strip = m2.run([m2.preds], {m2.image_input: x}, use_plan=True)[0]
             torch.cuda.synchronize()
         finally:
             ops.set_option("stem_algo", 0)

@@ -619,7 +619,7 @@ def test_fire_squeeze_next_one_launch(case):
     np.testing.assert_allclose(got.float().cpu().numpy(), ref.numpy(), rtol=2 ** -8, atol=2e-3)
 
 
-EXPSQ_CASES = [("fire3p-4", 16, 64, 32, 94, 311, 2, True), ("fire3p-4-odd", 16, 64, 32, 19, 37, 3, True), ("fire4-5", 32, 128, 32, 47, 156, 2, False),
+EXPSQ_CASES = [("fire2-3", 16, 64, 16, 94, 311, 2, False), ("fire2-3-ragged", 16, 64, 16, 21, 45, 3, False), ("fire3p-4", 16, 64, 32, 94, 311, 2, True), ("fire3p-4-odd", 16, 64, 32, 19, 37, 3, True), ("fire4-5", 32, 128, 32, 47, 156, 2, False),
                ("fire4-5-small", 32, 128, 32, 9, 15, 5, False), ("fire5p-6", 32, 128, 48, 47, 156, 2, True), ("fire5p-6-even", 32, 128, 48, 20, 28, 1, True)]
 
 
@@ -643,6 +643,30 @@ def test_fire_expand_squeeze_next(case):
     want = ops.conv2d_nhwc(y, pn, bn, 1, "SAME", True)
     torch.cuda.synchronize()
     assert got.shape == want.shape and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("shape", [(2, 375, 1242), (3, 45, 250), (1, 100, 236), (5, 19, 480)], ids=lambda v: "x".join(map(str, v)))
+def test_stem_conv_pool_squeeze(shape):
+    """sqdet_stem_conv_pool_squeeze_fwd (conv1 + pool1 + fire2/squeeze1x1 in the persistent stem launch: pool1's tensor is
+    never written) BITWISE against the persistent stem followed by the squeeze conv, and against the oracle."""
+    ops = _ops()
+    N, H, W = shape
+    rs = np.random.RandomState(H * 3 + W)
+    x = torch.from_numpy(rs.uniform(-2, 2, (N, H, W, 3)).astype(np.float32)).half()
+    w = torch.from_numpy((rs.randn(3, 3, 3, 64) * (2.0 / 27) ** 0.5).astype(np.float32)).half().float()
+    b = torch.from_numpy(rs.uniform(-0.5, 0.5, 64).astype(np.float32))
+    ws = torch.from_numpy((rs.randn(1, 1, 64, 16) * (2.0 / 64) ** 0.5).astype(np.float32)).half().float()
+    bs = torch.from_numpy(rs.uniform(-0.3, 0.3, 16).astype(np.float32))
+    assert ops.lib().sqdet_stem_conv_pool_squeeze_supported(H, W, 64, 3, 0, 0, 16, 1, N) == 1
+    p, ps = ops.pack_conv_weights(w.to(DEV), torch.float16), ops.pack_conv_weights(ws.to(DEV), torch.float16)
+    xd = x.to(DEV).contiguous()
+    got = ops.stem_conv_pool_squeeze(xd, p, b.to(DEV), ps, bs.to(DEV))
+    pool1 = ops.stem_conv_pool(xd, p, b.to(DEV))
+    want = ops.conv2d_nhwc(pool1, ps, bs.to(DEV), 1, "SAME", True)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape and torch.equal(got, want)
+    ref = O.conv_layer(O.pooling_layer(O.conv_layer(x.float(), w, b, 2, "SAME", True, storage="fp16"), 3, 2, "SAME"), ws, bs, 1, "SAME", True, storage="fp16")
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref.numpy(), rtol=2 ** -8, atol=2e-3)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
