@@ -428,6 +428,7 @@ static bool dispatch_tile(const TileArgs& a, int mt, int ntw, bool splitk, int g
       case 1: launch_tile<T, 8, 1, false>(a, grid_y, lds, st); return true;
       case 2: launch_tile<T, 8, 2, false>(a, grid_y, lds, st); return true;
       case 3: launch_tile<T, 8, 3, false>(a, grid_y, lds, st); return true;
+      case 4: launch_tile<T, 8, 4, false>(a, grid_y, lds, st); return true;
       default: return false;
     }
   }
@@ -482,6 +483,12 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
     } else if (g.nt == 4 && g.ngroups == 1) {
       mt = 8; ntw = 1;
       grid_y = 1;
+    } else if (g.nt == 4 && g.ngroups % 4 == 0 && g.nchunk >= 4 && (long)c.N * a.tiles_x * a.tiles_y * (g.ngroups / 4) >= 384) {
+      // whole-tile waves, four cout groups per workgroup: an A fragment feeds 8 MFMAs instead of 4 (SqueezeDet+ fire8
+      // expand3x3 110 -> 98 us = 1.0 PF/s); only with enough tiles -- on the 22x76 maps at batch 8 the 120 workgroups of this
+      // layout take 76 us against 43
+      mt = 8; ntw = 4;
+      grid_y = g.ngroups / 4;
     } else {
       mt = g.ngroups >= 2 ? 4 : 2;
       const int wc = mt == 4 ? 2 : 1;
