@@ -1,4 +1,4 @@
-// 1x1 / stride-1 convolution with deep K as a workgroup-level GEMM tile (the squeeze / expand1x1 layers of SqueezeDet+,
+// 1x1 convolution (any stride) with deep K as a workgroup-level GEMM tile (the squeeze / expand1x1 layers of SqueezeDet+,
 // every 1x1 of ResNet50's bottleneck blocks incl. the residual-accumulate ones; reference src/nn_skeleton.py:471-563 via
 // nets/squeezeDetPlus.py:81-106 and nets/resnet50_convDet.py:134-169).
 //
@@ -91,8 +91,16 @@ __global__ __launch_bounds__(256) void conv1x1_tile(G1Args a) {
           const int P = id / ppc, q = id - P * ppc;
           const int gq = c0 * 4 + q;
           v[u] = i32x4{0, 0, 0, 0};
-          if (id < total && gq < a.pieces && p0 + P < a.c.P)
-            v[u] = *reinterpret_cast<const i32x4*>(x + (size_t)(p0 + P) * row_bytes + gq * 16);
+          if (id < total && gq < a.pieces && p0 + P < a.c.P) {
+            size_t sp = (size_t)(p0 + P);                 // source pixel of output pixel p0 + P
+            if (a.c.stride != 1) {                        // strided 1x1 (ResNet50's res3a / res4a reductions): every stride-th pixel
+              const int hw = a.c.Ho * a.c.Wo;
+              const int n = (p0 + P) / hw, r = (p0 + P) - n * hw;
+              const int oy = r / a.c.Wo, ox = r - oy * a.c.Wo;
+              sp = ((size_t)n * a.c.H + (size_t)oy * a.c.stride) * a.c.W + (size_t)ox * a.c.stride;
+            }
+            v[u] = *reinterpret_cast<const i32x4*>(x + sp * row_bytes + gq * 16);
+          }
           off[u] = id < total ? (q >> 2) * CH + P * 64 + (((q & 3) ^ ((P >> 1) & 3)) << 4) : -1;
         }
 #pragma unroll
@@ -198,7 +206,7 @@ bool dispatch_g1(const G1Args& a, int mbw, int wr, int ntw, size_t lds, hipStrea
 int conv1x1_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStream_t st, bool* handled) {
   *handled = false;
   if (conv_algo() != 0) return SQDET_OK;
-  if (c.k != 1 || c.stride != 1 || g.gather) return SQDET_OK;
+  if (c.k != 1 || c.stride < 1 || c.pt != 0 || c.pl != 0 || g.gather) return SQDET_OK;
   const int esz = dtype == SQDET_F16 ? 2 : 4;
   if ((c.Cin * esz) % 16 != 0 || (c.x_cstride * esz) % 16 != 0 || (c.x_coffset * esz) % 16 != 0) return SQDET_OK;
   if (g.nt < 3 && g.ngroups != 1) return SQDET_OK;          // 1- and 2-tile groups: only the one-slice layout (Cout <= 32)

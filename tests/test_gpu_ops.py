@@ -89,6 +89,8 @@ CONV_CASES = [
     ("g1_k2048_n512", 1, 7, 9, 2048, 512, 1, 1, "SAME", True),
     ("g1_k1024_n2048", 1, 5, 11, 1024, 2048, 1, 1, "SAME", False),
     ("g1_k264_n40", 3, 11, 7, 264, 40, 1, 1, "SAME", True),
+    ("g1_stride2_k256_n512", 2, 23, 31, 256, 512, 1, 2, "SAME", False),
+    ("g1_stride2_k256_n128", 1, 94, 61, 256, 128, 1, 2, "SAME", True),
     # 3x3 with K walked in 4-chunk LDS stages (SqueezeDet+ fire6-11: 9 / 12 chunks in fp16; ResNet50 res4 / res5)
     ("e3_k288_n192", 1, 17, 30, 288, 192, 3, 1, "SAME", True),
     ("e3_k384_n256", 2, 9, 19, 384, 256, 3, 1, "SAME", True),

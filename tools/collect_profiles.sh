@@ -16,6 +16,16 @@ python $R/bench.py --no-cpu-baseline --layer-table $OUT/layer_table.json > /dev/
 # 2. rocprofv3 kernel stats of the headline command
 rocprofv3 --kernel-trace --stats -d $OUT/kstats -o ks --output-format csv -- python $R/bench.py --no-cpu-baseline > $OUT/kstats.log 2>&1
 python $R/profiles/summarize.py $(find $OUT/kstats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline" >> $OUT/kstats.log 2>&1
+# 2b. kernel stats of the other configs (which kernels carry SqueezeDet+, ResNet50 inference and the two training steps)
+for c in sqdetplus_infer sqdet_train_fp32 res50_train_fp16; do
+  rocprofv3 --kernel-trace --stats -d $OUT/ks_$c -o ks --output-format csv -- python $R/bench.py --config $c --no-cpu-baseline --no-graph > $OUT/kstats_$c.log 2>&1
+  python $R/profiles/summarize.py $(find $OUT/ks_$c -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$c.txt "rocprofv3 --kernel-trace --stats -- python bench.py --config $c --no-cpu-baseline --no-graph" >> $OUT/kstats_$c.log 2>&1
+  rm -rf $OUT/ks_$c
+done
+rocprofv3 --kernel-trace --stats -d $OUT/ks_res50_infer -o ks --output-format csv -- python $R/tools/netbench.py --arch resnet50 --batch 8 > $OUT/netbench_resnet50_b8.txt 2>&1
+python $R/profiles/summarize.py $(find $OUT/ks_res50_infer -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_res50_infer.txt "rocprofv3 --kernel-trace --stats -- python tools/netbench.py --arch resnet50 --batch 8" >> $OUT/kstats.log 2>&1
+rm -rf $OUT/ks_res50_infer
+python $R/tools/nextrows_bench.py > $OUT/nextrows_bench.json 2>/dev/null
 # 3. HBM (fabric) traffic per launch: FETCH_SIZE and WRITE_SIZE in separate passes
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch --output-format csv -- python $R/tools/pmc_forward.py > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o write --output-format csv -- python $R/tools/pmc_forward.py > $OUT/pmc_write.log 2>&1
