@@ -2,7 +2,8 @@
 """Where a fire_stream tile goes (experiment): needs libsqdet_hip.so built with fire2.hip compiled -DSQDET_FIRE_TIMING
 (see DESIGN.md).  Runs one fire module launch (batch 32 shapes of SqueezeDet) and prints the mean s_memtime cycles per
 tile of each segment of the tile loop, per wave.
-    python tools/fire_timing.py fire3 [--pool] [--sqnext: the module + the next module's squeeze, sqdet_fire_squeeze_next_fwd]"""
+    python tools/fire_timing.py fire3 [--pool] [--sqnext: the module + the next module's squeeze, sqdet_fire_squeeze_next_fwd]
+    [--expsq: expand (+ pool) from the squeeze tensor + next squeeze, sqdet_fire_expand_squeeze_next_fwd]"""
 import ctypes as C
 import os
 import sys
@@ -13,7 +14,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from squeezedet_amd import _lib, ops  # noqa: E402
 
-SHAPES = {"fire2": (94, 311, 64, 16, 64), "fire3": (96, 312, 128, 16, 64), "fire4": (48, 156, 128, 32, 128), "fire5": (48, 156, 256, 32, 128)}
+SHAPES = {"fire2": (94, 311, 64, 16, 64), "fire3": (94, 311, 128, 16, 64), "fire4": (47, 156, 128, 32, 128), "fire5": (47, 156, 256, 32, 128)}
 SEG = ["A: squeeze MFMAs", "A: bias/relu/LDS store", "prefetch issue", "barrier", "B: 3x3 MFMAs", "B: 3x3 epilogue", "B: 1x1 + epilogue", "loop overhead"]
 
 
@@ -32,6 +33,11 @@ def main():
     bs, b1, b3 = [torch.zeros(c, device=dev) for c in (s, e, e)]
     x = torch.randn(32, h, w, cin, device=dev).half()
     fn = (lambda: ops.fire_maxpool(x, ps, bs, p1, b1, p3, b3)) if pool else (lambda: ops.fire(x, ps, bs, p1, b1, p3, b3))
+    if "--expsq" in sys.argv:      # the module's expand half (+ pool) from its squeeze tensor + the next module's squeeze
+        s2 = {"fire2": 16, "fire3": 32, "fire4": 32, "fire5": 48}[name]
+        pn, bn = ops.pack_conv_weights(mk(1, 2 * e, s2), torch.float16), torch.zeros(s2, device=dev)
+        sq = torch.relu(torch.randn(32, h, w, s, device=dev)).half()
+        fn = lambda: ops.fire_expand_squeeze_next(sq, p1, b1, p3, b3, pn, bn, pool=pool)
     if "--sqnext" in sys.argv:
         pn, bn = ops.pack_conv_weights(mk(1, 2 * e, s), torch.float16), torch.zeros(s, device=dev)
         fn = lambda: ops.fire_squeeze_next(x, ps, bs, p1, b1, p3, b3, pn, bn)
