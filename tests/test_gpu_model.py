@@ -106,6 +106,24 @@ def test_native_plan_equals_builder_graph_and_oracle(dtype):
     _check_layers(p_plan, ref, dtype, "preds")
 
 
+@pytest.mark.parametrize("shape", [(3, 200, 600), (1, 97, 333), (5, 130, 236), (2, 64, 1000)], ids=lambda v: "x".join(map(str, v)))
+def test_native_plan_other_sizes_and_batches_fp16_vs_oracle(shape):
+    """The chained fp16 plan (stem + fire2's squeeze, squeeze-tensor launches through the pools, chain launches with two
+    images per workgroup, ConvDet) away from the two benchmark sizes: odd batches, ragged tiles everywhere, an odd width
+    (strip stem, no stem-squeeze launch), maps smaller than one tile row -- against the oracle in float16-storage mode."""
+    n, h, w = shape
+    m, mc, params, storage = _model("squeezeDet", torch.float16, n, (h, w))
+    x = O.synthetic_images(n, h, w, seed=7, storage=storage)
+    got = m.run([m.preds], {m.image_input: x}, use_plan=True)[0]
+    torch.cuda.synchronize()
+    ref = O.forward("squeezeDet", params, x, storage)
+    _check_layers(got, ref, torch.float16, "preds %dx%dx%d" % shape)
+    g2 = m.run([m.preds], {m.image_input: x}, use_plan=False)[0]       # the op-by-op graph agrees to fp16 noise as well
+    torch.cuda.synchronize()
+    d = (got.float() - g2.float()).abs().max().item()
+    assert d <= 4e-3 * g2.float().abs().max().item() + 1e-4
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
 def test_squeezedet_plus_vs_oracle(dtype):
     m, mc, params, storage = _model("squeezeDet+", dtype, 1)
