@@ -44,6 +44,9 @@ CONFIGS = {
                              metric="images/sec SqueezeDet 1248x384 fp32 training", steps=20, warmup=3),
     "res50_train_fp16": dict(kind="train", arch="resnet50", batch=8, height=375, width=1242, dtype="fp16",
                              metric="images/sec ResNet50+ConvDet 1242x375 fp16 (mixed precision) training", steps=20, warmup=3),
+    # (not a BASELINE.json config: configs[2] in mixed precision, for the fp32 / fp16 comparison DESIGN.md quotes)
+    "sqdet_train_fp16": dict(kind="train", arch="squeezeDet", batch=20, height=384, width=1248, dtype="fp16",
+                             metric="images/sec SqueezeDet 1248x384 fp16 (mixed precision) training", steps=20, warmup=3),
 }
 
 
