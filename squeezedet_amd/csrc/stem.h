@@ -1,4 +1,5 @@
-// Arguments shared by the fused-stem kernels (stem.hip: LDS conv tile; stem2.hip: in-register pool; stem3.hip: persistent).
+// Arguments shared by the fused-stem kernels (stem2.hip: strip kernel, pool in registers; stem3.hip: persistent); stem.hip is
+// their host side.
 #pragma once
 #include "conv_common.h"
 

@@ -116,7 +116,6 @@ __global__ __launch_bounds__(256, 4) void stem_pers(StemArgs a, int ntiles, int 
     dst_off[it] = p < QPCS ? row * QPB + c16 * 16 : -1;
   }
   const int cb = g * 8;                                               // this lane's couts: cb..cb+7 and 32+cb..32+cb+7
-  const unsigned int NEGH = 0xfc00fc00u;                              // -inf (packed f16)
   const float NEGF = __uint_as_float(0xff800000u);
   const unsigned int img_bytes = (unsigned int)a.H * a.W * 6;
   const int G8 = gridDim.x >> 3;
