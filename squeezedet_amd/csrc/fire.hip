@@ -59,7 +59,6 @@ __device__ unsigned long long g_ff_timing[2048 * 8];
 template <typename T, int NTS, int NTW, int MT>
 __global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused(FireArgs a) {
   constexpr int KG = Tr<T>::KG;
-  constexpr int KC = 4 * KG;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
