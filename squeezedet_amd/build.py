@@ -22,6 +22,8 @@ SOURCES = [
     # second copy of the accumulators in VGPRs around the epilogue and halves occupancy.
     ("conv.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("conv3x3.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    # the ConvDet split-K kernel needs > 256 registers: accumulators in AGPRs (hipcc's default form), see convdet.hip
+    ("convdet.hip", []),
     ("conv1x1.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("gemm1x1.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("stem.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
