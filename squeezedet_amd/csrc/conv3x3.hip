@@ -7,12 +7,12 @@ namespace sqdet {
 template <typename T, int MT>
 static bool dispatch_ntw(const TileArgs& a, int ntw, int grid_y, size_t lds, hipStream_t st) {
   switch (ntw) {
-    case 1: launch_tile<T, MT, 1, false>(a, grid_y, lds, st); return true;
-    case 2: launch_tile<T, MT, 2, false>(a, grid_y, lds, st); return true;
-    case 3: launch_tile<T, MT, 3, false>(a, grid_y, lds, st); return true;
-    case 4: launch_tile<T, MT, 4, false>(a, grid_y, lds, st); return true;
-    case 5: launch_tile<T, MT, 5, false>(a, grid_y, lds, st); return true;
-    case 6: launch_tile<T, MT, 6, false>(a, grid_y, lds, st); return true;
+    case 1: launch_tile<T, MT, 1>(a, grid_y, lds, st); return true;
+    case 2: launch_tile<T, MT, 2>(a, grid_y, lds, st); return true;
+    case 3: launch_tile<T, MT, 3>(a, grid_y, lds, st); return true;
+    case 4: launch_tile<T, MT, 4>(a, grid_y, lds, st); return true;
+    case 5: launch_tile<T, MT, 5>(a, grid_y, lds, st); return true;
+    case 6: launch_tile<T, MT, 6>(a, grid_y, lds, st); return true;
     default: return false;
   }
 }
@@ -21,14 +21,14 @@ template <typename T>
 static bool dispatch_tile(const TileArgs& a, int mt, int ntw, bool splitk, int grid_y, size_t lds, hipStream_t st) {
   if (splitk) {
     if (ntw != 5) return false;
-    return convdet_tile_launch(a, lds, sizeof(T) == 2 ? SQDET_F16 : SQDET_F32, st) == SQDET_OK;
+    return convdet_tile_launch(a, sizeof(T) == 2 ? SQDET_F16 : SQDET_F32, st) == SQDET_OK;
   }
   if (mt == 8) {  // one wave = all 8 tile rows x a slice of a group (4 waves along the cout tiles)
     switch (ntw) {
-      case 1: launch_tile<T, 8, 1, false>(a, grid_y, lds, st); return true;
-      case 2: launch_tile<T, 8, 2, false>(a, grid_y, lds, st); return true;
-      case 3: launch_tile<T, 8, 3, false>(a, grid_y, lds, st); return true;
-      case 4: launch_tile<T, 8, 4, false>(a, grid_y, lds, st); return true;
+      case 1: launch_tile<T, 8, 1>(a, grid_y, lds, st); return true;
+      case 2: launch_tile<T, 8, 2>(a, grid_y, lds, st); return true;
+      case 3: launch_tile<T, 8, 3>(a, grid_y, lds, st); return true;
+      case 4: launch_tile<T, 8, 4>(a, grid_y, lds, st); return true;
       default: return false;
     }
   }
@@ -65,9 +65,6 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
     // ConvDet-like: few couts, deep K -> split K over the 4 waves, 4 chunks per stage
     splitk = true;
     mt = 8;
-    lds = 4 * (size_t)CHUNK_BYTES;                         // 46080 B
-    const size_t red = (size_t)12 * (TROWS / 4) * 5 * 1024;   // 122880 B: reduce-scatter slots [owner][source]
-    if (red > lds) lds = red;
   } else {
     // a wave owns one whole packed group; 2 groups per workgroup (waves 2 rows x 2 groups) when
     // there are several, else the 4 waves split the 8 tile rows

@@ -13,9 +13,8 @@
 //   * COUT-split mode (expand3x3): a wave owns MT tile rows x one whole packed cout group
 //     (NTW = 4..6 tiles -> 32..48 contiguous output bytes per lane); the 4 waves are laid out
 //     WR = 8/MT along the rows x WC = 4/WR along the cout groups.
-//   * SPLIT-K mode (ConvDet, Cin = 768, 72 couts = 5 tiles): every wave owns all 5 cout tiles
-//     and a quarter of K -- the input is staged in stages of 4 K-chunks, wave w taking chunk w --
-//     and the 4 partial accumulators are summed through LDS at the end.
+//   * The ConvDet head (Cin = 768, 72 couts = 5 tiles) uses the same tile and LDS layout with K split over the waves:
+//     convdet.hip.
 #pragma once
 #include "conv_common.h"
 
@@ -72,23 +71,12 @@ __device__ __forceinline__ void stage_tile(const TileArgs& a, unsigned char* lds
   }
 }
 
-// -DSQDET_FIRE_TIMING (experiments only): per-wave s_memtime totals of the split-K kernel's segments (tools/convdet_timing.py)
-#ifdef SQDET_FIRE_TIMING
-__device__ unsigned long long g_cd_timing[2048 * 8];
-#define CT_MARK(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ct_acc[k] += now_ - ct_last; ct_last = now_; } while (0)
-#else
-#define CT_MARK(k) do {} while (0)
-#endif
-
-template <typename T, int MT, int NTW, bool SPLITK>
+template <typename T, int MT, int NTW>
 __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
-#ifdef SQDET_FIRE_TIMING
-  unsigned long long ct_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ct_last = __builtin_amdgcn_s_memtime();
-#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int WR = TROWS / MT;   // waves along the tile rows
   constexpr int WC = 4 / WR;       // waves along the cout groups
-  static_assert(SPLITK ? MT == TROWS : (WR * MT == TROWS && WR * WC == 4), "bad wave layout");
+  static_assert(WR * MT == TROWS && WR * WC == 4, "bad wave layout");
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
@@ -103,8 +91,8 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
   const int oy0 = ty * TROWS, ox0 = tx * TCOLS;
 
   // rows and cout tiles this wave owns
-  const int m0 = SPLITK ? 0 : (wave % WR) * MT;
-  const int tile0 = SPLITK ? 0 : (blockIdx.y * WC + wave / WR) * NTW;
+  const int m0 = (wave % WR) * MT;
+  const int tile0 = (blockIdx.y * WC + wave / WR) * NTW;
   const bool active = tile0 < a.total_tiles;
   const int group = tile0 / a.nt_pack;
   const int n0 = tile0 - group * a.nt_pack;
@@ -116,123 +104,11 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
     for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const i32x4* wbase = reinterpret_cast<const i32x4*>(a.c.wp) + ((size_t)group * a.c.steps * a.nt_pack + n0) * 64 + lane;
-  const int nstages = SPLITK ? (a.nchunk + 3) / 4 : (a.nchunk + a.stage_chunks - 1) / a.stage_chunks;
+  const int nstages = (a.nchunk + a.stage_chunks - 1) / a.stage_chunks;
 
   i32x4 wq[3][NTW];   // cout-split mode: weight fragments of three consecutive steps
-  if constexpr (SPLITK) {
-    // Wave w walks chunk 4*stage + w of every stage, 9 taps each: one 5-KiB weight step per 40 MFMAs (~0.27 us of
-    // the matrix pipe), and every weight byte is used once per workgroup, so each step's fragments come from L2
-    // (~0.8 us).  With a one-step look-ahead the wave was latency-bound (a workgroup alone on a CU: 65 us, 54 steps).
-    // Here the 9 taps are unrolled over THREE register sets named statically (step s uses set s % 3; 9 % 3 == 0, so
-    // the names line up across the stage loop and nothing is ever copied), two steps are in flight, and the first two
-    // of the next stage are issued before this stage ends -- they cross the staging barriers.
-    // (requires nchunk % 4 == 0: every wave has a chunk in every stage)
-    // That needs ~350 registers: one workgroup per CU (one wave per SIMD, 512 registers each), so nobody else hides
-    // this workgroup's input staging any more -- the NEXT stage's 46 KB are therefore fetched into registers (12 x 16 B
-    // per thread, raw buffer loads: out-of-image / past-the-end offsets have bit 31 set and return the zero padding)
-    // while the current stage computes, and only the LDS stores sit between the two barriers.
-    constexpr int NSV = (HP * 16 + 255) / 256;   // 16-byte pieces per thread per stage = 12 (the last one partial)
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.c.x), 0, a.x_bytes, 0x00020000);
-    const int sq = threadIdx.x & 15, sP0 = threadIdx.x >> 4;   // piece of the stage's 16; first halo pixel (then +16 per u)
-    unsigned goff[NSV];
-#pragma unroll
-    for (int u = 0; u < NSV; ++u) {
-      const int P = sP0 + 16 * u;
-      const int r = P / (TCOLS + 2), cc = P - r * (TCOLS + 2);
-      const int iy = oy0 - 1 + r, ix = ox0 - 1 + cc;
-      const bool ok = P < HP && iy >= 0 && iy < a.c.H && ix >= 0 && ix < a.c.W;
-      goff[u] = ok ? (unsigned)(((n * a.c.H + iy) * a.c.W + ix) * (a.pieces * 16) + sq * 16) : 0x80000000u;
-    }
-    // ((P + 16u) >> 1) & 3 == (P >> 1) & 3: the XOR slot is the same for all of a thread's pixels
-    unsigned char* sdst = lds + (sq >> 2) * CHUNK_BYTES + sP0 * 64 + (((sq & 3) ^ ((sP0 >> 1) & 3)) << 4);
-    i32x4 sv[NSV];
-    auto sload = [&](int stage) {
-      const unsigned so = stage < nstages ? (unsigned)stage * 256u : 0x80000000u;
-#pragma unroll
-      for (int u = 0; u < NSV; ++u) sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, goff[u] + so, 0, 0);
-    };
-    // After the first stage the pieces are issued two per tap over taps 0..5, not as one burst behind the barrier: the
-    // CU's L1 already moves 20 KB of weight fragments per tap (~60 % of its fill rate with the input), and a 12-deep burst
-    // from all four waves stalls the weight stream queued behind it (conv12 at batch 32: 69 -> 66 us)
-    auto sload_part = [&](int stage, int t9) {
-      const unsigned so = stage < nstages ? (unsigned)stage * 256u : 0x80000000u;
-#pragma unroll
-      for (int u = 2 * t9; u < 2 * t9 + 2; ++u)
-        if (u < NSV) sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, goff[u] + so, 0, 0);
-    };
-    static_assert(NSV <= 12, "two pieces per tap over six taps");
-    sload(0);
-    i32x4 wf[3][NTW];
-    auto wstep = [&](int stage, int t9) {   // weight fragments of (stage, tap) for this wave; clamped past the end
-      const int st = stage < nstages ? stage : nstages - 1;
-      return wbase + (size_t)(t9 * a.nchunk + st * 4 + wave) * a.nt_pack * 64;
-    };
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const i32x4* wp = wstep(0, p);
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) wf[p][t] = wp[t * 64];
-    }
-#pragma unroll 1
-    for (int stage = 0; stage < nstages; ++stage) {
-      CT_MARK(0);
-      if (stage > 0) __syncthreads();   // every wave is done reading the previous stage
-      CT_MARK(1);
-#pragma unroll
-      for (int u = 0; u < NSV; ++u)
-        if (u < NSV - 1 || sP0 + 16 * u < HP) *reinterpret_cast<i32x4*>(sdst + u * 1024) = sv[u];   // sP0 <= 15
-      CT_MARK(2);
-      __syncthreads();
-      CT_MARK(3);
-      const unsigned char* lchunk = lds + wave * CHUNK_BYTES;
-      // B fragments of tap t9 + 1 are read from LDS under the MFMAs of tap t9 (two statically named sets)
-      i32x4 bfs[2][MT];
-      auto bread = [&](int t9, i32x4 (&bf)[MT]) {
-        const int dy = t9 / 3, dx = t9 - dy * 3;
-        const int P0 = dy * (TCOLS + 2) + j + dx;
-        const int h0 = P0 >> 1;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const int slot = g ^ ((h0 + m) & 3);
-          bf[m] = *reinterpret_cast<const i32x4*>(lchunk + (P0 + (TCOLS + 2) * m) * 64 + (slot << 4));
-        }
-      };
-      bread(0, bfs[0]);
-      CT_MARK(4);
-#pragma unroll
-      for (int t9 = 0; t9 < 9; ++t9) {
-        __builtin_amdgcn_sched_barrier(0);   // steps stay in order: no later tap's reads hoisted, no load sunk
-        {
-          const i32x4* wp = t9 + 2 < 9 ? wstep(stage, t9 + 2) : wstep(stage + 1, t9 + 2 - 9);
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) wf[(t9 + 2) % 3][t] = wp[t * 64];
-        }
-        if (t9 < 6) sload_part(stage + 1, t9);
-        if (t9 + 1 < 9) bread(t9 + 1, bfs[(t9 + 1) & 1]);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], wf[t9 % 3][t], bfs[t9 & 1][m]);
-        // issue order inside the step: one memory instruction, then three MFMAs (the 13 issues + their address
-        // arithmetic cost ~200 cycles per step when they all sat ahead of the 40 MFMAs)
-        const bool spread = t9 < 6;   // two more VMEM issues in this step
-#pragma unroll
-        for (int k = 0; k < NTW + (spread ? 2 : 0); ++k) {
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // MFMA
-        }
-#pragma unroll
-        for (int k = 0; k < (t9 + 1 < 9 ? MT : 0); ++k) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-          if (spread) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          else __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        }
-      }
-      CT_MARK(5);
-    }
-  } else
   for (int stage = 0; stage < nstages; ++stage) {
-    const int sc = SPLITK ? 4 : a.stage_chunks;
+    const int sc = a.stage_chunks;
     const int c0 = stage * sc;
     const int nload = a.nchunk - c0 < sc ? a.nchunk - c0 : sc;
     if (stage > 0) __syncthreads();  // everyone done reading the previous stage
@@ -315,65 +191,6 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
     nt_valid += ok ? 1 : 0;
   }
 
-  if (SPLITK) {
-    // Deterministic sum of the 4 K-partial accumulators, ((w0+w1)+w2)+w3, as a reduce-scatter through LDS: wave o
-    // owns tile rows 2o, 2o+1; every wave writes the 30 accumulators it does not own (slot [owner][source][10 KiB],
-    // 120 KiB), one barrier, and every wave sums its own 10 in ascending source order and stores them.  (Taking
-    // turns on one 40-KiB buffer -- wave 0 writes, 1..3 add -- was 21 % of a workgroup's life: tools/convdet_timing.py.)
-    constexpr int MO = MT / 4;                      // rows per owner
-    constexpr int SLOT = MO * NTW * 1024;           // bytes of one (owner, source) slot
-    const int wu = __builtin_amdgcn_readfirstlane(wave);
-    __syncthreads();  // all waves are done reading the input tile (the buffer is reused)
-    auto slot_of = [&](int owner, int src) { return lds + ((owner * 3 + (src < owner ? src : src - 1)) * SLOT) + lane * 16; };
-    auto scatter = [&](auto oc) {   // this wave's partials of owner oc's rows
-      constexpr int o = decltype(oc)::value;
-      if (wu == o) return;
-      unsigned char* p = slot_of(o, wu);
-#pragma unroll
-      for (int mm = 0; mm < MO; ++mm)
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) *reinterpret_cast<f32x4*>(p + (mm * NTW + t) * 1024) = acc[o * MO + mm][t];
-    };
-    scatter(std::integral_constant<int, 0>{});
-    scatter(std::integral_constant<int, 1>{});
-    scatter(std::integral_constant<int, 2>{});
-    scatter(std::integral_constant<int, 3>{});
-    __syncthreads();
-    auto gather = [&](auto oc) {
-      constexpr int o = decltype(oc)::value;
-      if (wu != o || ox >= a.c.W) return;
-#pragma unroll
-      for (int mm = 0; mm < MO; ++mm) {
-        const int oy = oy0 + o * MO + mm;
-        if (oy >= a.c.H) break;
-        T* dst = y + (((size_t)n * a.c.H + oy) * a.c.W + ox) * a.c.y_cstride + a.c.y_coffset + cb;
-        f32x4 v[NTW];
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-          f32x4 s = o == 0 ? acc[o * MO + mm][t] : *reinterpret_cast<const f32x4*>(slot_of(o, 0) + (mm * NTW + t) * 1024);
-#pragma unroll
-          for (int src = 1; src < 4; ++src)
-            s += src == o ? acc[o * MO + mm][t] : *reinterpret_cast<const f32x4*>(slot_of(o, src) + (mm * NTW + t) * 1024);
-          v[t] = s + bias[t];
-          if (a.c.relu) {
-            v[t][0] = fmaxf(v[t][0], 0.f); v[t][1] = fmaxf(v[t][1], 0.f);
-            v[t][2] = fmaxf(v[t][2], 0.f); v[t][3] = fmaxf(v[t][3], 0.f);
-          }
-        }
-        store_couts<T, NTW>(dst, v, nt_valid);
-      }
-    };
-    gather(std::integral_constant<int, 0>{});
-    gather(std::integral_constant<int, 1>{});
-    gather(std::integral_constant<int, 2>{});
-    gather(std::integral_constant<int, 3>{});
-    CT_MARK(6);
-#ifdef SQDET_FIRE_TIMING
-    if (lane == 0 && blockIdx.x * 4 + wave < 2048)
-      for (int k = 0; k < 8; ++k) g_cd_timing[(blockIdx.x * 4 + wave) * 8 + k] = ct_acc[k];
-#endif
-    return;
-  }
   if (!active) return;
 
   if (ox < a.c.W) {
@@ -405,19 +222,19 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
   }
 }
 
-template <typename T, int MT, int NTW, bool SPLITK>
+template <typename T, int MT, int NTW>
 static void launch_tile(const TileArgs& a, int grid_y, size_t lds, hipStream_t st) {
   static bool big_lds_ok = false;   // > 64 KiB of dynamic LDS has to be allowed once per kernel
   if (lds > 65536 && !big_lds_ok) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_tile<T, MT, NTW, SPLITK>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_tile<T, MT, NTW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     big_lds_ok = true;
   }
   const dim3 grid((unsigned)((a.c.N * a.tiles_x * a.tiles_y + 7) / 8 * 8), (unsigned)grid_y);
-  hipLaunchKernelGGL((conv3x3_tile<T, MT, NTW, SPLITK>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_tile<T, MT, NTW>), grid, dim3(256), lds, st, a);
 }
 
-// the split-K (ConvDet) instantiations live in convdet.hip: that file is compiled with the accumulators in AGPRs
-int convdet_tile_launch(const TileArgs& a, size_t lds, int dtype, hipStream_t st);
+// the split-K (ConvDet) kernel lives in convdet.hip: that file is compiled with the accumulators in AGPRs
+int convdet_tile_launch(const TileArgs& a, int dtype, hipStream_t st);
 
 }  // namespace sqdet

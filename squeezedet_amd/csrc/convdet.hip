@@ -1,17 +1,325 @@
-// The split-K form of conv3x3_tile (conv3x3_tile.h) = the ConvDet head (3x3 / SAME, 768 -> 72 couts; reference
-// src/nets/squeezeDet.py:76-79, src/nn_skeleton.py:471-563), in a translation unit of its own: it is the one kernel here
-// that needs more than 256 registers per lane (160 accumulators + three weight sets + two B sets + the next stage's
-// input).  With the accumulators in VGPRs (-amdgpu-mfma-vgpr-form=1, the build's choice for every other MFMA kernel) the
-// compiler parks 36 values in AGPRs and moves them back and forth inside the tap loop -- 143 v_accvgpr_* + 29 extra s_nop
-// per 360 MFMAs.  Compiled with hipcc's default form the accumulators live in AGPRs, the 256 VGPRs hold everything else,
-// and the loop has no register moves at all (conv12 at batch 32: 70.3 -> 69.1 us, at batch 1: 27.5 -> 25.3 us).
+// The ConvDet head (3x3 / SAME, 768 -> 72 couts = 5 cout tiles, K = 6912; reference src/nets/squeezeDet.py:76-79,
+// src/nn_skeleton.py:471-563): conv3x3_tile's 8 x 16 output tile and LDS layout (conv3x3_tile.h) with K split over the
+// four waves, as a PERSISTENT kernel, in a translation unit of its own.
+//
+//   * Every wave owns all 5 cout tiles (40 accumulators) and a quarter of K: the input is staged in stages of 4 K-chunks
+//     (46 KB), wave w walks chunk 4*stage + w, 9 taps each -- one 5-KiB weight step per 40 MFMAs, every weight byte used
+//     once per workgroup, so each step's fragments come from L2.  The 9 taps are unrolled over THREE register sets named
+//     statically (step s uses set s % 3; 9 % 3 == 0, so the names line up across the stage loop and nothing is ever
+//     copied), two steps are in flight, and the first two of the next stage are issued before this stage ends.
+//     (requires nchunk % 4 == 0: every wave has a chunk in every stage)
+//   * That is ~230 VGPRs beside the 160 accumulators: one workgroup per CU (one wave per SIMD).  This file is compiled
+//     with hipcc's default register form -- accumulators in AGPRs, the 256 VGPRs for everything else; with
+//     -amdgpu-mfma-vgpr-form=1 (the build's choice for every other MFMA kernel) the compiler parks 36 values in AGPRs and
+//     moves them back and forth inside the tap loop: 143 v_accvgpr_* + 29 extra s_nop per 360 MFMAs (conv12 at batch 32:
+//     70.3 us against 69.1, at batch 1: 27.5 against 25.3).
+//   * Nobody else hides this workgroup's input staging, so the NEXT stage's 46 KB are fetched into registers (12 x 16 B
+//     per thread, raw buffer loads: out-of-image offsets have bit 31 set and return the zero padding) while the current
+//     stage computes -- two pieces per tap over taps 0..5, not one burst behind the barrier: the CU's L1 already moves
+//     20 KB of weight fragments per tap (~60 % of its fill rate together with the input), and a 12-deep burst from all
+//     four waves stalls the weight stream queued behind it (69 -> 66 us) -- and only the LDS stores sit between the two
+//     barriers of a stage hand-over.
+//   * tools/convdet_timing.py (s_memtime per segment): the tap loop is 63 % of a tile's time, the cold start (address
+//     arithmetic, first 46 KB from HBM, first weights) 14 %, the stage hand-overs 12 %, the reduction 11 %; the SQ counters
+//     (SQ_VALU_MFMA_BUSY_CYCLES = 16 cycles x every MFMA, against GRBM_GUI_ACTIVE) put the matrix pipe at 41 % of the
+//     kernel, i.e. ~65-70 % inside the tap loop (s_memtime ticks slower than the shader clock).  A float16 workgroup
+//     is therefore persistent (grid = one per CU, XCD-banded tile order): the last stage of a tile prefetches the first
+//     stage of the workgroup's NEXT tile (and its first two weight steps), which stays in registers across the reduction
+//     (same box, batch 32: 63.4 -> 61.4 us; one tile per workgroup, batch 1: 24.0 -> 24.6 us).  Register pressure decides
+//     everything here: any value that lives across the tap loop beside the 228 VGPRs it needs is spilled to scratch, and
+//     a spill in the prologue or the reduction costs 1-3 us per tile (measured: +11 us at batch 32 with 16 spilled
+//     registers) -- the staging offsets are a per-stage scalar base + 12 per-thread constants + one validity bit mask per
+//     tile, the bias is loaded per tile in the reduction, and hoisting out of the tile loop is blocked where it would
+//     keep 64-bit addresses alive.  float32 (5x the MFMA time per tile, same staging) keeps one tile per workgroup.
+//   * The 4 K-partials are summed by a reduce-scatter through LDS (wave o owns tile rows 2o, 2o+1; fixed order
+//     ((w0+w1)+w2)+w3): results are bitwise those of any other split of the same K order.
+// Tried and dropped (all bitwise-equal): wave-private double-buffered staging without barriers (64-byte line halves per
+// wave: twice the L1 requests, 63.5 us against 62), cooperative double buffering with one barrier per stage and the LDS
+// stores under taps 6..8 (62.0 us against 62.5 at batch 32, slower at batch 1 and 8), weights three steps ahead around a
+// one-tap input burst with a single rolling B set (67.6 us).  Reading the same bytes as [stage][pixel][256 B] planes
+// instead of NHWC rows: -1.2 us (not worth a private layout).  Without any input loads the kernel takes 55 us, with the
+// input read from a 4-KB region 57 us: what remains is the CU's L1 traffic (20 KB of weight fragments per tap + 46 KB of
+// input per stage = ~60 % of its fill rate) under an HBM-latency input stream.  Weights three steps ahead in the same three
+// register sets (MFMAs fragment-major, a fragment's registers reloaded as soon as its 8 MFMAs are issued): 67.4 us against
+// 61.2 on the same box.  float32: issuing the four K = 4 MFMAs of a
+// fragment pair kk-outermost (independent accumulators back to back) is 8 % SLOWER (551 us against 510).
 #include "conv3x3_tile.h"
 
 namespace sqdet {
 
-int convdet_tile_launch(const TileArgs& a, size_t lds, int dtype, hipStream_t st) {
-  if (dtype == SQDET_F16) launch_tile<f16, 8, 5, true>(a, 1, lds, st);
-  else launch_tile<float, 8, 5, true>(a, 1, lds, st);
+// -DSQDET_FIRE_TIMING (experiments only): per-wave s_memtime totals of the kernel's segments (tools/convdet_timing.py)
+#ifdef SQDET_FIRE_TIMING
+__device__ unsigned long long g_cd_timing[2048 * 8];
+#define CT_MARK(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ct_acc[k] += now_ - ct_last; ct_last = now_; } while (0)
+#else
+#define CT_MARK(k) do {} while (0)
+#endif
+
+constexpr int CD_SLOT = 2 * 5 * 1024;                 // reduce-scatter: one (owner, source) slot = 2 rows x 5 tiles
+constexpr int CD_LDS = 12 * CD_SLOT;                  // 122880 B (> the 46080 B of a staged input stage)
+
+// PERS = false (float32: the persistent form does not fit the register file without spilling inside the tap loop): one tile
+// per workgroup, nothing is prefetched across tiles
+template <typename T, bool PERS>
+__global__ __launch_bounds__(256) void convdet_kernel(TileArgs a, int ntiles, int per_xcd) {
+  constexpr int MT = 8, NTW = 5;
+  constexpr int NSV = (HP * 16 + 255) / 256;   // 16-byte pieces per thread per stage = 12 (the last one partial)
+  static_assert(NSV == 12, "two pieces per tap over six taps");
+#ifdef SQDET_FIRE_TIMING
+  unsigned long long ct_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ct_last = __builtin_amdgcn_s_memtime();
+#endif
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int j = lane & 15, g = lane >> 4;
+
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (own L2 each); every XCD walks a contiguous band of tiles, so
+  // the halos shared by neighbouring tiles are fetched into ONE L2.  Slot s of an XCD takes tiles s, s + nslot, ...
+  const int xcd = (int)(blockIdx.x & 7), nslot = (int)(gridDim.x >> 3);
+  int tl = (int)(blockIdx.x >> 3);
+  auto tile_ok = [&](int t) { return t < per_xcd && xcd * per_xcd + t < ntiles; };
+  if (!tile_ok(tl)) return;
+  auto decode = [&](int t, int& n, int& oy0, int& ox0) {
+    int b = xcd * per_xcd + t;
+    const int tx = b % a.tiles_x; b /= a.tiles_x;
+    const int ty = b % a.tiles_y;
+    n = b / a.tiles_y; oy0 = ty * TROWS; ox0 = tx * TCOLS;
+  };
+  const int nstages = a.nchunk >> 2;
+
+  f32x4 acc[MT][NTW];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();
+
+  // ---- input staging: thread = (16-byte piece sq of the stage's 16, halo pixels sP0 + 16u)
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.c.x), 0, a.x_bytes, 0x00020000);
+  const int sq = threadIdx.x & 15, sP0 = threadIdx.x >> 4;
+  // byte offset of piece u (halo pixel P = sP0 + 16u -> halo row r, column cc) = a per-(tile, stage) scalar base + rel[u];
+  // which of a thread's 12 pieces lie inside the image is one bit mask per tile (bit 31 of a buffer offset = zeros)
+  const int row_bytes = a.pieces * 16;
+  unsigned rel[NSV];
+#pragma unroll
+  for (int u = 0; u < NSV; ++u) {
+    const int P = sP0 + 16 * u;
+    const int r = P / (TCOLS + 2), cc = P - r * (TCOLS + 2);
+    rel[u] = (unsigned)((r * a.c.W + cc) * row_bytes + sq * 16);
+  }
+  auto tile_base = [&](int n, int oy0, int ox0) { return (unsigned)(((n * a.c.H + oy0 - 1) * a.c.W + ox0 - 1) * row_bytes); };
+  auto tile_mask = [&](int oy0, int ox0, bool valid) {
+    unsigned m = 0;
+    int p0 = sP0;
+    asm volatile("" : "+v"(p0));   // r, cc are recomputed here, not kept in 24 registers across the stage loop
+#pragma unroll
+    for (int u = 0; u < NSV; ++u) {
+      const int P = p0 + 16 * u;
+      const int r = (int)(__umul24((unsigned)P, 57u) >> 10);   // P / 18 for P < 192
+      const int cc = P - r * (TCOLS + 2);
+      const int ok = (int)(u < NSV - 1 || P < HP) & (int)((unsigned)(oy0 - 1 + r) < (unsigned)a.c.H) &
+                     (int)((unsigned)(ox0 - 1 + cc) < (unsigned)a.c.W);
+      m |= (unsigned)ok << u;
+    }
+    return valid ? m : 0u;
+  };
+  auto piece_off = [&](int u, unsigned base, unsigned mask) { return (mask >> u) & 1u ? base + rel[u] : 0x80000000u; };
+  // ((P + 16u) >> 1) & 3 == (P >> 1) & 3: the XOR slot is the same for all of a thread's pixels
+  unsigned char* const sdst = lds + (sq >> 2) * CHUNK_BYTES + sP0 * 64 + (((sq & 3) ^ ((sP0 >> 1) & 3)) << 4);
+  i32x4 sv[NSV];
+
+  // ---- weights: fragment t of step (tap t9, chunk 4*stage + wave)
+  const i32x4* wbase = reinterpret_cast<const i32x4*>(a.c.wp) + lane;
+  auto wstep = [&](int stage, int t9) { return wbase + (size_t)(t9 * a.nchunk + stage * 4 + wave) * (NTW * 64); };
+  i32x4 wf[3][NTW];
+
+  int cn, coy0, cox0;   // the tile being computed
+  decode(tl, cn, coy0, cox0);
+  unsigned mask_cur = tile_mask(coy0, cox0, true);
+  {
+    const unsigned base = tile_base(cn, coy0, cox0);
+#pragma unroll
+    for (int u = 0; u < NSV; ++u) sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, piece_off(u, base, mask_cur), 0, 0);
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const i32x4* wp = wstep(0, p);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) wf[p][t] = wp[t * 64];
+  }
+
+  T* const y = reinterpret_cast<T*>(a.c.y);
+  const int cb0 = (lane >> 4) * 4 * NTW;   // epilogue: lane = pixel (row m, col j); couts g*20 + t*4 .. +4
+
+  bool first = true;
+  int nn = 0, noy0 = 0, nox0 = 0;   // the workgroup's next tile
+  bool has_next = PERS && tile_ok(tl + nslot);
+  if (has_next) decode(tl + nslot, nn, noy0, nox0);
+  unsigned mask_next = PERS ? tile_mask(noy0, nox0, has_next) : 0u;
+  for (;;) {
+#pragma unroll 1
+    for (int stage = 0; stage < nstages; ++stage) {
+      CT_MARK(0);
+      if (!first) __syncthreads();   // every wave is done reading the previous stage (or the previous tile's reduction slots)
+      first = false;
+      CT_MARK(1);
+#pragma unroll
+      for (int u = 0; u < NSV; ++u)
+        if (u < NSV - 1 || sP0 + 16 * u < HP) *reinterpret_cast<i32x4*>(sdst + u * 1024) = sv[u];   // sP0 <= 15
+      CT_MARK(2);
+      __syncthreads();
+      CT_MARK(3);
+      // what taps 0..5 prefetch: the next stage of this tile, or the first stage of the next tile (or nothing)
+      const bool last = stage == nstages - 1;
+      const unsigned pbase = last ? tile_base(nn, noy0, nox0) : tile_base(cn, coy0, cox0) + (unsigned)(stage + 1) * 256u;
+      const unsigned pmask = last ? mask_next : mask_cur;
+      const int nstage = last ? 0 : stage + 1;               // whose first two weight steps follow tap 8
+      const unsigned char* lchunk = lds + wave * CHUNK_BYTES;
+      // B fragments of tap t9 + 1 are read from LDS under the MFMAs of tap t9 (two statically named sets)
+      i32x4 bfs[2][MT];
+      auto bread = [&](int t9, i32x4 (&bf)[MT]) {
+        const int dy = t9 / 3, dx = t9 - dy * 3;
+        const int Pb = dy * (TCOLS + 2) + j + dx;
+        const int h0 = Pb >> 1;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          bf[m] = *reinterpret_cast<const i32x4*>(lchunk + (Pb + (TCOLS + 2) * m) * 64 + ((g ^ ((h0 + m) & 3)) << 4));
+      };
+      bread(0, bfs[0]);
+      CT_MARK(4);
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        __builtin_amdgcn_sched_barrier(0);   // steps stay in order: no later tap's reads hoisted, no load sunk
+        {
+          const i32x4* wp = t9 + 2 < 9 ? wstep(stage, t9 + 2) : wstep(nstage, t9 + 2 - 9);
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) wf[(t9 + 2) % 3][t] = wp[t * 64];
+        }
+        if (t9 < 6) {
+#pragma unroll
+          for (int u = 2 * t9; u < 2 * t9 + 2; ++u) sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, piece_off(u, pbase, pmask), 0, 0);
+        }
+        if (t9 + 1 < 9) bread(t9 + 1, bfs[(t9 + 1) & 1]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], wf[t9 % 3][t], bfs[t9 & 1][m]);
+        // issue order inside the step: one memory instruction, then two or three MFMAs (the issues + their address
+        // arithmetic cost ~200 cycles per step when they all sat ahead of the 40 MFMAs)
+        const bool spread = t9 < 6;   // two more VMEM issues in this step
+#pragma unroll
+        for (int k = 0; k < NTW + (spread ? 2 : 0); ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // MFMA
+        }
+#pragma unroll
+        for (int k = 0; k < (t9 + 1 < 9 ? MT : 0); ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+          if (spread) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        }
+      }
+      CT_MARK(5);
+    }
+
+    // ---- deterministic sum of the 4 K-partial accumulators, ((w0+w1)+w2)+w3, as a reduce-scatter through LDS: wave o
+    // owns tile rows 2o, 2o+1; every wave writes the 30 accumulators it does not own (slot [owner][source][10 KiB],
+    // 120 KiB), one barrier, and every wave sums its own 10 in ascending source order and stores them.  (Taking
+    // turns on one 40-KiB buffer -- wave 0 writes, 1..3 add -- was 21 % of a workgroup's life.)
+    constexpr int MO = MT / 4;   // rows per owner
+    const int ox = cox0 + j;
+    __syncthreads();  // all waves are done reading the input tile (the buffer is reused)
+    int l16 = lane * 16;
+    asm volatile("" : "+v"(l16));   // the slot addresses are recomputed per tile: hoisted out of the tile loop they were spilled
+    auto slot_of = [&](int owner, int src) { return lds + (owner * 3 + (src < owner ? src : src - 1)) * CD_SLOT + l16; };
+    auto scatter = [&](auto oc) {   // this wave's partials of owner oc's rows
+      constexpr int o = decltype(oc)::value;
+      if (wave == o) return;
+      unsigned char* p = slot_of(o, wave);
+#pragma unroll
+      for (int mm = 0; mm < MO; ++mm)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) *reinterpret_cast<f32x4*>(p + (mm * NTW + t) * 1024) = acc[o * MO + mm][t];
+    };
+    scatter(std::integral_constant<int, 0>{});
+    scatter(std::integral_constant<int, 1>{});
+    scatter(std::integral_constant<int, 2>{});
+    scatter(std::integral_constant<int, 3>{});
+    // the tile after the next one: its mask is computed here, where the wave would only wait for the barrier
+    const int tl_nn = tl + 2 * nslot;
+    const bool has_nn = PERS && tile_ok(tl_nn);
+    int n2 = 0, n2oy0 = 0, n2ox0 = 0;
+    if (has_nn) decode(tl_nn, n2, n2oy0, n2ox0);
+    const unsigned mask_nn = PERS ? tile_mask(n2oy0, n2ox0, has_nn) : 0u;
+    f32x4 bias[NTW];   // loaded per tile: 20 registers that must not live across the tap loop
+    int nt_valid = 0;  // whole 4-cout pieces beyond Cout are skipped
+    int cb = cb0;
+    asm volatile("" : "+v"(cb));   // nothing derived from it (bias / output pointers) is hoisted out of the tile loop
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const bool ok = cb + t * 4 < a.c.Cout;
+      bias[t] = ok ? *reinterpret_cast<const f32x4*>(a.c.bias + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      nt_valid += ok ? 1 : 0;
+    }
+    __syncthreads();
+    auto gather = [&](auto oc) {
+      constexpr int o = decltype(oc)::value;
+      if (wave != o || ox >= a.c.W) return;
+#pragma unroll
+      for (int mm = 0; mm < MO; ++mm) {
+        const int oy = coy0 + o * MO + mm;
+        if (oy >= a.c.H) break;
+        T* dst = y + (((size_t)cn * a.c.H + oy) * a.c.W + ox) * a.c.y_cstride + a.c.y_coffset + cb;
+        f32x4 v[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          f32x4 s = o == 0 ? acc[o * MO + mm][t] : *reinterpret_cast<const f32x4*>(slot_of(o, 0) + (mm * NTW + t) * 1024);
+#pragma unroll
+          for (int src = 1; src < 4; ++src)
+            s += src == o ? acc[o * MO + mm][t] : *reinterpret_cast<const f32x4*>(slot_of(o, src) + (mm * NTW + t) * 1024);
+          v[t] = s + bias[t];
+          if (a.c.relu) {
+            v[t][0] = fmaxf(v[t][0], 0.f); v[t][1] = fmaxf(v[t][1], 0.f);
+            v[t][2] = fmaxf(v[t][2], 0.f); v[t][3] = fmaxf(v[t][3], 0.f);
+          }
+        }
+        store_couts<T, NTW>(dst, v, nt_valid);
+      }
+    };
+    gather(std::integral_constant<int, 0>{});
+    gather(std::integral_constant<int, 1>{});
+    gather(std::integral_constant<int, 2>{});
+    gather(std::integral_constant<int, 3>{});
+    CT_MARK(6);
+    if (!PERS || !has_next) break;
+    tl += nslot; cn = nn; coy0 = noy0; cox0 = nox0; mask_cur = mask_next;
+    has_next = has_nn; nn = n2; noy0 = n2oy0; nox0 = n2ox0; mask_next = mask_nn;
+    zero_acc();
+  }
+#ifdef SQDET_FIRE_TIMING
+  if (lane == 0 && blockIdx.x * 4 + wave < 2048)
+    for (int k = 0; k < 8; ++k) g_cd_timing[(blockIdx.x * 4 + wave) * 8 + k] = ct_acc[k];
+#endif
+}
+
+template <typename T, bool PERS>
+static void convdet_launch(const TileArgs& a, hipStream_t st) {
+  static bool lds_ok = false;   // > 64 KiB of dynamic LDS has to be allowed once per kernel
+  if (!lds_ok) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convdet_kernel<T, PERS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    lds_ok = true;
+  }
+  const int ntiles = a.c.N * a.tiles_x * a.tiles_y;
+  const int per_xcd = (ntiles + 7) / 8;
+  const int slots = (!PERS || per_xcd < 32) ? per_xcd : 32;   // persistent: one workgroup per CU, 32 CUs per XCD
+  hipLaunchKernelGGL((convdet_kernel<T, PERS>), dim3((unsigned)(slots * 8)), dim3(256), CD_LDS, st, a, ntiles, per_xcd);
+}
+
+int convdet_tile_launch(const TileArgs& a, int dtype, hipStream_t st) {
+  if (dtype == SQDET_F16) convdet_launch<f16, true>(a, st);
+  else convdet_launch<float, false>(a, st);
   return SQDET_OK;
 }
 

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
-"""Where a ConvDet (split-K conv3x3_tile) workgroup's time goes (experiment): needs libsqdet_hip.so with conv3x3.hip
-compiled -DSQDET_FIRE_TIMING.  conv12 of SqueezeDet (768 -> 72, 24x78) at the batch given on the command line
-(default 32 and 1); s_memtime ticks (100 MHz) per wave and segment (the first 512 workgroups)."""
+"""Where a ConvDet (convdet_kernel, csrc/convdet.hip) workgroup's time goes (experiment): needs libsqdet_hip.so with
+convdet.hip compiled -DSQDET_FIRE_TIMING (without -amdgpu-mfma-vgpr-form, as build.py does).  conv12 of SqueezeDet
+(768 -> 72, 24x78) at the batch given on the command line (default 32 and 1); s_memtime ticks per wave and segment (the
+first 512 workgroups; a persistent workgroup's totals cover all its tiles).  A tick is NOT a shader cycle here: 112 k
+ticks per 80 us of kernel = 1.4 per ns while GRBM_GUI_ACTIVE counts 2.2-2.3 per ns -- read the segments as fractions."""
 import ctypes as C
 import os
 import sys
@@ -34,7 +36,7 @@ for batch in [int(v) for v in sys.argv[1:]] or [32, 1]:
     assert lib.sqdet_debug_convdet_timing(buf, n) == 0
     t = np.array(buf[:], dtype=np.float64).reshape(2048, 8)[: min(2048, batch * 15 * 4)]
     t = t[t.sum(1) > 0]
-    print("batch %d: conv12 %.1f us, %d waves recorded; s_memtime ticks (10 ns) per wave:" % (batch, st.elapsed_time(en) * 1e3, len(t)))
+    print("batch %d: conv12 %.1f us, %d waves recorded; s_memtime ticks per wave:" % (batch, st.elapsed_time(en) * 1e3, len(t)))
     for k, name in enumerate(NAMES):
         print("  %-34s %8.0f   (min %6.0f max %6.0f)" % (name, t[:, k].mean(), t[:, k].min(), t[:, k].max()))
     print("  %-34s %8.0f" % ("total", t.sum(1).mean()))
