@@ -213,6 +213,19 @@ def spin_up(step, ms):
         torch.cuda.synchronize()
 
 
+def launch_roofline(flops, nbytes, ms, dtype):
+    """Roofline entry of one launch: MFMA-bound when its algorithmic intensity exceeds the ridge (fp16 only: the peak the
+    guide gives is the dense fp16 one), else HBM-bound; achieved = algorithmic flops (bytes) / measured duration."""
+    intensity = flops / nbytes if nbytes else 0.0
+    ridge = MFMA_F16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    if dtype == "fp16" and intensity > ridge:
+        roof = {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s"}
+    else:
+        roof = {"bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+    return roof
+
+
 def run_infer(args, rank, local_rank, world, device):
     model, mc, xs = build_infer_model(args, local_rank)
     plan = model._native_plan(args.batch)
@@ -265,13 +278,7 @@ def run_infer(args, rank, local_rank, world, device):
     value = aggregate_throughput(args.batch, args.steps, world, elapsed)
     name, flops, nbytes = layers[dom]
     avg_ms = float(np.mean(probe_ms)) if probe_ms else float(ms0[dom])
-    intensity = flops / nbytes if nbytes else 0.0
-    ridge = MFMA_F16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
-    if args.dtype == "fp16" and intensity > ridge:
-        roof = {"bound": "mfma", "achieved": round(flops / (avg_ms * 1e-3) / 1e12, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s"}
-    else:
-        roof = {"bound": "hbm", "achieved": round(nbytes / (avg_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+    roof = launch_roofline(flops, nbytes, avg_ms, args.dtype)
     # HBM bytes per launch from the PMC counters: not measurable inside this process; taken from the committed
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command ON THIS BUILD (fingerprint-checked), else null
     tr = pmc_traffic(args.config, name) if (args.batch, args.height, args.width) == tuple(CONFIGS[args.config][k] for k in ("batch", "height", "width")) else None
@@ -282,6 +289,11 @@ def run_infer(args, rank, local_rank, world, device):
     roof["avg_launch_ms"] = round(avg_ms, 5)
     roof["algorithmic_bytes_per_launch"] = nbytes
     roof["algorithmic_flops_per_launch"] = flops
+    # the next largest launches (several are within a microsecond of each other, so which one is "dominant" can change from
+    # run to run): durations from the untimed survey = one forward at a time, nothing else on the chip
+    order = [int(k) for k in np.argsort(ms0)[::-1] if int(k) != dom][:3]
+    roof["next_largest_launches"] = [dict(launch_roofline(layers[k][1], layers[k][2], float(ms0[k]), args.dtype), kernel=layers[k][0],
+                                          survey_launch_ms=round(float(ms0[k]), 5)) for k in order]
     table = [{"layer": n, "ms": round(m, 5), "GB/s": round(b / (m * 1e-3) / 1e9, 1) if m > 0 else None,
               "TFLOP/s": round(f / (m * 1e-3) / 1e12, 2) if m > 0 else None, "bytes": b, "flops": f}
              for (n, f, b), m in zip(layers, ms0)]
