@@ -135,6 +135,35 @@ def test_conv2d_parity(case, dtype, conv_algo):
         np.testing.assert_allclose(got, ref, rtol=2 ** -9, atol=1e-3)
 
 
+@pytest.mark.parametrize("batch", [20, 52])
+def test_convdet_persistent_workgroups_vs_single_tile_launch(batch):
+    """The fp16 ConvDet kernel is persistent above 256 tiles (csrc/convdet.hip): a workgroup walks 2-4 tiles and prefetches
+    the next tile's first stage across the reduction.  Size-independent property: with the SAME image in every batch slot,
+    every slot's output must be bitwise the batch-1 result (15 tiles, one per workgroup, checked against the oracle by
+    test_conv2d_parity[convdet_full_24x78]); a second run with distinct images must match the generic kernels."""
+    ops = _ops()
+    rs = np.random.RandomState(77)
+    w = torch.from_numpy((rs.randn(3, 3, 768, 72) * (2.0 / (9 * 768)) ** 0.5).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(rs.uniform(-0.5, 0.5, 72).astype(np.float32)).to(DEV)
+    packed = ops.pack_conv_weights(w, torch.float16)
+    img = torch.from_numpy(rs.randn(1, 24, 78, 768).astype(np.float32)).to(DEV, torch.float16)
+    y1 = ops.conv2d_nhwc(img, packed, b, 1, "SAME", False)
+    yb = ops.conv2d_nhwc(img.expand(batch, -1, -1, -1).contiguous(), packed, b, 1, "SAME", False)
+    torch.cuda.synchronize()
+    for n in range(batch):
+        assert torch.equal(yb[n], y1[0]), "slot %d differs from the batch-1 result" % n
+    x = torch.from_numpy(rs.randn(batch, 24, 78, 768).astype(np.float32)).to(DEV, torch.float16)
+    y = ops.conv2d_nhwc(x, packed, b, 1, "SAME", False)
+    ops.set_option("conv_algo", 1)
+    try:
+        yg = ops.conv2d_nhwc(x, packed, b, 1, "SAME", False)
+    finally:
+        ops.set_option("conv_algo", 0)
+    torch.cuda.synchronize()
+    # both accumulate in float32 (different K order) and round once to float16
+    np.testing.assert_allclose(y.float().cpu().numpy(), yg.float().cpu().numpy(), rtol=2 ** -9, atol=2e-3)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
 def test_conv2d_concat_offset_and_fire(dtype):
     """expand1x1 / expand3x3 write the two halves of one concat tensor (nets/squeezeDet.py:106);
