@@ -231,3 +231,15 @@ def test_loss_scale_bookkeeping_state_machine():
     with pytest.raises(FloatingPointError):
         tr._account(True)
     assert tr.skipped_steps == 4 and tr.global_step == 9
+
+
+def test_bench_launch_roofline_picks_the_bound_by_intensity():
+    """bench.py's roofline entry of one launch: MFMA-bound above the ridge (2.5 PF/s / 8 TB/s = 312 flop/B) in float16,
+    else HBM-bound; achieved = algorithmic work / measured duration."""
+    import bench
+    r = bench.launch_roofline(59.6e9, 102e6, 0.0632, "fp16")          # ConvDet: 584 flop/B
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["achieved"] - 59.6e9 / 0.0632e-3 / 1e12) < 1e-2
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    r = bench.launch_roofline(14.8e9, 119e6, 0.0735, "fp16")          # the stem launch: 124 flop/B
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["achieved"] - 119e6 / 0.0735e-3 / 1e9) < 1e-1
+    assert bench.launch_roofline(59.6e9, 102e6, 0.0632, "fp32")["bound"] == "hbm"   # the dense peak quoted is float16's
