@@ -13,7 +13,13 @@
   sqdet_train_fp32   configs[2]: SqueezeDet float32 training, batch 20 per GPU, 1248x384: GPU label build + forward
                      (dropout on) + loss + backward + flat-bucket gradient all-reduce (RCCL) + clipped Momentum update.
   res50_train_fp16   configs[4]: ResNet50+ConvDet mixed-precision (float16 activations) training, batch 8 per GPU.
+  sqdet_infer_384    configs[1] at the reference's TRUE input size (kitti_squeezeDet_config.py:13-14: 1248x384), batch 32.
+  sqdet_sample_b1    configs[0]: the reference's data/sample.png (tests/golden/sample.png) -> sqdet_preprocess_bgr (resize to
+                     1248x384, BGR mean subtraction: demo.py:186-190) -> the same step at batch 1; also reports the
+                     synchronous per-image latency in float16 and float32 and the CPU oracle's latency beside them.
 Inference shards by image (weak scaling, no data-path collective); training all-reduces one float32 gradient bucket.
+--gpus N > 1 without a torchrun environment re-launches this script under torch.distributed.run with N local ranks.
+--dry-run: no kernels, no GPU: the launcher, rendezvous (gloo), barrier and max-over-ranks timing only (CI on a CPU box).
 Every step reads a DIFFERENT input batch from a rotation larger than the 256 MiB Infinity Cache.
 Rank 0 prints ONE JSON line.
 """
@@ -38,6 +44,10 @@ MALL_BYTES = 256 << 20
 CONFIGS = {
     "sqdet_infer": dict(kind="infer", arch="squeezeDet", batch=32, height=375, width=1242, dtype="fp16",
                         metric="images/sec SqueezeDet 1242x375 inference", steps=200, warmup=20),
+    "sqdet_infer_384": dict(kind="infer", arch="squeezeDet", batch=32, height=384, width=1248, dtype="fp16",
+                            metric="images/sec SqueezeDet 1248x384 inference", steps=200, warmup=20),
+    "sqdet_sample_b1": dict(kind="infer", arch="squeezeDet", batch=1, height=384, width=1248, dtype="fp16", sample=True,
+                            metric="images/sec SqueezeDet single sample.png (1242x375 -> 1248x384) inference, batch 1", steps=500, warmup=20),
     "sqdetplus_infer": dict(kind="infer", arch="squeezeDet+", batch=8, height=375, width=1242, dtype="fp16",
                             metric="images/sec SqueezeDet+ 1242x375 inference", steps=100, warmup=10),
     "sqdet_train_fp32": dict(kind="train", arch="squeezeDet", batch=20, height=384, width=1248, dtype="fp32",
@@ -67,9 +77,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-graph", action="store_true", help="training configs: issue the step from Python instead of replaying a hipGraph")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--layer-table", default="", help="write the per-launch table (json) here")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / timing reduction only: gloo on CPU, no kernels")
     a = ap.parse_args(argv)
     c = CONFIGS[a.config]
-    a.kind, a.arch, a.metric = c["kind"], c["arch"], c["metric"]
+    a.kind, a.arch, a.metric, a.sample = c["kind"], c["arch"], c["metric"], bool(c.get("sample"))
     a.steps = a.steps or c["steps"]
     a.warmup = a.warmup if a.warmup >= 0 else c["warmup"]
     a.batch = a.batch or c["batch"]
@@ -110,6 +121,74 @@ def barrier(world, device):
 def aggregate_throughput(images_per_rank_step, steps, world, seconds_max):
     """value = the units ALL ranks processed / the max-over-ranks time."""
     return images_per_rank_step * steps * world / seconds_max
+
+
+def gpu_state(device_index=0):
+    """Clock / power / temperature of this rank's GPU right now (amdsmi; None where a field is unavailable): recorded
+    before and after the timed region so a slow box (round 2 saw one with every kernel 33 % slower) is identifiable from
+    the JSON line alone.  Costs ~1 ms, outside the timed region."""
+    out = {}
+    try:
+        import amdsmi
+        global _AMDSMI_READY
+        if not globals().get("_AMDSMI_READY"):
+            amdsmi.amdsmi_init()
+            _AMDSMI_READY = True
+        hs = amdsmi.amdsmi_get_processor_handles()
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or ""
+        phys = device_index
+        if vis:
+            try:
+                phys = int(vis.split(",")[device_index])
+            except (ValueError, IndexError):
+                phys = device_index
+        h = hs[min(phys, len(hs) - 1)]
+        try:
+            m = amdsmi.amdsmi_get_gpu_metrics_info(h)
+            for k_out, k_in in (("gfxclk_mhz", "current_gfxclk"), ("uclk_mhz", "current_uclk"), ("socclk_mhz", "current_socclk"),
+                                ("socket_power_w", "current_socket_power"), ("temp_hotspot_c", "temperature_hotspot"),
+                                ("temp_mem_c", "temperature_mem"), ("gfx_activity", "average_gfx_activity"),
+                                ("throttle_status", "throttle_status")):
+                v = m.get(k_in)
+                if isinstance(v, (list, tuple)):
+                    v = [x for x in v if isinstance(x, (int, float)) and 0 <= x < 65535][:8] or None
+                    if v and k_out.endswith("_mhz"):
+                        v = max(v)
+                out[k_out] = v if not (isinstance(v, str) and v == "N/A") else None
+        except Exception as e:  # noqa: BLE001 -- a monitoring read-out must never break the bench
+            out["metrics_error"] = repr(e)[:120]
+        for k_out, typ in (("sclk", "GFX"), ("mclk", "MEM")):
+            try:
+                c = amdsmi.amdsmi_get_clock_info(h, getattr(amdsmi.AmdSmiClkType, typ))
+                out[k_out + "_mhz"] = c.get("clk")
+                out[k_out + "_max_mhz"] = c.get("max_clk")
+            except Exception:  # noqa: BLE001
+                pass
+        try:
+            pw = amdsmi.amdsmi_get_power_info(h)
+            out["power_w"] = pw.get("current_socket_power", pw.get("average_socket_power"))
+            out["power_limit_w"] = pw.get("power_limit")
+        except Exception:  # noqa: BLE001
+            pass
+    except Exception as e:  # noqa: BLE001
+        out["error"] = "amdsmi unavailable: " + repr(e)[:120]
+    return out
+
+
+def rank_census(rank, local_rank, world, device):
+    """What the process group ACTUALLY is: world size as torch.distributed sees it and every rank's device -- a launcher
+    that silently ran fewer ranks (or two ranks on one GPU) shows up in the JSON line."""
+    mine = {"rank": rank, "local_rank": local_rank, "device": str(device), "pid": os.getpid()}
+    if device.type == "cuda":
+        pr = torch.cuda.get_device_properties(device)
+        mine.update(name=pr.name, cus=pr.multi_processor_count, uuid=str(getattr(pr, "uuid", "")),
+                    pci_bus_id=getattr(pr, "pci_bus_id", None))
+    if not _dist_on():
+        return 1, [mine]
+    import torch.distributed as dist
+    seen = [None] * dist.get_world_size()
+    dist.all_gather_object(seen, mine)
+    return dist.get_world_size(), seen
 
 
 def build_fingerprint():
@@ -166,35 +245,110 @@ def build_infer_model(args, device_index):
     model.load_params(synthetic.synthetic_params(model, seed=0))
     esz = 2 if args.dtype == "fp16" else 4
     nrot = rotation_count(args.batch * args.height * args.width * 3 * esz)
+    if args.sample:
+        # configs[0]: the reference's one input fixture through demo.py:186-190's preparation (cv2.imread's BGR uint8 ->
+        # resize to the network input -> BGR mean subtraction), done by sqdet_preprocess_bgr on the device; the rotation
+        # holds `nrot` resident COPIES of the prepared image at distinct addresses so that every step still reads HBM
+        x0 = sample_image_input(model, mc, tdt)
+        xs = [x0.clone() for _ in range(nrot)]
+        return model, mc, xs
     xs = [synthetic.synthetic_images(args.batch, args.height, args.width, seed=1000 * device_index + 100 + k).to(model.device, tdt).contiguous()
           for k in range(nrot)]
     return model, mc, xs
 
 
+SAMPLE_PNG = os.path.join(ROOT, "tests", "golden", "sample.png")     # = the reference's data/sample.png (1242x375 RGB)
+
+
+def sample_bgr_u8():
+    from PIL import Image
+    rgb = np.asarray(Image.open(SAMPLE_PNG).convert("RGB"))
+    return np.ascontiguousarray(rgb[:, :, ::-1])                      # what cv2.imread returns (demo.py:187)
+
+
+def sample_image_input(model, mc, tdt):
+    from squeezedet_amd import ops
+    bgr = torch.from_numpy(sample_bgr_u8()).to(model.device)
+    return ops.preprocess_bgr(bgr[None], mc.IMAGE_HEIGHT, mc.IMAGE_WIDTH, mc.BGR_MEANS, tdt).contiguous()
+
+
+def sync_latency_ms(model, x, iters=60):
+    """Per-image latency of the full step issued synchronously (forward + decode + filter + rows in pinned host memory,
+    device idle before and after): median over `iters`."""
+    ts = []
+    for i in range(iters + 5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.detect_filter_pipelined(x, to_host=True)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts[5:]))
+
+
+def cpu_thread_candidates():
+    n = os.cpu_count() or 8
+    c = sorted({t for t in (4, 8, 16, 32, 64, 128, n) if t <= n})
+    return c or [n]
+
+
 def cpu_baseline_infer(args, seconds):
     """The oracle (CPU restatement of the reference path: PyTorch-CPU fp32 convs with TF padding + NumPy
-    interpret_output + the restated filter_prediction) timed on this box's host cores on a bounded sample."""
+    interpret_output + the restated filter_prediction) timed on this box's host cores on a bounded sample.  The host's
+    BEST configuration is reported: a short sweep over torch.set_num_threads x images per call picks it (round 2 ran 128
+    threads at batch 4 and got HALF the images/s of 8 threads -- oneDNN oversubscription on small maps), then the rest
+    of the time budget measures it."""
     from oracle import sqdet_oracle as O
     if args.arch == "squeezeDet":
         mc = O.squeezeDet_config_for_input(args.height, args.width)
     else:
         mc = O.kitti_squeezeDetPlus_config()
     p32 = O.init_params(args.arch, seed=0, storage="fp32")
-    nb = 4
-    x = O.synthetic_images(nb, args.height, args.width, seed=7)
-    O.detect(args.arch, mc, p32, x[:1])  # warm-up
+    if args.sample:
+        from oracle import preproc_oracle as PO
+        x_all = torch.from_numpy(PO.preprocess_bgr(sample_bgr_u8(), mc.IMAGE_HEIGHT, mc.IMAGE_WIDTH, mc.BGR_MEANS)[None])
+        batches = [1]
+    else:
+        x_all = O.synthetic_images(4, args.height, args.width, seed=7)
+        batches = [1, 4]
+    prev_threads = torch.get_num_threads()
+    O.detect(args.arch, mc, p32, x_all[:1])  # warm-up
+    sweep, best = [], None
+    t_sweep = time.perf_counter()
+    for th in cpu_thread_candidates():
+        torch.set_num_threads(th)
+        for nb in batches:
+            x = x_all[:nb]
+            O.detect(args.arch, mc, p32, x)
+            t0 = time.perf_counter()
+            n = 0
+            while n < 2 * nb or time.perf_counter() - t0 < 0.4:
+                O.detect(args.arch, mc, p32, x)
+                n += nb
+            rate = n / (time.perf_counter() - t0)
+            sweep.append({"threads": th, "images_per_call": nb, "images_per_s": round(rate, 2)})
+            if best is None or rate > best[0]:
+                best = (rate, th, nb)
+        if time.perf_counter() - t_sweep > 0.6 * seconds:
+            break
+    _, th, nb = best
+    torch.set_num_threads(th)
+    x = x_all[:nb]
+    budget = max(2.0, seconds - (time.perf_counter() - t_sweep))
     t0 = time.perf_counter()
     n = 0
     while True:
         O.detect(args.arch, mc, p32, x)
         n += nb
-        if time.perf_counter() - t0 >= seconds:
+        if time.perf_counter() - t0 >= budget:
             break
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 3), "unit": "images/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": "%d synthetic %dx%d images (batches of %d), fp32: PyTorch-CPU convs with TF SAME padding + NumPy "
-                      "interpret_output + restated filter_prediction; host has %d logical cores; oneDNN is faster than "
-                      "TF-1.0 Eigen, so this over-estimates the reference's own CPU path" % (n, args.width, args.height, nb, os.cpu_count())}
+    torch.set_num_threads(prev_threads)
+    return {"value": round(n / dt, 3), "unit": "images/s", "cores": int(th), "kind": "port", "ms_per_image": round(dt / n * 1e3, 2),
+            "sample": "%d %s %dx%d images (%d per call) on the best of a (threads x images-per-call) sweep, fp32: PyTorch-CPU convs "
+                      "with TF SAME padding + NumPy interpret_output + restated filter_prediction; host has %d logical cores, one "
+                      "process; oneDNN is faster than TF-1.0 Eigen, so this over-estimates the reference's own CPU path"
+                      % (n, "copies of sample.png at" if args.sample else "synthetic", args.width, args.height, nb, os.cpu_count()),
+            "sweep": sweep}
 
 
 def spin_up(step, ms):
@@ -256,6 +410,7 @@ def run_infer(args, rank, local_rank, world, device):
     dom = int(np.argmax(ms0))
     spin_up(step, args.spinup_ms)
     plan.set_probe(dom, args.steps)
+    clocks = {"before": gpu_state(local_rank)}
 
     # ---- timed region: EXACTLY `steps` steps between barrier+synchronize pairs ----
     barrier(world, device)
@@ -267,7 +422,9 @@ def run_infer(args, rank, local_rank, world, device):
     torch.cuda.synchronize()
     barrier(world, device)
     elapsed = time.perf_counter() - t0
+    clocks["after"] = gpu_state(local_rank)
     elapsed = max_over_ranks(elapsed, world, device)
+    ranks_seen, devices = rank_census(rank, local_rank, world, device)
 
     probe_ms = plan.read_probe(args.steps)
     plan.set_probe(-1, 0)
@@ -301,7 +458,7 @@ def run_infer(args, rank, local_rank, world, device):
         with open(args.layer_table, "w") as fh:
             json.dump({"layers": table, "forward_ms_sum": sum(ms0), "step_ms": elapsed / args.steps * 1e3,
                        "build_fingerprint": build_fingerprint()}, fh, indent=1)
-    res = result_head(args, value, world, elapsed)
+    res = result_head(args, value, world, elapsed, ranks_seen, devices, clocks)
     res["config"] = {"workload": "%s %s inference, batch=%d per GPU, synthetic %dx%d images (%d distinct batches in rotation), full hot "
                                  "path (forward + interpret_output + filter_prediction + filtered rows to pinned host memory), inputs "
                                  "resident in HBM" % (args.arch, args.dtype, args.batch, args.width, args.height, nrot),
@@ -310,6 +467,16 @@ def run_infer(args, rank, local_rank, world, device):
     res["roofline"] = roof
     res["host_issue_ms_per_step"] = round(t_issued / args.steps * 1e3, 4)
     res["forward_launches_ms_sum"] = round(float(sum(ms0)), 4)
+    if args.sample:
+        # configs[0] is a LATENCY case: one image, device idle before and after (the timed region above is the pipelined
+        # throughput of the same step).  float32 = the reference's dtype, float16 = the benchmark's.
+        lat = {args.dtype: round(sync_latency_ms(model, xs[0]), 4)}
+        other = "fp32" if args.dtype == "fp16" else "fp16"
+        a2 = argparse.Namespace(**vars(args))
+        a2.dtype = other
+        m2, _, xs2 = build_infer_model(a2, local_rank)
+        lat[other] = round(sync_latency_ms(m2, xs2[0]), 4)
+        res["latency_ms_per_image_sync"] = lat
     if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline_infer(args, args.cpu_baseline_seconds)
     return res
@@ -410,6 +577,7 @@ def run_train(args, rank, local_rank, world, device):
         out = step(i)
     torch.cuda.synchronize()
     spin_up(step, args.spinup_ms)
+    clocks = {"before": gpu_state(local_rank)}
     barrier(world, device)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -420,7 +588,9 @@ def run_train(args, rank, local_rank, world, device):
     tr.flush()
     barrier(world, device)
     elapsed = time.perf_counter() - t0
+    clocks["after"] = gpu_state(local_rank)
     elapsed = max_over_ranks(elapsed, world, device)
+    ranks_seen, devices = rank_census(rank, local_rank, world, device)
     if rank != 0:
         return None
     value = aggregate_throughput(args.batch, args.steps, world, elapsed)
@@ -434,7 +604,7 @@ def run_train(args, rank, local_rank, world, device):
     roof["kernel"] = "whole training step (forward + loss + backward + update; ~300 launches%s)" % (", replayed as one hipGraph" if use_graph else "")
     roof["avg_launch_ms"] = round(step_ms, 4)
     roof["algorithmic_flops_per_launch"] = flops
-    res = result_head(args, value, world, elapsed)
+    res = result_head(args, value, world, elapsed, ranks_seen, devices, clocks)
     res["config"] = {"workload": "%s %s training, batch=%d per GPU, synthetic %dx%d images + KITTI-like ground truth (%d distinct batches "
                                  "in rotation): GPU label build + forward + loss + backward + gradient all-reduce + clipped Momentum"
                                  % (args.arch, "float32" if args.dtype == "fp32" else "mixed-precision (float16 activations)", args.batch,
@@ -451,7 +621,7 @@ def run_train(args, rank, local_rank, world, device):
     return res
 
 
-def result_head(args, value, world, elapsed):
+def result_head(args, value, world, elapsed, ranks_seen=1, devices=None, clocks=None):
     return {
         "metric": args.metric,
         "value": round(value, 2),
@@ -465,33 +635,115 @@ def result_head(args, value, world, elapsed):
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f16" if args.dtype == "fp16" else "f32",
-        "data": "synthetic",
+        "data": "reference data/sample.png (tests/golden/sample.png), random-init weights" if getattr(args, "sample", False) else "synthetic",
+        "ranks_seen": ranks_seen,          # dist.get_world_size() as the process group reports it (== n_gpus or the run is void)
+        "devices": devices,                # one entry per rank: device index, name, uuid / PCI id
+        "clocks": clocks,                  # rank 0's GPU right before / after the timed region (amdsmi)
     }
 
 
+def fail(msg, **extra):
+    """A failure is ONE JSON line on stdout (the driver parses stdout) and a non-zero exit code -- never a usage string."""
+    d = {"error": msg, "metric": None, "value": None}
+    d.update(extra)
+    print(json.dumps(d), flush=True)
+    sys.exit(2)
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside a torchrun environment: re-launch this script as N local ranks under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1), forward rank 0's JSON line and the exit code.
+    The reference is single-process / single-device (src/train.py:107, nets/squeezeDet.py:21): nothing to mirror."""
+    import subprocess
+    if not args.dry_run:
+        n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n < args.gpus:
+            fail("--gpus %d but only %d HIP device(s) are visible" % (args.gpus, n), n_gpus=args.gpus, devices_visible=n)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    sys.stderr.write(r.stderr[-6000:] if r.returncode != 0 else "")
+    if r.returncode != 0 or not lines:
+        fail("the %d-rank launch failed (exit code %d)" % (args.gpus, r.returncode), n_gpus=args.gpus,
+             stderr_tail=r.stderr[-1500:], stdout_tail=r.stdout[-500:])
+    print(lines[-1], flush=True)
+
+
+def run_dry(args, rank, local_rank, world, device):
+    """--dry-run: everything around the kernels -- rendezvous, barrier, the exactly-K-steps timed loop, max-over-ranks,
+    the rank census, the JSON line -- with a no-op step on CPU tensors (gloo)."""
+    step = lambda i: None
+    for i in range(max(args.warmup, 1)):
+        step(i)
+    barrier(world, device)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    time.sleep(0.01 * (1 + rank))                      # ranks finish at different times: the MAX must win
+    barrier(world, device)
+    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed, world, device)
+    ranks_seen, devices = rank_census(rank, local_rank, world, device)
+    if rank != 0:
+        return None
+    res = result_head(args, aggregate_throughput(args.batch, args.steps, world, elapsed), world, elapsed, ranks_seen, devices, None)
+    res.update(dry_run=True, value=None, ms_per_step=None, data="none (dry run: no kernels executed)")
+    res["config"] = {"workload": "DRY RUN of %s: launcher + rendezvous + timing reduction only" % args.config, "name": args.config,
+                     "global_batch": args.batch * world, "parallelism": "dp%d" % world}
+    return res
+
+
 def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
     rank, local_rank, world = dist_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    # (SQDET_FORCE_DIST=1 under torch.distributed.run with one process: exercises the RCCL path on a single-GPU box)
-    if world > 1 or (os.environ.get("SQDET_FORCE_DIST") == "1" and "RANK" in os.environ):
+    in_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if world > 1 and world != args.gpus:
+        fail("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world), n_gpus=args.gpus)
+    if args.gpus > 1 and not in_torchrun:
+        return self_launch(args, argv)
+    if args.dry_run:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    res = run_infer(args, rank, local_rank, world, device) if args.kind == "infer" else run_train(args, rank, local_rank, world, device)
+        device = torch.device("cpu")
+        if in_torchrun:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        res = run_dry(args, rank, local_rank, world, device)
+    else:
+        if not torch.cuda.is_available():
+            fail("bench.py needs a HIP device (there is no CPU fallback); --dry-run exercises the launcher without one", n_gpus=args.gpus)
+        if local_rank >= torch.cuda.device_count():
+            fail("rank %d: local rank %d but only %d HIP device(s) are visible" % (rank, local_rank, torch.cuda.device_count()), n_gpus=args.gpus)
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        # (SQDET_FORCE_DIST=1 under torch.distributed.run with one process: exercises the RCCL path on a single-GPU box)
+        if world > 1 or (os.environ.get("SQDET_FORCE_DIST") == "1" and in_torchrun):
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        res = run_infer(args, rank, local_rank, world, device) if args.kind == "infer" else run_train(args, rank, local_rank, world, device)
     if rank == 0:
+        if res.get("ranks_seen") != args.gpus:
+            res["error"] = "ranks_seen %s != --gpus %d" % (res.get("ranks_seen"), args.gpus)
         print(json.dumps(res), flush=True)
     if _dist_on():
         import torch.distributed as dist
         dist.destroy_process_group()
+    if rank == 0 and "error" in res:
+        sys.exit(2)
 
 
 if __name__ == "__main__":

@@ -297,13 +297,16 @@ int sqdet_maxpool_nhwc_bwd_relu(const void* x, const void* dy, void* dx, int n, 
  * input_mask [B,A], box_delta_input [B,A,4], box_input [B,A,4] (cx,cy,w,h), labels [B,A,C];
  * num_objects = sum(input_mask) over the batch.  Outputs: dpreds = d(class+conf+bbox loss)/dpreds
  * [B,gh,gw,K*(C+5)], ious [B,A] (the assign'ed IoU target, no gradient), losses3 = {class_loss,
- * conf_loss, bbox_loss}.  workspace: sqdet_loss_workspace_bytes() of device scratch. */
+ * conf_loss, bbox_loss}.  workspace: sqdet_loss_workspace_bytes() of device scratch.
+ * global_batch: the divisor of the confidence term's reduce_mean over the batch (nn_skeleton.py:304-312); <= 0 = `batch`.
+ * Data-parallel replicas that reproduce ONE graph of batch world*B (num_objects all-reduced, gradients SUMMED) pass
+ * world*B here: the class / bbox terms divide by num_objects only, the confidence term also by the batch. */
 size_t sqdet_loss_workspace_bytes(void);
 int sqdet_loss_fwd_bwd(const float* preds, const float* anchors, const float* input_mask, const float* box_delta_input,
                        const float* box_input, const float* labels, float* dpreds, float* ious, float* losses3,
                        float* workspace, int batch, int gh, int gw, int apg, int classes, float img_w, float img_h,
                        float exp_thresh, float epsilon, float coef_class, float coef_conf_pos, float coef_conf_neg,
-                       float coef_bbox, float num_objects, sqdet_stream_t stream);
+                       float coef_bbox, float num_objects, int global_batch, sqdet_stream_t stream);
 
 /* Same, with num_objects read from the DEVICE (float32 scalar, e.g. sqdet_sum_f32 of input_mask -- nn_skeleton.py:180 --
  * optionally SUM-all-reduced over the replicas first: the exact global-batch normalisation of SURVEY.md 8e option b):
@@ -312,7 +315,7 @@ int sqdet_loss_fwd_bwd_dev(const float* preds, const float* anchors, const float
                            const float* box_input, const float* labels, float* dpreds, float* ious, float* losses3,
                            float* workspace, int batch, int gh, int gw, int apg, int classes, float img_w, float img_h,
                            float exp_thresh, float epsilon, float coef_class, float coef_conf_pos, float coef_conf_neg,
-                           float coef_bbox, const float* num_objects_dev, sqdet_stream_t stream);
+                           float coef_bbox, const float* num_objects_dev, int global_batch, sqdet_stream_t stream);
 /* out[0] = sum(x[0..count)) in a fixed order (deterministic): tf.reduce_sum(self.input_mask), nn_skeleton.py:180. */
 int sqdet_sum_f32(const float* x, size_t count, float* out, sqdet_stream_t stream);
 /* y = max(a + b, 0): tf.nn.relu(shortcut + branch) (nets/resnet50_convDet.py:55) where the producing conv could not take

@@ -142,10 +142,14 @@ def forward_train(arch, params, x, dropout_mask, keep_prob=0.5, storage="fp32", 
     return t
 
 
-def loss_graph(mc, preds, input_mask, box_delta_input, box_input, labels):
+def loss_graph(mc, preds, input_mask, box_delta_input, box_input, labels, num_objects=None, global_batch=None):
     """_add_interpretation_graph + _add_loss_graph (nn_skeleton.py:142-327) on a preds tensor
     [B,gh,gw,K*(C+5)] (torch, may require grad).  Returns dict of scalar losses (without weight
-    decay) and the detached ious."""
+    decay) and the detached ious.
+    num_objects / global_batch (not in the reference, which is single-device): evaluate these B samples as a SHARE of one
+    graph of `global_batch` samples holding `num_objects` objects -- the shares of a partition of the batch then sum to
+    exactly the reference's losses at the full batch (:180 num_objects is a batch total; :304-312 reduce_mean divides
+    the confidence term by the batch)."""
     B = preds.shape[0]
     K, C, A = mc.ANCHOR_PER_GRID, mc.CLASSES, mc.ANCHORS
     eps = mc.EPSILON
@@ -157,7 +161,7 @@ def loss_graph(mc, preds, input_mask, box_delta_input, box_input, labels):
     dl_in = torch.as_tensor(box_delta_input, dtype=torch.float32)
     bx_in = torch.as_tensor(box_input, dtype=torch.float32)
     lab = torch.as_tensor(labels, dtype=torch.float32)
-    num_objects = mask.sum()
+    num_objects = mask.sum() if num_objects is None else torch.as_tensor(num_objects, dtype=torch.float32)
     # ious (nn_skeleton.py:240-269), no gradient (Variable.assign)
     with torch.no_grad():
         out = O.interpret_output(preds.detach().numpy(), mc)
@@ -175,7 +179,7 @@ def loss_graph(mc, preds, input_mask, box_delta_input, box_input, labels):
     # :304-312
     m2 = mask.reshape(B, A)
     conf_loss = (((ious - conf) ** 2) * (m2 * mc.LOSS_COEF_CONF_POS / num_objects
-                                          + (1 - m2) * mc.LOSS_COEF_CONF_NEG / (A - num_objects))).sum(dim=1).mean()
+                                          + (1 - m2) * mc.LOSS_COEF_CONF_NEG / (A - num_objects))).sum(dim=1).sum() / float(global_batch or B)
     # :317-323
     bbox_loss = (mc.LOSS_COEF_BBOX * (mask * (delta - dl_in)) ** 2).sum() / num_objects
     return dict(class_loss=class_loss, conf_loss=conf_loss, bbox_loss=bbox_loss, ious=ious, num_objects=num_objects,

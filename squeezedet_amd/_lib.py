@@ -8,6 +8,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsqdet_hip.so")
 
 SQDET_OK = 0
+SQDET_EUNSUPPORTED = -2
 F32, F16 = 0, 1
 PAD_SAME, PAD_VALID = 0, 1
 ARCH_SQUEEZEDET, ARCH_SQUEEZEDET_PLUS, ARCH_RESNET50 = 0, 1, 2
@@ -57,8 +58,8 @@ SIGNATURES = {
     "sqdet_maxpool_nhwc_bwd": (ci, [vp, vp, vp] + [ci] * 8 + [vp]),
     "sqdet_maxpool_nhwc_bwd_relu": (ci, [vp, vp, vp] + [ci] * 8 + [vp]),
     "sqdet_loss_workspace_bytes": (sz, []),
-    "sqdet_loss_fwd_bwd": (ci, [vp] * 10 + [ci] * 5 + [cf] * 9 + [vp]),
-    "sqdet_loss_fwd_bwd_dev": (ci, [vp] * 10 + [ci] * 5 + [cf] * 8 + [vp, vp]),
+    "sqdet_loss_fwd_bwd": (ci, [vp] * 10 + [ci] * 5 + [cf] * 9 + [ci, vp]),
+    "sqdet_loss_fwd_bwd_dev": (ci, [vp] * 10 + [ci] * 5 + [cf] * 8 + [vp, ci, vp]),
     "sqdet_sum_f32": (ci, [vp, sz, vp, vp]),
     "sqdet_add_relu": (ci, [vp, vp, vp, sz, ci, vp]),
     "sqdet_copy_channels": (ci, [vp, vp, sz, ci, ci, ci, ci, vp]),
@@ -94,6 +95,11 @@ class SqdetError(RuntimeError):
     pass
 
 
+class SqdetUnsupported(SqdetError):
+    """SQDET_EUNSUPPORTED: no kernel of this entry point takes the shape / option combination (the caller may use the
+    general entry points instead -- another HIP kernel, never a CPU path)."""
+
+
 def lib():
     """Loads the library once.  Raises (never falls back) when it is missing."""
     global _lib
@@ -114,7 +120,8 @@ def lib():
 def check(rc, what=""):
     if rc != SQDET_OK:
         msg = lib().sqdet_last_error()
-        raise SqdetError("%s failed (code %d): %s" % (what or "sqdet call", rc, msg.decode() if msg else "?"))
+        cls = SqdetUnsupported if rc == SQDET_EUNSUPPORTED else SqdetError
+        raise cls("%s failed (code %d): %s" % (what or "sqdet call", rc, msg.decode() if msg else "?"))
 
 
 def dtype_code(torch_dtype):

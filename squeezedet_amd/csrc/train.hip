@@ -258,6 +258,8 @@ struct LossArgs {
   float* ious;             // [B,A]
   float* partial;          // [blocks][4]: class, conf, bbox loss partial sums (+ unused)
   int B, cells, K, C;
+  int Bmean;               // divisor of the confidence loss's reduce_mean over the batch (nn_skeleton.py:304-312): B, or the
+                           // GLOBAL batch when N replicas of batch B compute one graph of batch N*B (SURVEY.md 8e option b)
   float w1, h1, thr, slope, eps;
   float coef_class, coef_pos, coef_neg, coef_bbox;
   float num_obj;           // sum(mask) over the whole batch (host computed from the label tensors) ...
@@ -326,8 +328,8 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
     // confidence loss (:304-312): mean over the batch of sum_a (iou-conf)^2 * w_a
     const float wgt = m * a.coef_pos / nobj + (1.0f - m) * a.coef_neg / ((float)A - nobj);
     const float dc = iou - conf;
-    l_conf += dc * dc * wgt / (float)a.B;
-    dp[a.K * a.C + k] = 2.0f * (conf - iou) * wgt / (float)a.B * conf * (1.0f - conf);
+    l_conf += dc * dc * wgt / (float)a.Bmean;
+    dp[a.K * a.C + k] = 2.0f * (conf - iou) * wgt / (float)a.Bmean * conf * (1.0f - conf);
     // bbox loss (:317-323)
     for (int d = 0; d < 4; ++d) {
       const float df = m * (dl[d] - a.delta_in[idx * 4 + d]);
@@ -666,18 +668,18 @@ static int loss_fwd_bwd_impl(const float* preds, const float* anchors, const flo
                              float* dpreds, float* ious, float* losses3, float* workspace, int batch, int gh, int gw,
                              int apg, int classes, float img_w, float img_h, float exp_thresh, float epsilon,
                              float coef_class, float coef_conf_pos, float coef_conf_neg, float coef_bbox,
-                             float num_objects, const float* num_objects_dev, sqdet_stream_t stream);
+                             float num_objects, const float* num_objects_dev, int global_batch, sqdet_stream_t stream);
 
 extern "C" int sqdet_loss_fwd_bwd_dev(const float* preds, const float* anchors, const float* input_mask,
                                       const float* box_delta_input, const float* box_input, const float* labels,
                                       float* dpreds, float* ious, float* losses3, float* workspace, int batch, int gh, int gw,
                                       int apg, int classes, float img_w, float img_h, float exp_thresh, float epsilon,
                                       float coef_class, float coef_conf_pos, float coef_conf_neg, float coef_bbox,
-                                      const float* num_objects_dev, sqdet_stream_t stream) {
+                                      const float* num_objects_dev, int global_batch, sqdet_stream_t stream) {
   SQDET_REQUIRE(num_objects_dev, "loss_fwd_bwd_dev: null num_objects");
   return loss_fwd_bwd_impl(preds, anchors, input_mask, box_delta_input, box_input, labels, dpreds, ious, losses3, workspace,
                            batch, gh, gw, apg, classes, img_w, img_h, exp_thresh, epsilon, coef_class, coef_conf_pos,
-                           coef_conf_neg, coef_bbox, 1.0f, num_objects_dev, stream);
+                           coef_conf_neg, coef_bbox, 1.0f, num_objects_dev, global_batch, stream);
 }
 
 extern "C" int sqdet_loss_fwd_bwd(const float* preds, const float* anchors, const float* input_mask,
@@ -685,10 +687,10 @@ extern "C" int sqdet_loss_fwd_bwd(const float* preds, const float* anchors, cons
                                   float* dpreds, float* ious, float* losses3, float* workspace, int batch, int gh, int gw,
                                   int apg, int classes, float img_w, float img_h, float exp_thresh, float epsilon,
                                   float coef_class, float coef_conf_pos, float coef_conf_neg, float coef_bbox,
-                                  float num_objects, sqdet_stream_t stream) {
+                                  float num_objects, int global_batch, sqdet_stream_t stream) {
   return loss_fwd_bwd_impl(preds, anchors, input_mask, box_delta_input, box_input, labels, dpreds, ious, losses3, workspace,
                            batch, gh, gw, apg, classes, img_w, img_h, exp_thresh, epsilon, coef_class, coef_conf_pos,
-                           coef_conf_neg, coef_bbox, num_objects, nullptr, stream);
+                           coef_conf_neg, coef_bbox, num_objects, nullptr, global_batch, stream);
 }
 
 static int loss_fwd_bwd_impl(const float* preds, const float* anchors, const float* input_mask,
@@ -696,14 +698,15 @@ static int loss_fwd_bwd_impl(const float* preds, const float* anchors, const flo
                                   float* dpreds, float* ious, float* losses3, float* workspace, int batch, int gh, int gw,
                                   int apg, int classes, float img_w, float img_h, float exp_thresh, float epsilon,
                                   float coef_class, float coef_conf_pos, float coef_conf_neg, float coef_bbox,
-                                  float num_objects, const float* num_objects_dev, sqdet_stream_t stream) {
+                                  float num_objects, const float* num_objects_dev, int global_batch, sqdet_stream_t stream) {
   SQDET_REQUIRE(preds && anchors && input_mask && box_delta_input && box_input && labels && dpreds && ious && losses3 &&
                     workspace, "loss_fwd_bwd: null pointer");
   SQDET_REQUIRE(batch > 0 && gh > 0 && gw > 0 && apg > 0 && classes > 0 && num_objects > 0.f, "loss_fwd_bwd: bad arguments");
+  SQDET_REQUIRE(global_batch <= 0 || global_batch >= batch, "loss_fwd_bwd: global_batch smaller than batch");
   LossArgs a;
   a.preds = preds; a.anchors = anchors; a.mask = input_mask; a.delta_in = box_delta_input; a.box_in = box_input;
   a.labels = labels; a.dpreds = dpreds; a.ious = ious; a.partial = workspace;
-  a.B = batch; a.cells = gh * gw; a.K = apg; a.C = classes;
+  a.B = batch; a.Bmean = global_batch > 0 ? global_batch : batch; a.cells = gh * gw; a.K = apg; a.C = classes;
   a.w1 = img_w - 1.0f; a.h1 = img_h - 1.0f; a.thr = exp_thresh; a.slope = (float)exp((double)exp_thresh); a.eps = epsilon;
   a.coef_class = coef_class; a.coef_pos = coef_conf_pos; a.coef_neg = coef_conf_neg; a.coef_bbox = coef_bbox;
   a.num_obj = num_objects;

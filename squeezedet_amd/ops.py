@@ -510,10 +510,11 @@ def dropout_mask_into(mask, keep_prob, seed):
     return mask
 
 
-def loss_fwd_bwd(preds, anchors_f32, input_mask, box_delta_input, box_input, labels, mc, num_objects):
+def loss_fwd_bwd(preds, anchors_f32, input_mask, box_delta_input, box_input, labels, mc, num_objects, global_batch=0):
     """ModelSkeleton._add_loss_graph forward + backward (nn_skeleton.py:285-327).  All tensors float32 on
     the device.  num_objects: a Python number, or a float32 DEVICE scalar (no host round trip: hipGraph-capturable).
-    Returns (dpreds, ious [B,A], losses [3] = class, conf, bbox)."""
+    global_batch: divisor of the confidence term's mean over the batch when this call is one replica's share of a larger
+    batch (0 = this call's batch).  Returns (dpreds, ious [B,A], losses [3] = class, conf, bbox)."""
     n, gh, gw, ch = [int(v) for v in preds.shape]
     A = gh * gw * mc.ANCHOR_PER_GRID
     dev = preds.device
@@ -529,7 +530,7 @@ def loss_fwd_bwd(preds, anchors_f32, input_mask, box_delta_input, box_input, lab
                                            n, gh, gw, int(mc.ANCHOR_PER_GRID), int(mc.CLASSES), float(mc.IMAGE_WIDTH),
                                            float(mc.IMAGE_HEIGHT), float(mc.EXP_THRESH), float(mc.EPSILON), float(mc.LOSS_COEF_CLASS),
                                            float(mc.LOSS_COEF_CONF_POS), float(mc.LOSS_COEF_CONF_NEG), float(mc.LOSS_COEF_BBOX),
-                                           _dev(num_objects, "num_objects", torch.float32), stream_ptr()), "sqdet_loss_fwd_bwd_dev")
+                                           _dev(num_objects, "num_objects", torch.float32), int(global_batch), stream_ptr()), "sqdet_loss_fwd_bwd_dev")
         return dpreds, ious, losses
     check(lib().sqdet_loss_fwd_bwd(_dev(preds, "preds", torch.float32), _dev(anchors_f32, "anchors", torch.float32),
                                    _dev(input_mask, "mask", torch.float32), _dev(box_delta_input, "delta", torch.float32),
@@ -538,7 +539,7 @@ def loss_fwd_bwd(preds, anchors_f32, input_mask, box_delta_input, box_input, lab
                                    n, gh, gw, int(mc.ANCHOR_PER_GRID), int(mc.CLASSES), float(mc.IMAGE_WIDTH),
                                    float(mc.IMAGE_HEIGHT), float(mc.EXP_THRESH), float(mc.EPSILON), float(mc.LOSS_COEF_CLASS),
                                    float(mc.LOSS_COEF_CONF_POS), float(mc.LOSS_COEF_CONF_NEG), float(mc.LOSS_COEF_BBOX),
-                                   float(num_objects), stream_ptr()), "sqdet_loss_fwd_bwd")
+                                   float(num_objects), int(global_batch), stream_ptr()), "sqdet_loss_fwd_bwd")
     return dpreds, ious, losses
 
 

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import ops
-from ._lib import SqdetError
+from ._lib import SqdetError, SqdetUnsupported
 
 
 def allreduce_gradients(flat_grads, world, group=None):
@@ -33,6 +33,25 @@ def allreduce_gradients(flat_grads, world, group=None):
     if world > 1:
         torch.distributed.all_reduce(flat_grads, op=torch.distributed.ReduceOp.SUM, group=group)
     return 1.0 / world
+
+
+def reduce_num_objects(num_objects, world, group=None):
+    """global_num_objects mode: the scalar num_objects = sum(input_mask) (nn_skeleton.py:180) SUM-all-reduced in place over
+    the replicas -- the second (one-element) collective of a step in that mode."""
+    if world > 1:
+        torch.distributed.all_reduce(num_objects, op=torch.distributed.ReduceOp.SUM, group=group)
+    return num_objects
+
+
+def step_normalisation(global_num_objects, local_batch, world):
+    """(global_batch argument of the loss kernel, factor applied to the SUM-all-reduced gradient bucket).
+    replica-mean (default): every replica is the reference at its own batch -- loss divisors local (0 = this call's
+    batch), gradients averaged (1/world).  global: the replicas' losses are shares of ONE graph of batch world*B -- the
+    confidence term's batch divisor is world*B (the class / bbox terms only see the all-reduced num_objects), and the
+    shares' gradients are SUMMED (factor 1)."""
+    if global_num_objects:
+        return int(local_batch) * int(world), 1.0
+    return 0, 1.0 / world
 
 
 class _TrainerBase:
@@ -46,7 +65,7 @@ class _TrainerBase:
     gradients overflowed (inf / NaN norm in any variable, on any rank -- the SUM all-reduce spreads it) is skipped by
     the optimizer kernel and halves the scale; `growth_interval` clean steps double it."""
 
-    def __init__(self, model, process_group=None, loss_scale=1024.0, growth_interval=200, lazy_overflow_check=False,
+    def __init__(self, model, process_group=None, loss_scale=1024.0, growth_interval=200, lazy_overflow_check=None,
                  global_num_objects=False, seed=0):
         if model.dtype not in (torch.float32, torch.float16):
             raise SqdetError("training runs in float32 (the reference's training dtype) or float16 (mixed precision)")
@@ -57,7 +76,10 @@ class _TrainerBase:
         # lazy_overflow_check: read a step's overflow flag at the END OF THE NEXT step (asynchronous copy to pinned
         # memory + event) instead of synchronising with the device every step.  The skipped update itself happens on the
         # device either way; only the loss-scale / counter bookkeeping lags one step.  flush() settles the last one.
-        self.lazy_overflow_check = bool(lazy_overflow_check)
+        # Default: lazy in float32 (the flag can only raise the divergence error there -- no reason to pay a device
+        # synchronisation per step for it; global_step advances at once, so the staircase decay fires on the reference's
+        # step), eager in float16 (the next step's loss scale depends on it).
+        self.lazy_overflow_check = (not self.half) if lazy_overflow_check is None else bool(lazy_overflow_check)
         self._pending_flag = None
         if not model.has_device:
             raise SqdetError("squeezedet_amd needs a HIP device: there is no CPU path")
@@ -68,7 +90,11 @@ class _TrainerBase:
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
         self.global_num_objects = bool(global_num_objects)
-        self.seed, self._mask_calls = int(seed), 0
+        # dropout masks are independent across the global batch (one tf.nn.dropout over all samples in the reference,
+        # nets/squeezeDet.py:74): every replica draws from its own counter stream -- only parameters and momentum must
+        # match across ranks, masks must not
+        self.rank = torch.distributed.get_rank(process_group) if self.world > 1 else 0
+        self.seed, self._mask_calls = int(seed) * self.world + self.rank, 0
         self.global_step = 0
         # trainable variables (conv1 is frozen: nets/squeezeDet.py:40-42) packed into flat buffers
         self.names = [n for n in model.params if model.trainable[n]]
@@ -102,15 +128,18 @@ class _TrainerBase:
         mc = self.mc
         return mc.LEARNING_RATE * mc.LR_DECAY_FACTOR ** (self.global_step // mc.DECAY_STEPS)   # staircase decay
 
-    def _labels(self, B, input_mask, box_delta_input, box_input, labels, num_objects=None):
+    def _labels(self, B, input_mask, box_delta_input, box_input, labels, num_objects=None, num_objects_is_global=False):
         t = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))).to(self.dev, torch.float32).contiguous()
         mask = t(input_mask).reshape(B, -1)
         if num_objects is None:       # sum(input_mask) on the device (nn_skeleton.py:180): no host round trip
             num_objects = ops.sum_f32(mask)
         elif not isinstance(num_objects, torch.Tensor):
             num_objects = torch.full((1,), float(num_objects), dtype=torch.float32, device=self.dev)
-        if self.global_num_objects and self.world > 1:      # exact global-batch normalisation: one scalar all-reduce
-            torch.distributed.all_reduce(num_objects, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        if self.global_num_objects and self.world > 1 and not num_objects_is_global:      # exact global-batch normalisation: one scalar all-reduce
+            if torch.cuda.is_current_stream_capturing():
+                raise SqdetError("global_num_objects at world > 1: the num_objects all-reduce must run eagerly -- pass "
+                                 "num_objects (already all-reduced) into the captured step (GraphedStep does)")
+            reduce_num_objects(num_objects, self.world, self.pg)
         return t, mask, t(box_delta_input), t(box_input), t(labels), num_objects
 
     def _mask_tensor(self, dropout_mask, t):
@@ -129,15 +158,18 @@ class _TrainerBase:
         """Loss forward + backward in float32; returns (gradient w.r.t. preds in the activation dtype -- times
         loss_scale in float16 mode --, float32 dpreds, ious, losses)."""
         p32 = ops.convert_scale(preds, torch.float32) if self.half else preds
-        dpreds, ious, losses = ops.loss_fwd_bwd(p32, self.model.anchors_f32(), mask, delta, box, lab, self.mc, num_objects)
+        # global_num_objects: this replica's loss is its share of ONE graph of batch world*B -- the confidence term's
+        # reduce_mean over the batch (nn_skeleton.py:304-312) divides by the global batch too; the bucket is then SUMMED
+        gb, _ = step_normalisation(self.global_num_objects, int(preds.shape[0]), self.world)
+        dpreds, ious, losses = ops.loss_fwd_bwd(p32, self.model.anchors_f32(), mask, delta, box, lab, self.mc, num_objects, global_batch=gb)
         g = ops.convert_scale(dpreds, torch.float16, self.loss_scale) if self.half else dpreds
         return g, dpreds, ious, losses
 
     def _finish_step(self, apply_update):
         """Gradient all-reduce (the one collective) + clipped Momentum update on the flat buffers."""
-        grad_scale = allreduce_gradients(self.flat_grads, self.world, self.pg)
-        if self.global_num_objects:
-            grad_scale = 1.0      # every replica's loss is already divided by the GLOBAL num_objects: the bucket is a sum
+        allreduce_gradients(self.flat_grads, self.world, self.pg)
+        # (global mode: every replica's loss is its share of the global-batch graph: the bucket is a sum, factor 1)
+        _, grad_scale = step_normalisation(self.global_num_objects, 0, self.world)
         if apply_update:
             # (the kernel skips the whole update when any gradient norm is inf / NaN, in either precision: found_inf tells)
             self.opt.step(self.flat_params, self.flat_grads, self.flat_accum, self.learning_rate(), self.mc.MOMENTUM,
@@ -158,13 +190,20 @@ class _TrainerBase:
                 self._flag_host.copy_(self.found_inf, non_blocking=True)
                 self._flag_event.record(torch.cuda.current_stream())
                 self._pending_flag = True
+                if not self.half:
+                    self.global_step += 1                     # float32: counted now, the late flag can only raise
 
     def flush(self):
         """lazy_overflow_check: settle the bookkeeping of the last step (loss scale, skipped / global step counters)."""
         if self._pending_flag:
             self._flag_event.synchronize()
             self._pending_flag = None
-            self._account(bool(int(self._flag_host[0])))
+            overflowed = bool(int(self._flag_host[0]))
+            if self.half:
+                self._account(overflowed)
+            elif overflowed:
+                self.global_step -= 1                         # the kernel skipped that update
+                self._account(True)                           # raises FloatingPointError
 
     def _account(self, overflowed):
         if overflowed and not self.half:
@@ -240,14 +279,14 @@ class SqueezeDetTrainer(_TrainerBase):
         return out
 
     def forward_backward(self, images, input_mask, box_delta_input, box_input, labels, dropout_mask=None,
-                         keep_activations=False, num_objects=None):
+                         keep_activations=False, num_objects=None, num_objects_is_global=False):
         """Forward + loss + backward into the flat gradient bucket: kernel launches and stream-ordered allocations only,
         no host round trip (hipGraph-capturable).  _finish_step (all-reduce + update) completes the step."""
         m, mc, P = self.model, self.mc, self.model.params
         acts = {}
         x = m._to_input(images)
         B = int(x.shape[0])
-        t, mask, delta, box, lab, num_objects = self._labels(B, input_mask, box_delta_input, box_input, labels, num_objects)
+        t, mask, delta, box, lab, num_objects = self._labels(B, input_mask, box_delta_input, box_input, labels, num_objects, num_objects_is_global)
         keep = m.keep_prob
         # ---------------- forward, keeping what the backward needs ----------------
         saved = []
@@ -266,14 +305,18 @@ class SqueezeDetTrainer(_TrainerBase):
                         and ops.stem_supported(int(P[node.name + "/kernels"].shape[3]), int(P[node.name + "/kernels"].shape[0]))):
                     # frozen conv1 + pool1 (nets/squeezeDet.py:40-44): nothing below pool1's output is needed by the
                     # backward, so the fused stem launch serves the training forward too
-                    y = ops.stem_conv_pool(cur, self._pack(node.name), P[node.name + "/biases"], node.attrs["padding"],
-                                           nxt[2].attrs["padding"])
-                    saved.append(("conv", node, cur, None))
-                    saved.append(("pool", nxt[2], None, y))
-                    acts[nxt[2].name] = y
-                    cur = y
-                    skip_pool = nxt[2]
-                    continue
+                    try:
+                        y = ops.stem_conv_pool(cur, self._pack(node.name), P[node.name + "/biases"], node.attrs["padding"],
+                                               nxt[2].attrs["padding"])
+                    except SqdetUnsupported:
+                        y = None        # e.g. set_option("conv_algo", 1): the separate conv + pool kernels below
+                    if y is not None:
+                        saved.append(("conv", node, cur, None))
+                        saved.append(("pool", nxt[2], None, y))
+                        acts[nxt[2].name] = y
+                        cur = y
+                        skip_pool = nxt[2]
+                        continue
                 if node.name == "conv12":
                     drop_in = cur
                     if dropout_mask is None:
@@ -414,12 +457,12 @@ class ResNet50ConvDetTrainer(_TrainerBase):
         return out
 
     def forward_backward(self, images, input_mask, box_delta_input, box_input, labels, dropout_mask=None,
-                         keep_activations=False, num_objects=None):
+                         keep_activations=False, num_objects=None, num_objects_is_global=False):
         m, mc, P = self.model, self.mc, self.model.params
         eps = mc.BATCH_NORM_EPSILON
         (xb,) = m.run([self.boundary], {m.image_input: images}, use_plan=False)
         B = int(xb.shape[0])
-        t, mask, delta, box, lab, num_objects = self._labels(B, input_mask, box_delta_input, box_input, labels, num_objects)
+        t, mask, delta, box, lab, num_objects = self._labels(B, input_mask, box_delta_input, box_input, labels, num_objects, num_objects_is_global)
         # ---------------- forward over the trainable region ----------------
         val, aux = {self.boundary: xb}, {}
         for n in self.region:
@@ -516,7 +559,10 @@ class GraphedStep:
     (sqdet_build_labels), forward, loss and backward into the flat gradient bucket -- static shapes, no host round trip;
     the inputs are copied into static buffers, the dropout mask is drawn by one launch ahead of the replay, and the
     gradient all-reduce + optimizer step follow it eagerly (so the collective is an ordinary RCCL call).  Anything that
-    enters the captured launches BY VALUE (the loss scale) triggers a re-capture when it changes."""
+    enters the captured launches BY VALUE (the loss scale) triggers a re-capture when it changes; at most MAX_GRAPHS
+    captured graphs are kept (each pins its own static buffers and activation pool), least recently used first out."""
+
+    MAX_GRAPHS = 4
 
     def __init__(self, trainer, anchors_f64, classes):
         self.tr, self.anchors, self.classes = trainer, anchors_f64, int(classes)
@@ -532,8 +578,14 @@ class GraphedStep:
         din = last.inputs[0]
         dshape = (int(x.shape[0]),) + tuple(int(v) for v in din.get_shape()[1:])
         st["mask"] = torch.ones(dshape, dtype=tr.adt, device=tr.dev)
+        # global_num_objects at world > 1: the scalar all-reduce is an ordinary eager RCCL call AHEAD of the replay (step()
+        # below fills st["nobj"]); the captured launches read the already-global count from that static buffer
+        self.eager_nobj = tr.global_num_objects and tr.world > 1
+        if self.eager_nobj:
+            st["nobj"] = torch.ones(1, dtype=torch.float32, device=tr.dev)
         run = lambda: tr.forward_backward(st["x"], *ops.build_labels(self.anchors, st["gt"], st["gcls"], st["gcnt"], self.classes)[:4],
-                                          dropout_mask=st["mask"] if keep != 1.0 else None)
+                                          dropout_mask=st["mask"] if keep != 1.0 else None,
+                                          num_objects=st.get("nobj"), num_objects_is_global=self.eager_nobj)
         side = torch.cuda.Stream(device=tr.dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -545,6 +597,8 @@ class GraphedStep:
         self.graph, self.static, self.out = g, st, out
         self.key = (tr.loss_scale, tuple(x.shape))
         self.cache[self.key] = (g, st, out)
+        while len(self.cache) > self.MAX_GRAPHS:          # dict order = insertion / last-use order (step() re-inserts on a hit)
+            del self.cache[next(iter(self.cache))]
 
     def step(self, x, gt, gcls, gcnt, apply_update=True):
         tr = self.tr
@@ -553,7 +607,9 @@ class GraphedStep:
             if self.key != key:
                 if key in self.cache:
                     self.graph, self.static, self.out = self.cache[key]
+                    self.cache[key] = self.cache.pop(key)          # most recently used last
                     self.key = key
+                    self.eager_nobj = "nobj" in self.static
                 else:
                     self._capture(x, gt, gcls, gcnt)
             st = self.static
@@ -561,6 +617,10 @@ class GraphedStep:
             if tr.model.keep_prob != 1.0:
                 tr._mask_calls += 1
                 ops.dropout_mask_into(st["mask"], tr.model.keep_prob, (tr.seed << 32) + tr._mask_calls)
+            if getattr(self, "eager_nobj", False):
+                mask = ops.build_labels(self.anchors, st["gt"], st["gcls"], st["gcnt"], self.classes)[0]
+                ops.sum_f32(mask, out=st["nobj"])
+                reduce_num_objects(st["nobj"], tr.world, tr.pg)
             self.graph.replay()
             tr._finish_step(apply_update)
         return self.out

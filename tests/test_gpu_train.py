@@ -249,6 +249,42 @@ def test_loss_forward_backward_vs_oracle():
     _close(dp, dref, rel=5e-5, what="dpreds")
 
 
+def test_loss_two_replica_shares_sum_to_the_full_batch_graph():
+    """global_num_objects mode (SURVEY.md 8e option b) emulated in one process: two replicas of batch 2, each handed the
+    GLOBAL num_objects and global_batch = 4, produce the dpreds rows and (summed) losses of ONE graph of batch 4 -- checked
+    against the oracle's autograd at batch 4 (nn_skeleton.py:180,297-321: class / bbox divide by num_objects, the confidence
+    term also by the batch).  With the local batch as the divisor the confidence gradient came out world x too large."""
+    ops = _ops()
+    mc = O.squeezeDet_config_for_input(128, 256)
+    B = 4
+    rs = np.random.RandomState(15)
+    gh, gw = O.squeezedet_grid(128, 256)
+    preds = torch.from_numpy((rs.randn(B, gh, gw, 72) * 1.2).astype(np.float32)).requires_grad_(True)
+    mask, delta, box, labels = TO.synthetic_labels(mc, B, seed=16)
+    parts = TO.loss_graph(mc, preds, mask, delta, box, labels)
+    total = parts["class_loss"] + parts["conf_loss"] + parts["bbox_loss"]
+    (dref,) = torch.autograd.grad(total, preds)
+    anchors = torch.from_numpy(mc.ANCHOR_BOX.astype(np.float32)).to(DEV)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    nobj = float(mask.sum())
+    full = ops.loss_fwd_bwd(preds.detach().to(DEV), anchors, t(mask.reshape(B, -1)), t(delta), t(box), t(labels), mc, nobj)
+    halves = [ops.loss_fwd_bwd(preds.detach()[i:i + 2].to(DEV).contiguous(), anchors, t(mask[i:i + 2].reshape(2, -1)), t(delta[i:i + 2]),
+                               t(box[i:i + 2]), t(labels[i:i + 2]), mc, nobj, global_batch=B) for i in (0, 2)]
+    torch.cuda.synchronize()
+    dp = torch.cat([h[0] for h in halves], 0)
+    assert torch.equal(dp, full[0])                      # per-anchor arithmetic is identical: bitwise
+    _close(dp, dref, rel=5e-5, what="dpreds of the two shares vs the batch-4 graph")
+    ls = (halves[0][2] + halves[1][2]).cpu().numpy()
+    np.testing.assert_allclose(ls, [float(parts["class_loss"]), float(parts["conf_loss"]), float(parts["bbox_loss"])], rtol=2e-5)
+    # and the default (replica-mean) call of a half is the reference at batch 2: a different, self-consistent normalisation
+    own = ops.loss_fwd_bwd(preds.detach()[:2].to(DEV).contiguous(), anchors, t(mask[:2].reshape(2, -1)), t(delta[:2]), t(box[:2]),
+                           t(labels[:2]), mc, float(mask[:2].sum()))
+    p2 = preds.detach()[:2].clone().requires_grad_(True)
+    parts2 = TO.loss_graph(mc, p2, mask[:2], delta[:2], box[:2], labels[:2])
+    (d2,) = torch.autograd.grad(parts2["class_loss"] + parts2["conf_loss"] + parts2["bbox_loss"], p2)
+    _close(own[0], d2, rel=5e-5, what="replica-mean dpreds")
+
+
 def _trainer(img=(128, 256), batch=2, seed=0, dtype=torch.float32, **kw):
     import squeezedet_amd as S
     from squeezedet_amd import nets

@@ -96,3 +96,128 @@ def test_single_rank_defaults():
     assert a.gpus == 1 and a.batch == 32 and (a.height, a.width) == (375, 1242) and a.dtype == "fp16"
     assert bench.max_over_ranks(2.0, 1, torch.device("cpu")) == 2.0
     assert bench.aggregate_throughput(32, 30, 1, 2.0) == 480.0
+
+
+def _trainer_step_worker(rank, world, port, q, global_mode):
+    """One data-parallel 'trainer step' on CPU tensors, through the trainer's OWN host logic (squeezedet_amd.train:
+    reduce_num_objects, step_normalisation, allreduce_gradients) with the oracle's loss graph standing in for the HIP
+    loss kernel: a one-parameter-vector model preds = base * w, each rank holding half of a batch of 4."""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from oracle import sqdet_oracle as O
+    from oracle import train_oracle as TO
+    from squeezedet_amd.train import allreduce_gradients, reduce_num_objects, step_normalisation
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    mc = O.squeezeDet_config_for_input(64, 128)
+    gh, gw = O.squeezedet_grid(64, 128)
+    Bl = 2
+    rs = np.random.RandomState(77)
+    base = torch.from_numpy((rs.randn(Bl * world, gh, gw, 72)).astype(np.float32))
+    mask, delta, box, labels = TO.synthetic_labels(mc, Bl * world, seed=78)
+    w = torch.full((72,), 1.1, requires_grad=True)
+    sl = slice(rank * Bl, (rank + 1) * Bl)
+    nobj = torch.as_tensor(mask[sl]).float().sum().reshape(1)
+    gb, _ = step_normalisation(global_mode, Bl, world)
+    if global_mode:
+        reduce_num_objects(nobj, world)                       # the scalar collective
+    parts = TO.loss_graph(mc, base[sl] * w, mask[sl], delta[sl], box[sl], labels[sl], num_objects=nobj[0] if global_mode else None,
+                          global_batch=gb or None)
+    (g,) = torch.autograd.grad(parts["class_loss"] + parts["conf_loss"] + parts["bbox_loss"], w)
+    bucket = g.clone()
+    allreduce_gradients(bucket, world)                         # the bucket collective (SUM)
+    _, scale = step_normalisation(global_mode, Bl, world)
+    q.put((rank, float(nobj[0]), (bucket * scale).numpy(), g.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_trainer_step(global_mode):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_step_worker, args=(r, world, port, q, global_mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def _single_process_reference(global_mode):
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from oracle import sqdet_oracle as O
+    from oracle import train_oracle as TO
+    mc = O.squeezeDet_config_for_input(64, 128)
+    gh, gw = O.squeezedet_grid(64, 128)
+    rs = np.random.RandomState(77)
+    base = torch.from_numpy((rs.randn(4, gh, gw, 72)).astype(np.float32))
+    mask, delta, box, labels = TO.synthetic_labels(mc, 4, seed=78)
+
+    def grad(sl):
+        w = torch.full((72,), 1.1, requires_grad=True)
+        parts = TO.loss_graph(mc, base[sl] * w, mask[sl], delta[sl], box[sl], labels[sl])
+        return torch.autograd.grad(parts["class_loss"] + parts["conf_loss"] + parts["bbox_loss"], w)[0].numpy()
+    if global_mode:
+        return grad(slice(0, 4)), float(torch.as_tensor(mask).sum())     # the reference graph at batch 4 (nn_skeleton.py:285-327)
+    return (grad(slice(0, 2)) + grad(slice(2, 4))) / 2, None              # mean of two reference graphs at batch 2
+
+
+def test_world2_trainer_step_global_num_objects_equals_the_full_batch_graph():
+    """global_num_objects=True at world 2: num_objects all-reduce + global batch divisor + SUMMED bucket = the gradient of
+    the reference's single graph at batch world*B (round 2's bug: the confidence term came out world x too large)."""
+    import numpy as np
+    res = _run_trainer_step(True)
+    ref, nobj = _single_process_reference(True)
+    for rank, n, applied, local in res:
+        assert n == nobj
+        np.testing.assert_allclose(applied, ref, rtol=2e-5, atol=1e-7)
+    assert np.array_equal(res[0][2], res[1][2])                          # identical bits on both ranks
+    assert not np.allclose(res[0][3], res[1][3])                         # the ranks really held different shards
+
+
+def test_world2_trainer_step_replica_mean_is_the_mean_of_two_reference_graphs():
+    import numpy as np
+    res = _run_trainer_step(False)
+    ref, _ = _single_process_reference(False)
+    for rank, n, applied, local in res:
+        np.testing.assert_allclose(applied, ref, rtol=2e-5, atol=1e-7)
+    assert np.array_equal(res[0][2], res[1][2])
+
+
+def _bench(args, timeout=300):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout, r.stderr[-2000:])
+    return r.returncode, json.loads(lines[0])
+
+
+def test_bench_self_launches_n_ranks_dry_run():
+    """`python bench.py --gpus 2` with no torchrun environment (how a driver runs --gpus 1): the script re-launches itself
+    under torch.distributed.run; --dry-run skips the kernels so this runs on the CPU box.  ONE JSON line, ranks_seen = 2,
+    two distinct processes."""
+    rc, res = _bench(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"])
+    assert rc == 0 and res["dry_run"] is True and res["value"] is None
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["config"]["global_batch"] == 64
+    assert sorted(d["rank"] for d in res["devices"]) == [0, 1] and len({d["pid"] for d in res["devices"]}) == 2
+
+
+def test_bench_failures_are_one_json_line():
+    """No GPU / fewer GPUs than asked for: a one-line JSON error and a non-zero exit code, not a usage string."""
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-box behaviour")
+    rc, res = _bench(["--gpus", "8"])
+    assert rc != 0 and "error" in res and res["n_gpus"] == 8 and res["devices_visible"] == 0 and res["value"] is None
+    rc, res = _bench([])
+    assert rc != 0 and "HIP device" in res["error"]
