@@ -10,7 +10,9 @@ in which order -- can only be demanded where every decision the reference's filt
            m_iou  = min over same-class pairs of selected anchors of |IoU - NMS_THRESH|
   noise    n_p    = max |prob_gpu - prob_oracle| over all anchors
            n_iou  = max |IoU_gpu - IoU_oracle| over the same-class selected pairs
-and an image is DECIDABLE when every margin exceeds twice the matching noise.  Used by
+and an image is DECIDABLE when every margin exceeds twice the matching noise.  A pair of anchors whose scores are
+BITWISE equal on both sides (the exact background ties of the planted head, squeezedet_amd/synthetic.py) is decided by
+the tie rule (higher anchor index first) on both sides alike and does not count as a zero margin.  Used by
 tests/test_gpu_model.py::test_end_to_end_decision_margins and tools/decision_margins.py (test infrastructure)."""
 import numpy as np
 
@@ -25,8 +27,12 @@ def image_margins(mc, ref, got):
     order = O.rank_order(ref["det_probs"])
     top = p[order[:n + 1]]
     sel = order[:n]
-    m_sel = float(top[n - 1] - top[n])
-    m_ord = float(np.min(top[:-1] - top[1:]))
+    gaps = top[:-1] - top[1:]
+    gp = got["det_probs"][order[:n + 1]]
+    exact_tie = (gaps == 0) & (gp[:-1] == gp[1:])          # same bits in the oracle AND on the device: the index decides
+    gaps = np.where(exact_tie, np.inf, gaps)
+    m_sel = float(gaps[n - 1])
+    m_ord = float(np.min(gaps))
     pc = ref["pred_class_probs"][sel].astype(np.float64) * ref["pred_conf"][sel].astype(np.float64)[:, None]
     pcs = np.sort(pc, axis=1)
     m_cls = float(np.min(pcs[:, -1] - pcs[:, -2]))
@@ -46,8 +52,11 @@ def image_margins(mc, ref, got):
     return dict(m_sel=m_sel, m_ord=m_ord, m_cls=m_cls, m_iou=float(m_iou), n_p=n_p, n_iou=n_iou, decidable=bool(decidable))
 
 
-def run(size, dtype_name, nimg=16, seed=40, device="cuda:0"):
-    """Runs nimg seeded images through the device path and the oracle; returns (rows, summary)."""
+def run(size, dtype_name, nimg=16, seed=40, device="cuda:0", planted=False, batch=None, pipelined=False):
+    """Runs seeded images through the device path and the oracle; returns (rows, summary) for the first nimg.
+    planted: install the planted-object head (calibrated on two other images) on both sides.  batch: device batch
+    (>= nimg; default nimg).  pipelined: the device picks come from detect_filter_pipelined (bench.py's step) instead of
+    detect -> filter_prediction_batch."""
     import torch
 
     import squeezedet_amd as S
@@ -55,19 +64,26 @@ def run(size, dtype_name, nimg=16, seed=40, device="cuda:0"):
     tdt = torch.float16 if dtype_name == "fp16" else torch.float32
     mc = S.kitti_squeezeDet_config_for_input(*size)
     mc.LOAD_PRETRAINED_MODEL = False
-    mc.BATCH_SIZE = nimg
+    batch = batch or nimg
+    mc.BATCH_SIZE = batch
     m = nets.SqueezeDet(mc, gpu_id="0", dtype=tdt)
     params = O.init_params("squeezeDet", seed=seed, storage=dtype_name)
+    if planted:
+        params, _ = O.planted_head("squeezeDet", params, O.synthetic_images(2, size[0], size[1], seed=seed + 999, storage=dtype_name))
     m.load_params(params)
     omc = O.squeezeDet_config_for_input(*size)
-    x = O.synthetic_images(nimg, size[0], size[1], seed=seed + 1, storage=dtype_name)
+    x = O.synthetic_images(batch, size[0], size[1], seed=seed + 1, storage=dtype_name)
     xd = x.to(device, tdt)
     outs = m.run([m.det_boxes, m.det_probs, m.det_class, m.pred_class_probs, m.pred_conf], {m.image_input: xd})
-    ob, op, oc, oi, cnt = m.filter_prediction_batch(outs[0], outs[1], outs[2])
+    if pipelined:
+        ob, op, oc, oi, cnt = [t.clone() for t in m.detect_filter_pipelined(xd, to_host=True)]
+    else:
+        ob, op, oc, oi, cnt = m.filter_prediction_batch(outs[0], outs[1], outs[2])
     torch.cuda.synchronize()
-    g = [o.cpu().numpy() for o in outs]
+    g = [o.cpu().numpy()[:nimg] for o in outs]
+    ob, op, oc = ob.cpu().numpy(), op.cpu().numpy(), oc.cpu().numpy()
     oi, cnt = oi.cpu().numpy(), cnt.cpu().numpy()
-    _, ref, dets = O.detect("squeezeDet", omc, params, x, storage=dtype_name)
+    _, ref, dets = O.detect("squeezeDet", omc, params, x[:nimg], storage=dtype_name)
     rows = []
     for i in range(nimg):
         r = {k: ref[k][i] for k in ("det_boxes", "det_probs", "det_class", "pred_class_probs", "pred_conf")}
@@ -76,7 +92,10 @@ def run(size, dtype_name, nimg=16, seed=40, device="cuda:0"):
         picks_gpu = oi[i, :cnt[i]].tolist()
         picks_ref = list(dets[i][3])
         inter = len(set(picks_gpu) & set(picks_ref))
-        row.update(image=i, same_picks=picks_gpu == picks_ref, n_picks=len(picks_ref),
+        same_cls = oc[i, :cnt[i]].tolist() == [int(c) for c in dets[i][2]]
+        same_box = len(picks_gpu) == len(picks_ref) and bool(np.allclose(ob[i, :cnt[i]], np.asarray(dets[i][0], np.float32).reshape(-1, 4), rtol=2e-6, atol=0))   # decoded floats: expf ulp
+        strong = [k for k, pr in enumerate(dets[i][1]) if pr > omc.PLOT_PROB_THRESH]      # what demo.py:201-205 draws
+        row.update(image=i, same_picks=picks_gpu == picks_ref and same_cls, same_boxes=same_box, n_picks=len(picks_ref), n_strong=len(strong),
                    jaccard=inter / float(max(len(set(picks_gpu) | set(picks_ref)), 1)),
                    same_class=bool(np.array_equal(g[2][i], r["det_class"])))
         rows.append(row)

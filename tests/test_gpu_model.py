@@ -249,7 +249,30 @@ def test_end_to_end_decision_margins(size, dtype, capsys):
         assert summary["decidable"] >= 6 and summary["all_same"] >= summary["decidable"], summary
         assert summary["max_n_p"] < 2e-5, summary
     else:
-        assert summary["max_n_p"] < 1e-2 and summary["mean_jaccard"] > 0.5, summary
+        # (random-weight float16: only the noise bound -- the pick identity of the float16 path is asserted on the
+        # planted-object head below, where the decisions have margins)
+        assert summary["max_n_p"] < 1e-2, summary
+
+
+@pytest.mark.parametrize("size", [(375, 1242), (384, 1248)], ids=["375x1242", "384x1248"])
+def test_fp16_headline_path_picks_identical_planted_objects(size, capsys):
+    """The benchmarked path pinned end to end (north_star: bit-exact anchor indices / NMS picks): float16, batch 32,
+    through detect_filter_pipelined (bench.py's step: forward + decode + top-N + NMS + rows to pinned host memory), against
+    the float16-storage oracle, image -> picks.  Weights: random backbone + the planted-object head
+    (squeezedet_amd/synthetic.py: ~10-50 anchors per image score 0.58-0.91, the rest tie exactly at a background level),
+    so every decision has a margin unless a detector cell sits within float16 noise of its threshold -- those images are
+    reported undecidable by the margins and skipped.  Asserted on the decidable ones (>= 8 of the 16 compared): identical
+    anchor indices in output order, identical classes, boxes equal to 2e-6 relative (device expf against glibc's)."""
+    from tests import decision_margins as DM
+    rows, summary = DM.run(size, "fp16", nimg=16, seed=40, planted=True, batch=32, pipelined=True)
+    with capsys.disabled():
+        print("\n[planted head] " + DM.format_report(rows, summary))
+    dec = [r for r in rows if r["decidable"]]
+    assert len(dec) >= 8, summary
+    for r in dec:
+        assert r["same_picks"] and r["same_boxes"], "image %d: margins above the noise but the picks differ: %r" % (r["image"], r)
+        assert r["n_strong"] >= 3, r                       # the comparison is not vacuous: planted objects were found
+    assert summary["all_same"] >= len(dec)
 
 
 def test_zz_report_observed_errors(capsys):
