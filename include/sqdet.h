@@ -70,6 +70,17 @@ int sqdet_conv2d_nhwc_fwd(const void* x, const void* w_packed, const float* bias
                           int n, int h, int w, int cin, int cout, int k, int stride, int pad_mode, int relu,
                           int dtype, int y_cstride, int y_coffset, sqdet_stream_t stream);
 
+/* The ConvDet head (nets/squeezeDet.py:76-79: conv12, 3x3 / SAME, no ReLU) TOGETHER WITH the score half of
+ * _add_interpretation_graph (nn_skeleton.py:150-170, 274-283): preds [n,h,w,apg*(classes+5)] as sqdet_conv2d_nhwc_fwd would
+ * write them, and scores float32 [n, h*w*apg] = det_probs (max over classes of softmax(class logits) * sigmoid(confidence)),
+ * computed in the conv's epilogue from the float16-rounded preds with the float expressions of sqdet_interpret_output --
+ * bitwise the det_probs that call returns.  float16, anchors_per_grid 9, classes 3, Cin a multiple of 128 (the split-K
+ * ConvDet kernel); SQDET_EUNSUPPORTED otherwise (sqdet_convdet_scores_supported tells in advance).  Follow with
+ * sqdet_detect_filter_scored: the whole post-processing is then one 32-workgroup launch. */
+int sqdet_convdet_fwd(const void* x, const void* w_packed, const float* bias, void* preds, float* scores, int n, int h, int w,
+                      int cin, int anchors_per_grid, int classes, int dtype, sqdet_stream_t stream);
+int sqdet_convdet_scores_supported(int cin, int anchors_per_grid, int classes, int dtype);
+
 /* Residual form used by ResNet50ConvDet (nets/resnet50_convDet.py:55, `tf.nn.relu(branch1+branch2)`):
  *   y = relu?(conv2d(x, W) + b + y)   -- y holds the shortcut branch on entry, the block output on exit
  * (the branch2c 1x1 conv of a bottleneck adds its result to the shortcut in its own epilogue, so
@@ -236,6 +247,15 @@ int sqdet_detect_filter(const void* preds, const float* anchors, float* scratch_
                         float img_w, float img_h, float exp_thresh, int top_n, int max_out, double nms_thresh, int dtype,
                         sqdet_stream_t stream);
 
+/* sqdet_detect_filter with the scores already computed (sqdet_convdet_fwd / sqdet_net_set_scores: det_probs float32 [n, A]):
+ * the filter launch only.  Identical outputs.  max_workgroups > 0: the n images are walked by at most that many workgroups
+ * (<= 0: one per image) -- a serving loop that overlaps this launch with the next batch's forward sizes it to the CUs that
+ * forward leaves idle (16 during SqueezeDet's fire6..fire11 launches at batch 32). */
+int sqdet_detect_filter_scored(const void* preds, const float* anchors, const float* scores, float* out_boxes, float* out_probs,
+                               int32_t* out_cls, int32_t* out_index, int32_t* out_count, int n, int gh, int gw, int apg,
+                               int classes, float img_w, float img_h, float exp_thresh, int top_n, int max_out,
+                               double nms_thresh, int dtype, int max_workgroups, sqdet_stream_t stream);
+
 /* ------------------------------------------------------------ training --
  * Replaces the gradient half of the reference's TF graph for the trainable convs (stride 1,
  * SAME: every conv but the frozen conv1, nets/squeezeDet.py:40-42), the loss graph
@@ -378,6 +398,31 @@ int sqdet_net_output_dims(const sqdet_net_t* net, int* gh, int* gw, int* channel
 /* image_input: [batch,img_h,img_w,3] (dtype storage, BGR mean-subtracted:
  * demo.py:187-190) -> preds [batch,gh,gw,channels] (dtype storage). */
 int sqdet_net_forward(sqdet_net_t* net, const void* image_input, void* preds, sqdet_stream_t stream);
+/* Binds (NULL: unbinds) a float32 [batch, gh*gw*anchors_per_grid] device buffer: every following sqdet_net_forward also
+ * writes interpret_output's det_probs there, from the ConvDet launch's epilogue (see sqdet_convdet_fwd).
+ * SQDET_EUNSUPPORTED when the plan's last layer has no score epilogue (sqdet_net_scores_supported). */
+int sqdet_net_set_scores(sqdet_net_t* net, float* scores);
+int sqdet_net_scores_supported(const sqdet_net_t* net);
+/* Serving-loop hook: every following sqdet_net_forward records `hip_event` (a hipEvent_t; NULL: none) on its stream right
+ * before the launch of layer `layer_index` -- side work of the PREVIOUS batch (its filter launch, the copy of its rows) that
+ * waits for the event on another stream then runs beside the launches behind that point instead of beside the stem.
+ * sqdet_net_overlap_layer: the index where side work is cheapest -- the first fire_chain launch (those launches occupy 240
+ * of the 256 CUs at batch 32) -- or -1 when the plan has none. */
+int sqdet_net_set_signal(sqdet_net_t* net, int layer_index, void* hip_event);
+int sqdet_net_overlap_layer(const sqdet_net_t* net);
+/* Serving loop without a second stream: the decode + filter of the PREVIOUS batch (what sqdet_detect_filter_scored would
+ * launch: same arguments, identical outputs) is handed to the plan and rides in the NEXT sqdet_net_forward as extra "rider"
+ * workgroups of its fire_chain launches -- those occupy 240 of the 256 CUs at batch 32, a rider takes an idle CU and one
+ * image.  No side stream, no events, no extra launches: stream order alone orders the previous batch's preds / scores
+ * (written by its ConvDet launch) before the riders and the riders before the next overwrite.  The out_* rows may be
+ * pinned host memory (device-accessible): the rows then need no copy either.  One-shot (consumed by the next forward;
+ * preds == NULL cancels).  SQDET_EUNSUPPORTED when the plan cannot carry n images (sqdet_net_rider_capacity: the idle CUs
+ * summed over its fire_chain launches; 0 for plans without such launches) -- run sqdet_detect_filter_scored instead. */
+int sqdet_net_set_post_job(sqdet_net_t* net, const void* preds, const float* scores, const float* anchors, float* out_boxes,
+                           float* out_probs, int32_t* out_cls, int32_t* out_index, int32_t* out_count, int n, int gh, int gw,
+                           int apg, int classes, float img_w, float img_h, float exp_thresh, int top_n, int max_out,
+                           double nms_thresh, int dtype);
+int sqdet_net_rider_capacity(const sqdet_net_t* net);
 
 /* Layer table for measurement: name, 2*MAC flops and algorithmic bytes (every
  * tensor touched once) of each launch of sqdet_net_forward. */

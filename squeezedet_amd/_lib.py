@@ -47,6 +47,15 @@ SIGNATURES = {
     "sqdet_interpret_output": (ci, [vp] * 7 + [ci] * 5 + [cf, cf, cf, ci, vp]),
     "sqdet_filter_prediction": (ci, [vp] * 8 + [ci] * 5 + [cd, cf, vp]),
     "sqdet_detect_filter": (ci, [vp] * 8 + [ci] * 5 + [cf, cf, cf, ci, ci, cd, ci, vp]),
+    "sqdet_detect_filter_scored": (ci, [vp] * 8 + [ci] * 5 + [cf, cf, cf, ci, ci, cd, ci, ci, vp]),
+    "sqdet_net_set_signal": (ci, [vp, ci, vp]),
+    "sqdet_net_set_post_job": (ci, [vp] * 9 + [ci] * 5 + [cf, cf, cf, ci, ci, cd, ci]),
+    "sqdet_net_rider_capacity": (ci, [vp]),
+    "sqdet_net_overlap_layer": (ci, [vp]),
+    "sqdet_convdet_fwd": (ci, [vp] * 5 + [ci] * 7 + [vp]),
+    "sqdet_convdet_scores_supported": (ci, [ci] * 4),
+    "sqdet_net_set_scores": (ci, [vp, vp]),
+    "sqdet_net_scores_supported": (ci, [vp]),
     "sqdet_conv_pack_weights_bwd_data": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "sqdet_conv2d_nhwc_bwd_data": (ci, [vp, vp, vp] + [ci] * 10 + [vp]),
     "sqdet_conv2d_nhwc_bwd_data_relu": (ci, [vp, vp, vp, vp] + [ci] * 10 + [vp]),
@@ -108,12 +117,22 @@ def lib():
             raise SqdetError(
                 "libsqdet_hip.so not found at %s -- build it with `python -m squeezedet_amd.build` "
                 "(there is no CPU fallback)" % LIB_PATH)
+        # ONE HIP runtime per process: torch ships its own libamdhip64 / libhsa-runtime64, and the device pointers this
+        # library is handed come from torch's.  Loaded before torch, libsqdet_hip.so would bind to the system copy under
+        # /opt/rocm -- a second runtime that sees no device ("HIP error 100" at the first launch).  With torch imported
+        # first the dynamic linker resolves the same sonames to the copy already in the process.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError = library/header mismatch: fail loudly
             fn.restype = res
             fn.argtypes = args
         _lib = l
+        # SQDET_OPTIONS="dbg=200,stem_algo=2": tuning knobs (sqdet_set_option) for A/B runs of unmodified callers (bench.py)
+        for kv in filter(None, os.environ.get("SQDET_OPTIONS", "").split(",")):
+            k, _, v = kv.partition("=")
+            if l.sqdet_set_option(k.strip().encode(), int(v)) != SQDET_OK:
+                raise SqdetError("SQDET_OPTIONS: unknown option %r" % kv)
     return _lib
 
 

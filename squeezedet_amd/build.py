@@ -23,7 +23,8 @@ SOURCES = [
     ("conv.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("conv3x3.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     # the ConvDet split-K kernel needs > 256 registers: accumulators in AGPRs (hipcc's default form), see convdet.hip
-    ("convdet.hip", []),
+    # (-ffp-contract=off: its score epilogue shares postproc.h's float expressions with filter_fast.hip, bit for bit)
+    ("convdet.hip", ["-ffp-contract=off"]),
     ("conv1x1.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("gemm1x1.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("stem.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
@@ -31,7 +32,8 @@ SOURCES = [
     ("stem3.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("fire.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("fire2.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
-    ("chain.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    # (-ffp-contract=off: its rider workgroups run filter_body.h's decode / IoU arithmetic, bit-exact by contract)
+    ("chain.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-ffp-contract=off"]),
     ("pool.hip", []),
     ("bn.hip", ["-ffp-contract=off"]),
     ("preproc.hip", ["-ffp-contract=off"]),

@@ -27,6 +27,8 @@
 // Accumulation orders are those of conv3x3_tile / conv1x1_stream / fire_fused (chunk-major, tap-minor; squeeze
 // chunks ascending), so the result is bitwise the three-launch path's.
 #include "conv_common.h"
+#include "chain.h"
+#include "filter_body.h"
 
 namespace sqdet {
 
@@ -65,6 +67,10 @@ struct ChainArgs {
   int tiles_x, tiles_y;
   int nb1, nb3, nstages;
   unsigned in_bytes, out_bytes, y_bytes;
+  // RIDERS (chain.h): workgroups behind the `per_xcd` chain slots of every XCD that run filter_prediction's top-N branch
+  // for images of the PREVIOUS batch instead of a tile
+  int per_xcd;             // chain workgroups per XCD (grid = 8 * (per_xcd + riders per XCD))
+  ChainRide ride;
 };
 
 // One 1-KiB piece of the weight stream straight into LDS (no registers): global address = wave-uniform `sbase` +
@@ -112,7 +118,19 @@ __global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
   const int pg = wave & 3, h = wave >> 2;
   const int j = lane & 15, g = lane >> 4;
 
-  int b = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));   // XCD-banded order (gridDim.x % 8 == 0)
+  if ((int)(blockIdx.x >> 3) >= a.per_xcd) {
+    // ---- RIDER: this workgroup sits on a CU the launch would leave idle (240 chain workgroups on 256 CUs at batch 32) and
+    // does the decode + top-N + NMS of image(s) of the PREVIOUS batch (filter_body.h), straight into the caller's output
+    // rows (pinned host memory in the serving loop).  No side stream, no events, no extra launch: see chain.h.
+    const int rider = (int)((blockIdx.x >> 3) - a.per_xcd) * 8 + (int)(blockIdx.x & 7);
+    FastLds<512>& fs = *reinterpret_cast<FastLds<512>*>(lds);
+    for (int im = rider; im < a.ride.nimg; im += a.ride.nriders) {
+      filter_one_image<true, f16, 512>(a.ride.fa, a.ride.da, a.ride.img0 + im, fs);
+      __syncthreads();
+    }
+    return;
+  }
+  int b = (int)((blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3));   // XCD-banded order
   const int npairs = (a.N + 1) >> 1;
   if (b >= npairs * a.tiles_x * a.tiles_y) return;
   const int tx = b % a.tiles_x; b /= a.tiles_x;
@@ -766,7 +784,11 @@ int launch_chain(const ChainArgs& a, hipStream_t st) {
     attr_done = true;
   }
   const int wgs = ((a.N + 1) / 2) * a.tiles_x * a.tiles_y;
-  const dim3 grid((unsigned)((wgs + 7) / 8 * 8));
+  ChainArgs& am = const_cast<ChainArgs&>(a);
+  am.per_xcd = (wgs + 7) / 8;
+  const int riders_per_xcd = a.ride.nimg > 0 ? (a.ride.nriders + 7) / 8 : 0;
+  const dim3 grid((unsigned)(8 * (am.per_xcd + riders_per_xcd)));
+  static_assert(sizeof(FastLds<512>) <= RG * STAGE_B, "the rider's state lives in the ring's LDS");
 #ifdef SQDET_CHAIN_DBG   // experiment builds only (tools/chainbench.py --dbg): cost ladder of the fire10 -> fire11 shape
   if constexpr (NCH == 3 && NSQ == 6 && !WY) {
     const int d = tune(TUNE_DBG);
@@ -859,6 +881,24 @@ extern "C" int sqdet_fire_chain_pack(const float* w_e1_hwio, const float* w_e3_h
 extern "C" int sqdet_fire_chain_fwd(const void* sq_in, const void* stream_buf, const float* b_e1, const float* b_e3,
                                     const float* b_next_s, void* y, void* sq_out, int n, int h, int w, int s1x1,
                                     int e1x1, int e3x3, int next_s1x1, int dtype, sqdet_stream_t stream) {
+  return sqdet::fire_chain_launch_ride(sq_in, stream_buf, b_e1, b_e3, b_next_s, y, sq_out, n, h, w, s1x1, e1x1, e3x3, next_s1x1, dtype,
+                                       nullptr, as_stream(stream));
+}
+
+int sqdet::fire_chain_idle_cus(int n, int h, int w, int s1x1, int e1x1, int e3x3, int next_s1x1, int dtype) {
+  if (!fire_chain_eligible(s1x1, e1x1, e3x3, next_s1x1, dtype)) return 0;
+  const ChainGeom g = chain_geom(s1x1, e1x1, e3x3, next_s1x1);
+  const long px = (long)n * h * w;
+  if (g.nch == 1 && px > 100000) return 0;                       // (the persistent form fills every CU)
+  const int wgs = ((n + 1) / 2) * ((w + CCOLS - 1) / CCOLS) * ((h + CROWS - 1) / CROWS);
+  const int per = (wgs + 7) / 8;
+  return per < 32 ? (32 - per) * 8 : 0;                          // one chain workgroup per CU (its LDS), 32 CUs per XCD
+}
+
+int sqdet::fire_chain_launch_ride(const void* sq_in, const void* stream_buf, const float* b_e1, const float* b_e3,
+                                  const float* b_next_s, void* y, void* sq_out, int n, int h, int w, int s1x1,
+                                  int e1x1, int e3x3, int next_s1x1, int dtype, const ChainRide* ride, hipStream_t st_in) {
+  const sqdet_stream_t stream = reinterpret_cast<sqdet_stream_t>(st_in);
   SQDET_REQUIRE(sq_in && stream_buf && b_e1 && b_e3, "fire_chain_fwd: null pointer");
   SQDET_REQUIRE(n > 0 && h > 0 && w > 0, "fire_chain_fwd: bad dims");
   SQDET_REQUIRE((next_s1x1 > 0) == (sq_out != nullptr) && (next_s1x1 == 0 || b_next_s), "fire_chain_fwd: sq_out / next_s1x1 mismatch");
@@ -876,10 +916,13 @@ extern "C" int sqdet_fire_chain_fwd(const void* sq_in, const void* stream_buf, c
   a.in_bytes = (unsigned)(px * s1x1 * 2);
   a.out_bytes = (unsigned)(px * next_s1x1 * 2);
   a.y_bytes = (unsigned)(px * (e1x1 + e3x3) * 2);
+  a.per_xcd = 0;
+  if (ride) a.ride = *ride; else { a.ride = ChainRide{}; a.ride.nimg = 0; a.ride.nriders = 0; a.ride.img0 = 0; }
   hipStream_t st = as_stream(stream);
   // large maps with a one-chunk squeeze: the persistent, weights-resident form ("dbg" 30 keeps the ring kernel for
   // A/B, 31 takes the persistent form at any size -- tests)
   if (!y && g.nch == 1 && (px > 100000 || tune(TUNE_DBG) == 31) && fire_chain_stream_shape(s1x1, e1x1, e3x3, next_s1x1) && tune(TUNE_DBG) != 30) {
+    SQDET_REQUIRE(a.ride.nimg == 0, "fire_chain: the persistent form carries no riders");
     ChainSArgs c;
     c.sq_in = sq_in; c.sq_out = sq_out; c.stream = a.stream; c.b1 = b_e1; c.b3 = b_e3; c.bs2 = b_next_s;
     c.N = n; c.H = h; c.W = w; c.S = s1x1; c.E1 = e1x1; c.E3 = e3x3; c.S2 = next_s1x1;

@@ -339,6 +339,7 @@ int conv2d_launch_masked(const void* x, const void* w_packed, const float* bias,
   a.y_cstride = y_cstride; a.y_coffset = y_coffset; a.relu = relu;
   a.x_cstride = x_cstride; a.x_coffset = x_coffset; a.accum = accum;
   a.relu_of = relu_of;
+  a.scores = nullptr; a.score_apg = 0; a.score_classes = 0;
   const bool plain = x_cstride == cin && x_coffset == 0 && !accum && bias != nullptr && !relu_of;
   SQDET_UNSUPPORTED(!plain && g.gather, "conv2d: channel-sliced / accumulating convs need Cin %% %d == 0", kg_);
   bool handled = false;
@@ -358,6 +359,36 @@ int conv2d_launch_masked(const void* x, const void* w_packed, const float* bias,
   rc = dtype == SQDET_F16 ? dispatch_mt<f16>(a, g.nt, g.gather, st) : dispatch_mt<float>(a, g.nt, g.gather, st);
   if (rc != SQDET_OK) return rc;
   SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
+// ConvDet + the score half of interpret_output in one launch (convdet.hip SCORE form): preds = conv3x3/SAME(x) + bias (no
+// ReLU), scores[n, h*w*apg] = det_probs.  UNSUPPORTED unless the split-K ConvDet kernel takes the shape in float16.
+int convdet_scored_launch(const void* x, const void* w_packed, const float* bias, void* preds, float* scores, int n, int h, int w,
+                          int cin, int apg, int classes, int dtype, hipStream_t st) {
+  SQDET_REQUIRE(x && w_packed && bias && preds && scores, "convdet: null pointer");
+  SQDET_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && apg > 0 && classes > 0, "convdet: bad dims");
+  const int cout = apg * (classes + 5);
+  SQDET_UNSUPPORTED(conv_algo() != 0 || !convdet_score_supported(cout, apg, classes, dtype),
+                    "convdet: the score epilogue needs float16, 9 anchors x (3 classes + 5) and conv_algo = auto");
+  const ConvGeom g = conv_geom(3, cin, cout, dtype);
+  SQDET_UNSUPPORTED(g.gather || !(g.nt == 5 && g.ngroups == 1 && g.nchunk >= 8 && g.nchunk % 4 == 0),
+                    "convdet: Cin %d is not a split-K ConvDet shape", cin);
+  ConvArgs a;
+  a.x = x; a.wp = w_packed; a.bias = bias; a.y = preds;
+  a.N = n; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout; a.k = 3; a.stride = 1;
+  a.pt = 1; a.pl = 1; a.Ho = h; a.Wo = w;
+  const long P = (long)n * h * w;
+  SQDET_UNSUPPORTED(P > (1L << 30), "convdet: more than 2^30 pixels");
+  a.P = (int)P; a.ntiles = 0;
+  a.nchunk = g.nchunk; a.steps = g.steps; a.ngroups = g.ngroups;
+  a.y_cstride = cout; a.y_coffset = 0; a.relu = 0;
+  a.x_cstride = cin; a.x_coffset = 0; a.accum = 0; a.relu_of = nullptr;
+  a.scores = scores; a.score_apg = apg; a.score_classes = classes;
+  bool handled = false;
+  const int rc = conv3x3_tile_launch(a, g, dtype, st, &handled);
+  if (rc != SQDET_OK) return rc;
+  SQDET_UNSUPPORTED(!handled, "convdet: the split-K kernel did not take this shape");
   return SQDET_OK;
 }
 
@@ -427,6 +458,18 @@ extern "C" int sqdet_conv2d_nhwc_fwd(const void* x, const void* w_packed, const 
                                      int y_cstride, int y_coffset, sqdet_stream_t stream) {
   return conv2d_launch(x, w_packed, bias, y, n, h, w, cin, cout, k, stride, pad_mode, relu, dtype, y_cstride,
                        y_coffset, as_stream(stream));
+}
+
+extern "C" int sqdet_convdet_fwd(const void* x, const void* w_packed, const float* bias, void* preds, float* scores, int n, int h,
+                                 int w, int cin, int anchors_per_grid, int classes, int dtype, sqdet_stream_t stream) {
+  return convdet_scored_launch(x, w_packed, bias, preds, scores, n, h, w, cin, anchors_per_grid, classes, dtype, as_stream(stream));
+}
+
+extern "C" int sqdet_convdet_scores_supported(int cin, int anchors_per_grid, int classes, int dtype) {
+  const int cout = anchors_per_grid * (classes + 5);
+  if (conv_algo() != 0 || !convdet_score_supported(cout, anchors_per_grid, classes, dtype)) return 0;
+  const ConvGeom g = conv_geom(3, cin, cout, dtype);
+  return (!g.gather && g.nt == 5 && g.ngroups == 1 && g.nchunk >= 8 && g.nchunk % 4 == 0) ? 1 : 0;
 }
 
 extern "C" int sqdet_conv2d_add_nhwc_fwd(const void* x, const void* w_packed, const float* bias, void* y_inout, int n,

@@ -92,6 +92,7 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
       grid_y = (g.ngroups + wc - 1) / wc;
     }
   }
+  if (c.scores && !splitk) return SQDET_OK;   // only the ConvDet kernel has the score epilogue (the caller reports UNSUPPORTED)
   const bool ok = dtype == SQDET_F16 ? dispatch_tile<f16>(a, mt, ntw, splitk, grid_y, lds, st)
                                      : dispatch_tile<float>(a, mt, ntw, splitk, grid_y, lds, st);
   if (!ok) return SQDET_OK;

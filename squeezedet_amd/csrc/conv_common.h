@@ -40,6 +40,11 @@ struct ConvArgs {
   // backward-data only: the result is the gradient w.r.t. a ReLU OUTPUT r (same layout as y); it is zeroed where r <= 0 --
   // the ReLU backward of the layer below, taken in this conv's epilogue instead of a separate pass over the tensor
   const void* relu_of;
+  // ConvDet only (convdet.hip, float16): when not NULL, the epilogue also writes one float32 SCORE per anchor --
+  // det_probs of interpret_output (nn_skeleton.py:150-170, 274-283) computed from the float16-rounded preds it stores --
+  // to scores[N, H*W*score_apg]; Cout = score_apg * (score_classes + 5), score_classes == 3
+  float* scores;
+  int score_apg, score_classes;
 };
 
 template <typename T>
@@ -110,6 +115,10 @@ int fire_expand_squeeze_next_launch(const void* sq_in, const void* w1, const flo
                                     const void* ws2, const float* bs2, void* s_out, int n, int h, int w, int s, int e1, int e3,
                                     int s2, int pool, int dtype, hipStream_t st, bool* handled);
 int conv3x3_tile_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);
+// convdet.hip: the score epilogue's shapes; conv.hip: ConvDet + scores in one launch (sqdet_convdet_fwd)
+bool convdet_score_supported(int cout, int apg, int classes, int dtype);
+int convdet_scored_launch(const void* x, const void* w_packed, const float* bias, void* preds, float* scores, int n, int h, int w,
+                          int cin, int apg, int classes, int dtype, hipStream_t st);
 int conv1x1_stream_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);
 int conv1x1_tile_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);   // gemm1x1.hip
 

@@ -44,6 +44,7 @@
 // 61.2 on the same box.  float32: issuing the four K = 4 MFMAs of a
 // fragment pair kk-outermost (independent accumulators back to back) is 8 % SLOWER (551 us against 510).
 #include "conv3x3_tile.h"
+#include "postproc.h"
 
 namespace sqdet {
 
@@ -57,11 +58,21 @@ __device__ unsigned long long g_cd_timing[2048 * 8];
 
 constexpr int CD_SLOT = 2 * 5 * 1024;                 // reduce-scatter: one (owner, source) slot = 2 rows x 5 tiles
 constexpr int CD_LDS = 12 * CD_SLOT;                  // 122880 B (> the 46080 B of a staged input stage)
+// SCORE form: behind the reduction slots, per wave, the float16-rounded preds channels [0, 40) of the wave's 2 x 16 pixels
+// (class logits 0..26, confidences 27..35; 80 B per pixel) -- the exchange area of the score pass
+constexpr int CD_SC_PIX = 80, CD_SC_WAVE = 2 * 16 * CD_SC_PIX, CD_SC_LDS = 4 * CD_SC_WAVE;
 
 // PERS = false (float32: the persistent form does not fit the register file without spilling inside the tap loop): one tile
 // per workgroup, nothing is prefetched across tiles
-template <typename T, bool PERS>
+// SCORE (float16, Cout = 9 * (3 + 5) = 72: the reference's head): the epilogue also computes interpret_output's det_probs for the
+// tile's 128 x 9 anchors from the float16-ROUNDED preds it stores -- score_from_logits (postproc.h), the very function the
+// stand-alone score kernel and the filter kernel use, so the picks stay bit-exact -- and writes them as float32: the
+// post-processing that follows is the 32 filter workgroups only (no second pass over preds, no 2100-workgroup launch on the
+// side stream competing with the next forward's stem).  Per wave: its 2 rows x 16 pixels x 9 anchors = 288 scores, 4.5 per
+// lane; a lane's anchor needs values of lane groups 0 and 1 of its pixel (couts 0..19 / 20..39), hence the LDS bounce.
+template <typename T, bool PERS, bool SCORE = false>
 __global__ __launch_bounds__(256) void convdet_kernel(TileArgs a, int ntiles, int per_xcd) {
+  static_assert(!SCORE || sizeof(T) == 2, "the score epilogue is float16 only");
   constexpr int MT = 8, NTW = 5;
   constexpr int NSV = (HP * 16 + 255) / 256;   // 16-byte pieces per thread per stage = 12 (the last one partial)
   static_assert(NSV == 12, "two pieces per tap over six taps");
@@ -233,6 +244,8 @@ __global__ __launch_bounds__(256) void convdet_kernel(TileArgs a, int ntiles, in
     __syncthreads();  // all waves are done reading the input tile (the buffer is reused)
     int l16 = lane * 16;
     asm volatile("" : "+v"(l16));   // the slot addresses are recomputed per tile: hoisted out of the tile loop they were spilled
+    int lz = lane;
+    asm volatile("" : "+v"(lz));    // (SCORE: the same for the exchange-area addresses)
     auto slot_of = [&](int owner, int src) { return lds + (owner * 3 + (src < owner ? src : src - 1)) * CD_SLOT + l16; };
     auto scatter = [&](auto oc) {   // this wave's partials of owner oc's rows
       constexpr int o = decltype(oc)::value;
@@ -286,12 +299,49 @@ __global__ __launch_bounds__(256) void convdet_kernel(TileArgs a, int ntiles, in
           }
         }
         store_couts<T, NTW>(dst, v, nt_valid);
+        if constexpr (SCORE) {
+          // (address from the per-tile laundered lane id: hoisted out of the tile loop it was spilled, and a scratch
+          // reload in the reduction waits for the whole in-order vmcnt queue, i.e. for the next tile's prefetched input)
+          const int j2 = lz & 15, g2 = lz >> 4;
+          if (g2 < 2) {    // channels [20g, 20g + 20) of pixel (row mm, column j), rounded as stored
+            unsigned char* sp = lds + CD_LDS + o * CD_SC_WAVE + (mm * 16 + j2) * CD_SC_PIX + g2 * 40;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+              const f16x4 h = {(f16)v[t][0], (f16)v[t][1], (f16)v[t][2], (f16)v[t][3]};
+              *reinterpret_cast<f16x4*>(sp + t * 8) = h;
+            }
+          }
+        }
       }
     };
     gather(std::integral_constant<int, 0>{});
     gather(std::integral_constant<int, 1>{});
     gather(std::integral_constant<int, 2>{});
     gather(std::integral_constant<int, 3>{});
+    if constexpr (SCORE) {
+      // this wave's LDS writes above are complete before its reads below (same wave: one in-order LDS queue; the wait makes
+      // the data visible to the OTHER lanes' reads)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned char* sw = lds + CD_LDS + wave * CD_SC_WAVE;
+      const int cells = a.c.H * a.c.W;
+      int l2 = lz;                      // nothing of the 5 iterations' index arithmetic is hoisted out of the tile loop
+#pragma unroll 1
+      for (int it = 0; it < 5; ++it) {
+        const int idx = it * 64 + l2;                       // (row mm, pixel px, anchor k) = idx / 144, (idx % 144) / 9, idx % 9
+        const int mm = idx >= 144 ? 1 : 0;
+        const int r = idx - mm * 144;
+        const int px = (int)(__umul24((unsigned)r, 57u) >> 9);   // r / 9 for r < 144
+        const int k = r - px * 9;
+        const int oy = coy0 + wave * MO + mm, oxx = cox0 + px;
+        if (idx < 288 && oy < a.c.H && oxx < a.c.W) {
+          const f16* hp = reinterpret_cast<const f16*>(sw + (mm * 16 + px) * CD_SC_PIX);
+          const float lg[3] = {(float)hp[3 * k], (float)hp[3 * k + 1], (float)hp[3 * k + 2]};
+          int bc;
+          const float sc = score_from_logits(lg, 3, (float)hp[27 + k], &bc);
+          a.c.scores[((size_t)cn * cells + (size_t)oy * a.c.W + oxx) * 9 + k] = sc;
+        }
+      }
+    }
     CT_MARK(6);
     if (!PERS || !has_next) break;
     tl += nslot; cn = nn; coy0 = noy0; cox0 = nox0; mask_cur = mask_next;
@@ -304,20 +354,32 @@ __global__ __launch_bounds__(256) void convdet_kernel(TileArgs a, int ntiles, in
 #endif
 }
 
-template <typename T, bool PERS>
+template <typename T, bool PERS, bool SCORE = false>
 static void convdet_launch(const TileArgs& a, hipStream_t st) {
   static bool lds_ok = false;   // > 64 KiB of dynamic LDS has to be allowed once per kernel
   if (!lds_ok) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convdet_kernel<T, PERS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convdet_kernel<T, PERS, SCORE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     lds_ok = true;
   }
   const int ntiles = a.c.N * a.tiles_x * a.tiles_y;
   const int per_xcd = (ntiles + 7) / 8;
   const int slots = (!PERS || per_xcd < 32) ? per_xcd : 32;   // persistent: one workgroup per CU, 32 CUs per XCD
-  hipLaunchKernelGGL((convdet_kernel<T, PERS>), dim3((unsigned)(slots * 8)), dim3(256), CD_LDS, st, a, ntiles, per_xcd);
+  hipLaunchKernelGGL((convdet_kernel<T, PERS, SCORE>), dim3((unsigned)(slots * 8)), dim3(256), CD_LDS + (SCORE ? CD_SC_LDS : 0), st, a, ntiles, per_xcd);
+}
+
+bool convdet_score_supported(int cout, int apg, int classes, int dtype) {
+  return dtype == SQDET_F16 && apg == 9 && classes == 3 && cout == apg * (classes + 5);
 }
 
 int convdet_tile_launch(const TileArgs& a, int dtype, hipStream_t st) {
+  if (a.c.scores) {
+    if (!convdet_score_supported(a.c.Cout, a.c.score_apg, a.c.score_classes, dtype) || a.c.relu) {
+      set_error("convdet: the score epilogue needs float16, 9 anchors x (3 classes + 5) = 72 couts, no ReLU");
+      return SQDET_EUNSUPPORTED;
+    }
+    convdet_launch<f16, true, true>(a, st);
+    return SQDET_OK;
+  }
   if (dtype == SQDET_F16) convdet_launch<f16, true>(a, st);
   else convdet_launch<float, false>(a, st);
   return SQDET_OK;

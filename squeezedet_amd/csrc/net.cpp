@@ -3,12 +3,14 @@
 // src/nets/squeezeDet.py:30-79, src/nets/squeezeDetPlus.py:30-79, src/nets/resnet50_convDet.py:31-169).
 // It owns no device memory: packed parameters and the activation workspace are bound by the
 // caller (sqdet_net_bind).
+#include <math.h>
 #include <string.h>
 
 #include <string>
 #include <vector>
 
 #include "common.h"
+#include "chain.h"
 
 namespace sqdet {
 int conv2d_launch(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
@@ -17,6 +19,8 @@ int conv2d_launch(const void* x, const void* w_packed, const float* bias, void* 
 int conv2d_launch_ex(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
                      int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
                      int x_cstride, int x_coffset, int accum, hipStream_t st);
+int convdet_scored_launch(const void* x, const void* w_packed, const float* bias, void* preds, float* scores, int n, int h, int w,
+                          int cin, int apg, int classes, int dtype, hipStream_t st);
 int fold_bn_launch(const float* w, const float* cbias, const float* gamma, const float* beta, const float* mean,
                    const float* var, float eps, float* wf, float* bf, int k, int cin, int cout, hipStream_t st);
 int maxpool_launch(const void* x, void* y, int n, int h, int w, int c, int k, int stride, int pad_mode, int dtype,
@@ -128,6 +132,17 @@ struct sqdet_net {
   int probe_layer = -1;
   int probe_count = 0;
   std::vector<hipEvent_t> probe_events;  // 2 per record
+  // sqdet_net_set_scores: when not NULL the ConvDet launch (last layer) also writes interpret_output's det_probs there
+  float* scores = nullptr;
+  // sqdet_net_set_post_job: the previous batch's decode + filter, carried by the NEXT forward's fire_chain launches as rider
+  // workgroups (chain.h); one-shot
+  bool job_set = false;
+  sqdet::FilterArgs job_fa;
+  sqdet::DecodeArgs job_da;
+  int job_n = 0;
+  // sqdet_net_set_signal: an event recorded right before layer signal_layer's launch
+  int signal_layer = -1;
+  hipEvent_t signal_event = nullptr;
 };
 
 namespace {
@@ -294,6 +309,14 @@ void* buf_ptr(const sqdet_net* net, int buf, const void* input, void* preds) {
 
 // Runs layer L on images [n0, n0 + nb) of the batch (activations are NHWC with the image index outermost, so a
 // sub-batch is a pointer offset).
+// riders one fire_chain launch takes: its idle CUs ("dbg" 300 + k caps it at k -- experiments)
+int layer_riders(const sqdet_net* net, const Layer& L) {
+  int idle = sqdet::fire_chain_idle_cus(net->batch, L.h, L.w, L.fs, L.fe1, L.fe3, L.fs2, net->dtype);
+  const int d = sqdet::tune(5);
+  if (d >= 300 && d < 400 && idle > d - 300) idle = d - 300;
+  return idle;
+}
+
 int run_layer_part(sqdet_net* net, const Layer& L, const void* input, void* preds, int n0, int nb, hipStream_t st) {
   const size_t esz = dtype_size(net->dtype);
   if (L.type == L_CHAIN) {
@@ -301,9 +324,27 @@ int run_layer_part(sqdet_net* net, const Layer& L, const void* input, void* pred
     const char* sq_in = reinterpret_cast<const char*>(buf_ptr(net, L.in_buf, input, preds)) + px0 * L.fs * esz;
     char* out = reinterpret_cast<char*>(buf_ptr(net, L.out_buf, input, preds)) + px0 * (L.fs2 > 0 ? L.fs2 : L.fe1 + L.fe3) * esz;
     auto pb = [&](int i) { return i >= 0 ? reinterpret_cast<const float*>(net->param_mem + net->params[i].offset) : nullptr; };
-    return sqdet_fire_chain_fwd(sq_in, net->param_mem + L.chain_off, pb(L.bp_1), pb(L.bp_3), pb(L.bp_s2),
-                                L.fs2 > 0 ? nullptr : out, L.fs2 > 0 ? out : nullptr, nb, L.h, L.w, L.fs, L.fe1, L.fe3, L.fs2,
-                                net->dtype, reinterpret_cast<sqdet_stream_t>(st));
+    // riders: the pending job's images are dealt over the plan's fire_chain launches from the LAST one backwards (the late
+    // launches are the long ones), one image per idle CU and launch
+    sqdet::ChainRide ride;
+    const sqdet::ChainRide* rp = nullptr;
+    if (net->job_set && n0 == 0 && nb == net->batch) {
+      const int idle = layer_riders(net, L);
+      int later = 0;      // images taken by the chain launches behind this one
+      for (size_t i = net->layers.size(); i-- > 0 && &net->layers[i] != &L;)
+        if (net->layers[i].type == L_CHAIN) later += layer_riders(net, net->layers[i]);
+      const int left = net->job_n - later;
+      if (idle > 0 && left > 0) {
+        ride.fa = net->job_fa; ride.da = net->job_da;
+        ride.nimg = left < idle ? left : idle;
+        ride.img0 = left - ride.nimg;
+        ride.nriders = ride.nimg;
+        rp = &ride;
+      }
+    }
+    return sqdet::fire_chain_launch_ride(sq_in, net->param_mem + L.chain_off, pb(L.bp_1), pb(L.bp_3), pb(L.bp_s2),
+                                         L.fs2 > 0 ? nullptr : out, L.fs2 > 0 ? out : nullptr, nb, L.h, L.w, L.fs, L.fe1, L.fe3, L.fs2,
+                                         net->dtype, rp, st);
   }
   if (L.type == L_FIRESQ) {
     const char* xin = reinterpret_cast<const char*>(buf_ptr(net, L.in_buf, input, preds)) + (size_t)n0 * L.h * L.w * L.cin * esz;
@@ -353,6 +394,9 @@ int run_layer_part(sqdet_net* net, const Layer& L, const void* input, void* pred
     const void* wp = net->param_mem + net->params[L.kparam].offset;
     const float* b = reinterpret_cast<const float*>(
         net->param_mem + (L.fold >= 0 ? net->folds[L.fold].fbias_off : net->params[L.bparam].offset));
+    if (net->scores && &L == &net->layers.back())   // (validated by sqdet_net_set_scores)
+      return convdet_scored_launch(x, wp, b, y, net->scores + (size_t)n0 * L.h * L.w * net->apg, nb, L.h, L.w, L.cin, net->apg,
+                                   net->classes, net->dtype, st);
     return conv2d_launch_ex(x, wp, b, y, nb, L.h, L.w, L.cin, L.cout, L.k, L.stride, L.pad_mode, L.relu,
                             net->dtype, L.y_cstride, L.y_coffset, L.cin, 0, L.accum, st);
   }
@@ -831,9 +875,78 @@ extern "C" int sqdet_net_forward(sqdet_net_t* net, const void* image_input, void
     return SQDET_OK;
   };
   for (int i = 0; i < nl; ++i) {
+    if (i == net->signal_layer && net->signal_event) SQDET_CHECK_HIP(hipEventRecord(net->signal_event, st));
     const int rc = one(i, 0, net->batch, st);
-    if (rc != SQDET_OK) return rc;
+    if (rc != SQDET_OK) { net->job_set = false; return rc; }
   }
+  net->job_set = false;      // (one-shot: its riders went out with this forward's fire_chain launches)
+  return SQDET_OK;
+}
+
+static int net_rider_capacity(const sqdet_net* net) {
+  int cap = 0;
+  for (const Layer& L : net->layers)
+    if (L.type == L_CHAIN) cap += layer_riders(net, L);
+  return cap;
+}
+
+extern "C" int sqdet_net_rider_capacity(const sqdet_net_t* net) { return net ? net_rider_capacity(net) : 0; }
+
+extern "C" int sqdet_net_set_post_job(sqdet_net_t* net, const void* preds, const float* scores, const float* anchors, float* out_boxes,
+                                      float* out_probs, int32_t* out_cls, int32_t* out_index, int32_t* out_count, int n, int gh,
+                                      int gw, int apg, int classes, float img_w, float img_h, float exp_thresh, int top_n,
+                                      int max_out, double nms_thresh, int dtype) {
+  SQDET_REQUIRE(net, "net_set_post_job: null net");
+  if (!preds) { net->job_set = false; return SQDET_OK; }      // cancel
+  SQDET_REQUIRE(scores && anchors && out_boxes && out_probs && out_cls && out_index && out_count, "net_set_post_job: null pointer");
+  SQDET_REQUIRE(n > 0 && gh > 0 && gw > 0 && apg > 0 && classes > 0 && max_out >= top_n, "net_set_post_job: bad dims");
+  const int A = gh * gw * apg;
+  SQDET_UNSUPPORTED(dtype != SQDET_F16 || !(top_n > 0 && top_n <= 64 && top_n < A && A <= 20480),
+                    "net_set_post_job: float16 preds and the top-N branch (0 < top_n <= 64 < anchors <= 20480) only");
+  SQDET_UNSUPPORTED(n > net_rider_capacity(net), "net_set_post_job: %d images, but this plan's fire_chain launches leave %d CUs idle",
+                    n, net_rider_capacity(net));
+  sqdet::FilterArgs& a = net->job_fa;
+  a.boxes = nullptr; a.probs = scores; a.cls = nullptr;
+  a.out_boxes = out_boxes; a.out_probs = out_probs; a.out_cls = out_cls; a.out_index = out_index; a.out_count = out_count;
+  a.A = A; a.C = classes; a.top_n = top_n; a.max_out = max_out; a.cap = 0; a.use_topn = 1;
+  a.nms_thresh = nms_thresh; a.prob_thresh = 0.f;
+  sqdet::DecodeArgs& d = net->job_da;
+  d.preds = preds; d.anchors = anchors; d.cells = gh * gw; d.apg = apg; d.C = classes; d.dtype = dtype;
+  d.w1 = img_w - 1.0f; d.h1 = img_h - 1.0f; d.thr = exp_thresh; d.slope = (float)exp((double)exp_thresh);
+  net->job_n = n;
+  net->job_set = true;
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_net_set_signal(sqdet_net_t* net, int layer_index, void* hip_event) {
+  SQDET_REQUIRE(net, "net_set_signal: null net");
+  SQDET_REQUIRE(!hip_event || (layer_index >= 0 && layer_index < (int)net->layers.size()), "net_set_signal: bad layer index %d", layer_index);
+  net->signal_layer = hip_event ? layer_index : -1;
+  net->signal_event = reinterpret_cast<hipEvent_t>(hip_event);
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_net_overlap_layer(const sqdet_net_t* net) {
+  if (!net) return -1;
+  for (size_t i = 0; i < net->layers.size(); ++i)
+    if (net->layers[i].type == L_CHAIN) return (int)i;
+  return -1;
+}
+
+static bool net_scores_ok(const sqdet_net* net) {
+  if (net->layers.empty()) return false;
+  const Layer& L = net->layers.back();
+  return L.type == L_CONV && L.k == 3 && L.stride == 1 && L.pad_mode == SQDET_PAD_SAME && !L.relu && !L.accum && L.fold < 0 &&
+         L.out_buf == BUF_PREDS && L.cout == net->apg * (net->classes + 5) && L.y_cstride == L.cout && L.y_coffset == 0 &&
+         sqdet_convdet_scores_supported(L.cin, net->apg, net->classes, net->dtype) != 0;
+}
+
+extern "C" int sqdet_net_scores_supported(const sqdet_net_t* net) { return net && net_scores_ok(net) ? 1 : 0; }
+
+extern "C" int sqdet_net_set_scores(sqdet_net_t* net, float* scores) {
+  SQDET_REQUIRE(net, "net_set_scores: null net");
+  SQDET_UNSUPPORTED(scores && !net_scores_ok(net), "net_set_scores: this plan's last layer has no score epilogue (float16 SqueezeDet-style ConvDet head only)");
+  net->scores = scores;
   return SQDET_OK;
 }
 

@@ -52,20 +52,43 @@ struct DecodeArgs {
   float w1, h1, thr, slope;
 };
 
-// score = max_c(softmax(class logits)_c * sigmoid(conf)), class = first argmax (nn_skeleton.py:150-170, 274-283)
+// score = max_c(softmax(class logits)_c * sigmoid(conf)), class = first argmax (nn_skeleton.py:150-170, 274-283), on the
+// float32 VALUES of the stored logits.  ONE definition for the score kernel, the filter kernel's re-decode and the score
+// pass in the ConvDet epilogue (convdet.hip): the three must agree bit for bit (all compiled with -ffp-contract=off).
+__device__ __forceinline__ float score_from_logits(const float* lg, int C, float conf_logit, int* bestc_out) {
+  float mx = lg[0];
+  for (int c = 1; c < C; ++c) mx = fmaxf(mx, lg[c]);
+  float sum = expf(lg[0] - mx);
+  for (int c = 1; c < C; ++c) sum = sum + expf(lg[c] - mx);
+  const float inv = 1.0f / sum;
+  const float conf = 1.0f / (1.0f + expf(-conf_logit));
+  float best = 0.f;
+  int bestc = 0;
+  for (int c = 0; c < C; ++c) {
+    const float pr = (expf(lg[c] - mx) * inv) * conf;
+    if (c == 0 || pr > best) { best = pr; bestc = c; }
+  }
+  *bestc_out = bestc;
+  return best;
+}
+
 template <typename T>
 __device__ __forceinline__ float decode_score(const T* p, int k, int apg, int C, int* bestc_out) {
-  const T* lg = p + k * C;
-  float mx = (float)lg[0];
-  for (int c = 1; c < C; ++c) mx = fmaxf(mx, (float)lg[c]);
-  float sum = expf((float)lg[0] - mx);
-  for (int c = 1; c < C; ++c) sum = sum + expf((float)lg[c] - mx);
+  const T* lgp = p + k * C;
+  if (C == 3) {      // (the reference's CLASSES: a register array)
+    const float lg[3] = {(float)lgp[0], (float)lgp[1], (float)lgp[2]};
+    return score_from_logits(lg, 3, (float)p[apg * C + k], bestc_out);
+  }
+  float mx = (float)lgp[0];
+  for (int c = 1; c < C; ++c) mx = fmaxf(mx, (float)lgp[c]);
+  float sum = expf((float)lgp[0] - mx);
+  for (int c = 1; c < C; ++c) sum = sum + expf((float)lgp[c] - mx);
   const float inv = 1.0f / sum;
   const float conf = 1.0f / (1.0f + expf(-(float)p[apg * C + k]));
   float best = 0.f;
   int bestc = 0;
   for (int c = 0; c < C; ++c) {
-    const float pr = (expf((float)lg[c] - mx) * inv) * conf;
+    const float pr = (expf((float)lgp[c] - mx) * inv) * conf;
     if (c == 0 || pr > best) { best = pr; bestc = c; }
   }
   *bestc_out = bestc;
@@ -101,6 +124,9 @@ __device__ __forceinline__ f32x4 decode_box(const T* p, int k, int apg, int C, c
 int filter_topn_fast_launch(const FilterArgs& a, int n, hipStream_t st, bool* handled);
 // interpret_output + filter_prediction (top-N branch): a chip-wide score kernel, then the filter kernel with boxes decoded for the
 // selected anchors only; a.probs = scratch [n, A] (scores, read back by the mass-tie fallback), a.boxes / a.cls unused
-int detect_topn_fused_launch(const FilterArgs& a, const DecodeArgs& d, int n, hipStream_t st, bool* handled);
+// scores_ready: a.probs already holds the scores (written by the ConvDet epilogue, sqdet_convdet_fwd): the score kernel is skipped
+// max_wgs > 0: at most that many workgroups (each walks several images)
+int detect_topn_fused_launch(const FilterArgs& a, const DecodeArgs& d, int n, hipStream_t st, bool* handled, bool scores_ready = false,
+                             int max_wgs = 0);
 
 }  // namespace sqdet

@@ -285,10 +285,10 @@ extern "C" int sqdet_filter_prediction(const float* boxes, const float* probs, c
   return SQDET_OK;
 }
 
-extern "C" int sqdet_detect_filter(const void* preds, const float* anchors, float* scratch_probs, float* out_boxes,
-                                   float* out_probs, int32_t* out_cls, int32_t* out_index, int32_t* out_count, int n, int gh,
-                                   int gw, int apg, int classes, float img_w, float img_h, float exp_thresh, int top_n,
-                                   int max_out, double nms_thresh, int dtype, sqdet_stream_t stream) {
+static int detect_filter_impl(const void* preds, const float* anchors, float* scratch_probs, float* out_boxes,
+                              float* out_probs, int32_t* out_cls, int32_t* out_index, int32_t* out_count, int n, int gh,
+                              int gw, int apg, int classes, float img_w, float img_h, float exp_thresh, int top_n,
+                              int max_out, double nms_thresh, int dtype, bool scores_ready, int max_wgs, sqdet_stream_t stream) {
   SQDET_REQUIRE(preds && anchors && scratch_probs && out_boxes && out_probs && out_cls && out_index && out_count,
                 "detect_filter: null pointer");
   SQDET_REQUIRE(n > 0 && gh > 0 && gw > 0 && apg > 0 && classes > 0 && max_out >= top_n, "detect_filter: bad dims");
@@ -304,8 +304,25 @@ extern "C" int sqdet_detect_filter(const void* preds, const float* anchors, floa
   d.preds = preds; d.anchors = anchors; d.cells = gh * gw; d.apg = apg; d.C = classes; d.dtype = dtype;
   d.w1 = img_w - 1.0f; d.h1 = img_h - 1.0f; d.thr = exp_thresh; d.slope = (float)exp((double)exp_thresh);
   bool handled = false;
-  const int rc = detect_topn_fused_launch(a, d, n, as_stream(stream), &handled);
+  const int rc = detect_topn_fused_launch(a, d, n, as_stream(stream), &handled, scores_ready, max_wgs);
   if (rc != SQDET_OK) return rc;
   SQDET_UNSUPPORTED(!handled, "detect_filter: needs the top-N branch with 0 < top_n <= 64 < anchors <= 20480 (else interpret_output + filter_prediction)");
   return SQDET_OK;
+}
+
+extern "C" int sqdet_detect_filter(const void* preds, const float* anchors, float* scratch_probs, float* out_boxes,
+                                   float* out_probs, int32_t* out_cls, int32_t* out_index, int32_t* out_count, int n, int gh,
+                                   int gw, int apg, int classes, float img_w, float img_h, float exp_thresh, int top_n,
+                                   int max_out, double nms_thresh, int dtype, sqdet_stream_t stream) {
+  return detect_filter_impl(preds, anchors, scratch_probs, out_boxes, out_probs, out_cls, out_index, out_count, n, gh, gw, apg,
+                            classes, img_w, img_h, exp_thresh, top_n, max_out, nms_thresh, dtype, false, 0, stream);
+}
+
+extern "C" int sqdet_detect_filter_scored(const void* preds, const float* anchors, const float* scores, float* out_boxes,
+                                          float* out_probs, int32_t* out_cls, int32_t* out_index, int32_t* out_count, int n,
+                                          int gh, int gw, int apg, int classes, float img_w, float img_h, float exp_thresh,
+                                          int top_n, int max_out, double nms_thresh, int dtype, int max_workgroups,
+                                          sqdet_stream_t stream) {
+  return detect_filter_impl(preds, anchors, const_cast<float*>(scores), out_boxes, out_probs, out_cls, out_index, out_count, n, gh,
+                            gw, apg, classes, img_w, img_h, exp_thresh, top_n, max_out, nms_thresh, dtype, true, max_workgroups, stream);
 }

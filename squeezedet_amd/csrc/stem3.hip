@@ -25,6 +25,13 @@
 // stores 52.5 us, no loads 47.6, neither 43.3 -- the kernel is bound by dependent-issue latency at 4 waves per SIMD
 // (removing 8 of 72 VALU instructions per pooled row by taking the bias through the accumulator input changed nothing).
 // LDS row pitch 196 dwords: the four gather reads of a wave are at most 2-way bank-conflicted (brute-forced).
+// Tried in round 3 and dropped: handing the tiles out by a per-XCD atomic counter instead of the static stride (so that
+// workgroups placed late -- the previous batch's filter workgroups hold 32 CUs when this launch starts in the serving step:
+// 58 -> 71 us -- simply take fewer tiles).  Device-scope atomics are served memory-side at ~60 ns apiece per XCD and address;
+// a batch-32 launch needs 20 per microsecond per XCD: with the eight counters in one 128-byte line the launch took 155 us,
+// with a line per XCD and the request issued a whole tile ahead 75 us against 58 (bitwise the same output).  The serving
+// step moves the side work to where it costs nothing instead (nn_skeleton.py: the filter of batch k runs on the 16 CUs the
+// chain launches of batch k+1 leave idle).
 #include <type_traits>
 #include "stem.h"
 
@@ -321,7 +328,7 @@ int stem_pers_launch(StemArgs a, int k, int dtype, hipStream_t st, bool* handled
   const int per_xcd = (ntiles + 7) / 8;
   int grid = 1024;                                                   // 4 workgroups per CU, a multiple of 8
   if (per_xcd < grid / 8) grid = per_xcd * 8;
-  const int dbg = tune(TUNE_DBG) >= 100 ? tune(TUNE_DBG) - 100 : 0;
+  const int dbg = tune(TUNE_DBG) >= 100 && tune(TUNE_DBG) < 200 ? tune(TUNE_DBG) - 100 : 0;
   if (a.ws2) hipLaunchKernelGGL(stem_pers<true>, dim3(grid), dim3(256), QLDS, st, a, ntiles, per_xcd, dbg);
   else hipLaunchKernelGGL(stem_pers<false>, dim3(grid), dim3(256), QLDS, st, a, ntiles, per_xcd, dbg);
   SQDET_CHECK_HIP(hipGetLastError());

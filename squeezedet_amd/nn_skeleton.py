@@ -410,7 +410,7 @@ class ModelSkeleton:
         return tuple(self.run([self.det_boxes, self.det_probs, self.det_class], {self.image_input: images},
                               use_plan=use_plan))
 
-    def detect_filter_pipelined(self, images, to_host=False):
+    def detect_filter_pipelined(self, images, to_host=False, defer=False):
         """One step of the serving loop as a two-stage pipeline: the network forward runs on the caller's stream,
         interpret_output + filter_prediction (a few dozen microseconds of latency-bound work on 32 workgroups)
         run on a side HIP stream behind an event, so the NEXT batch's forward starts while this batch's boxes
@@ -425,11 +425,62 @@ class ModelSkeleton:
         one run to the next.)  The returned tensors are those of the slot: valid until the second-next call.
         to_host=True: the filtered rows (<= TOP_N per image: boxes, probs, classes, anchor indices, counts) are also copied
         to the slot's PINNED host buffers on the side stream -- what sess.run + filter_prediction hand the reference's
-        caller -- and those host tensors are returned (complete once the side stream / the device is synchronised)."""
-        with torch.cuda.device(self.device):
-            return self._detect_filter_pipelined(images, to_host)
+        caller -- and those host tensors are returned (complete once the side stream / the device is synchronised).
 
-    def _detect_filter_pipelined(self, images, to_host):
+        defer=True (plans with the score epilogue and fire_chain launches: float16 SqueezeDet): the decode + filter of this
+        call is carried out BY THE NEXT CALL's forward (or by flush_pipeline()): it is handed to the plan as a post job
+        (sqdet_net_set_post_job) and runs in rider workgroups of that forward's fire_chain launches, one image per
+        otherwise idle CU, writing the rows straight into the slot's pinned host buffer -- no side stream, no events, no
+        extra launch.  Every launch of the forward fills the chip exactly once (persistent kernels with a static share of
+        tiles per workgroup), so side work on another stream costs a whole round of whatever it lands beside, and every
+        event ordering the two streams drains the forward's queue: measured 35 us per 0.49 ms step wherever the filter
+        launch was placed (side stream, same stream, with or without the score kernel, beside the stem or beside the
+        fire_chain launches) -- whereas the six fire_chain launches occupy 240 of the 256 CUs at batch 32.  The returned
+        tensors are this call's, complete after the NEXT call (or flush_pipeline()) and a synchronisation of the caller's
+        stream.  (SQDET_POST_DEFER=signal: the previous form -- the side stream's launch gated on a mid-forward event.)"""
+        with torch.cuda.device(self.device):
+            return self._detect_filter_pipelined(images, to_host, defer)
+
+    def flush_pipeline(self):
+        """defer=True: enqueue the side work of the last call now (nothing to overlap it with)."""
+        with torch.cuda.device(self.device):
+            pipe = getattr(self, "_pipe", None)
+            if pipe is not None and pipe.get("pending") is not None:
+                s = pipe["pending"]
+                if s.get("ride"):       # same stream as the forward: stream order is all the synchronisation there is
+                    cur = torch.cuda.current_stream()
+                    s["fwd_done"].record(cur)
+                    self._enqueue_post(s, None, stream=cur)
+                else:
+                    self._enqueue_post(s, None)
+                pipe["pending"] = None
+
+    def _enqueue_post(self, s, gate, stream=None):
+        """Decode + filter + row copy of slot s on the side stream, behind its forward (and `gate`, an event of a later forward)."""
+        mc = self.mc
+        pstream = stream if stream is not None else (torch.cuda.current_stream() if os.environ.get("SQDET_POST_INLINE") == "1" else self.post_stream)
+        with torch.cuda.stream(pstream):
+            pstream.wait_event(s["fwd_done"])
+            if gate is not None:
+                pstream.wait_event(gate)
+            if s["fused_post"]:
+                # decode + top-N + NMS in one call (score kernel unless scored + filter kernel): boxes / classes are decoded for the selected anchors only
+                ops.detect_filter(s["preds"], self.anchors_f32(), mc.CLASSES, mc.ANCHOR_PER_GRID, mc.IMAGE_WIDTH, mc.IMAGE_HEIGHT,
+                                  mc.EXP_THRESH, mc.TOP_N_DETECTION, mc.NMS_THRESH, scratch=s["det"][1], out=s["out"],
+                                  scores_ready=s["scored"], max_workgroups=s["post_wgs"] if gate is not None else 0)
+            else:
+                ops.interpret_output(s["preds"], self.anchors_f32(), mc.CLASSES, mc.ANCHOR_PER_GRID, mc.IMAGE_WIDTH,
+                                     mc.IMAGE_HEIGHT, mc.EXP_THRESH, out=s["det"])
+                ops.filter_prediction(s["det"][0], s["det"][1], s["det"][2], mc.CLASSES, mc.TOP_N_DETECTION, mc.NMS_THRESH,
+                                      mc.PROB_THRESH, out=s["out"])
+            if s["to_host"]:
+                if s["host"] is None:
+                    s["host_flat"] = torch.empty(s["flat"].shape, dtype=torch.uint8).pin_memory()
+                    s["host"] = self._out_views(s["host_flat"])
+                ops.copy_to_pinned_host(s["flat"], s["host_flat"])      # all five outputs in one launch (never blocks the host)
+            s["post_done"].record(pstream)
+
+    def _detect_filter_pipelined(self, images, to_host, defer=False):
         mc = self.mc
         if getattr(self, "post_stream", None) is None:
             # high priority: the two small post-processing kernels are dispatched as soon as CUs free up at a kernel
@@ -443,6 +494,7 @@ class ModelSkeleton:
             B = int(x.shape[0])
             plan = self._native_plan(B)
             if self._pipe is None or self._pipe["batch"] != B:
+                self.flush_pipeline()
                 A = mc.ANCHORS
                 M = mc.TOP_N_DETECTION if 0 < mc.TOP_N_DETECTION < A else min(A, 1024)
                 f32, dev = torch.float32, self.device
@@ -459,36 +511,64 @@ class ModelSkeleton:
 
                 def mk():
                     flat = torch.empty(out_bytes, dtype=torch.uint8, device=dev)
+                    sig = torch.cuda.Event()
+                    sig.record(cur)                    # (creates the handle sqdet_net_set_signal is given)
                     return dict(preds=torch.empty((B, plan.gh, plan.gw, plan.out_ch), dtype=self.dtype, device=dev),
                                 det=(torch.empty((B, A, 4), dtype=f32, device=dev), torch.empty((B, A), dtype=f32, device=dev),
                                      torch.empty((B, A), dtype=torch.int64, device=dev)),
                                 flat=flat, out=out_views(flat), host_flat=None, host=None,
-                                fwd_done=torch.cuda.Event(), post_done=torch.cuda.Event(), used=False)
+                                fwd_done=torch.cuda.Event(), post_done=torch.cuda.Event(), sig=sig, used=False)
                 self._out_views = out_views
-                self._pipe = dict(batch=B, slots=[mk(), mk()], k=0)
-            s = self._pipe["slots"][self._pipe["k"] & 1]
-            self._pipe["k"] += 1
+                self._pipe = dict(batch=B, slots=[mk(), mk()], k=0, pending=None)
+            pipe = self._pipe
+            s = pipe["slots"][pipe["k"] & 1]
+            pipe["k"] += 1
             if s["used"]:
                 cur.wait_event(s["post_done"])          # the side stream has finished reading this slot's preds
-            plan.forward(x, s["preds"])
+            fused_post = ops.detect_filter_supported(mc.ANCHORS, mc.TOP_N_DETECTION) and os.environ.get("SQDET_SPLIT_POST") != "1"
+            # the score half of interpret_output rides in the ConvDet launch's epilogue where the plan has it (float16
+            # SqueezeDet head): what is left for the side stream is ONE filter launch + the row copy
+            # (SQDET_SCORE_EPILOGUE=0: the stand-alone score kernel on the side stream, for A/B)
+            scored = fused_post and plan.scores_supported() and os.environ.get("SQDET_SCORE_EPILOGUE") != "0"
+            mode = os.environ.get("SQDET_POST_DEFER", "ride")
+            ride = bool(defer and scored and mode == "ride" and plan.rider_capacity() >= B)
+            ov = plan.overlap_layer() if (defer and scored and mode == "signal") else -1
+            deferred = ov >= 0
+            s.update(fused_post=fused_post, scored=scored, to_host=to_host, ride=ride,
+                     post_wgs=int(os.environ.get("SQDET_POST_WGS", "16")) if B > 16 else 0)
+            if to_host and s["host"] is None:
+                s["host_flat"] = torch.empty(s["flat"].shape, dtype=torch.uint8).pin_memory()
+                s["host"] = self._out_views(s["host_flat"])
+            prev = pipe["pending"]
+            if ride:
+                # everything on the caller's stream: the previous call's decode + filter rides in this forward's fire_chain
+                # launches and writes its rows where the caller reads them (no post_done wait above either: a slot's preds /
+                # scores are next overwritten by the ConvDet launch of the second-next forward, behind its riders in stream order)
+                if prev is not None:
+                    if prev.get("ride"):
+                        plan.set_post_job(prev["preds"], prev["det"][1], self.anchors_f32(), prev["host"] if prev["to_host"] else prev["out"],
+                                          mc.CLASSES, mc.ANCHOR_PER_GRID, mc.IMAGE_WIDTH, mc.IMAGE_HEIGHT, mc.EXP_THRESH,
+                                          mc.TOP_N_DETECTION, mc.NMS_THRESH)
+                    else:
+                        self._enqueue_post(prev, None)
+                plan.set_signal(-1, None)
+                plan.forward(x, s["preds"], scores=s["det"][1])
+                pipe["pending"] = s
+                s["used"] = False                       # (no side-stream reader to wait for)
+                return s["host"] if to_host else s["out"]
+            plan.set_signal(ov, s["sig"] if (deferred and prev is not None) else None)
+            plan.forward(x, s["preds"], scores=s["det"][1] if scored else None)
             s["fwd_done"].record(cur)
-            with torch.cuda.stream(self.post_stream):
-                self.post_stream.wait_event(s["fwd_done"])
-                if ops.detect_filter_supported(mc.ANCHORS, mc.TOP_N_DETECTION) and os.environ.get("SQDET_SPLIT_POST") != "1":
-                    # decode + top-N + NMS in one call (score kernel + filter kernel): boxes / classes are decoded for the selected anchors only
-                    ops.detect_filter(s["preds"], self.anchors_f32(), mc.CLASSES, mc.ANCHOR_PER_GRID, mc.IMAGE_WIDTH, mc.IMAGE_HEIGHT,
-                                      mc.EXP_THRESH, mc.TOP_N_DETECTION, mc.NMS_THRESH, scratch=s["det"][1], out=s["out"])
+            if prev is not None:                        # the previous call's side work: beside THIS forward's fire_chain launches
+                if prev.get("ride"):
+                    self._enqueue_post(prev, None, stream=cur)
                 else:
-                    ops.interpret_output(s["preds"], self.anchors_f32(), mc.CLASSES, mc.ANCHOR_PER_GRID, mc.IMAGE_WIDTH,
-                                         mc.IMAGE_HEIGHT, mc.EXP_THRESH, out=s["det"])
-                    ops.filter_prediction(s["det"][0], s["det"][1], s["det"][2], mc.CLASSES, mc.TOP_N_DETECTION, mc.NMS_THRESH,
-                                          mc.PROB_THRESH, out=s["out"])
-                if to_host:
-                    if s["host"] is None:
-                        s["host_flat"] = torch.empty(s["flat"].shape, dtype=torch.uint8).pin_memory()
-                        s["host"] = self._out_views(s["host_flat"])
-                    ops.copy_to_pinned_host(s["flat"], s["host_flat"])      # all five outputs in one launch (never blocks the host)
-                s["post_done"].record(self.post_stream)
+                    self._enqueue_post(prev, s["sig"] if deferred else None)
+                pipe["pending"] = None
+            if deferred:
+                pipe["pending"] = s
+            else:
+                self._enqueue_post(s, None)
             s["used"] = True
             return s["host"] if to_host else s["out"]
         (preds,) = self.run([self.preds], {self.image_input: images})

@@ -318,9 +318,12 @@ def detect_filter_supported(num_anchors, top_n):
     return 0 < top_n <= 64 < num_anchors <= 20480
 
 
-def detect_filter(preds, anchors_f32, classes, anchors_per_grid, img_w, img_h, exp_thresh, top_n, nms_thresh, scratch=None, out=None):
+def detect_filter(preds, anchors_f32, classes, anchors_per_grid, img_w, img_h, exp_thresh, top_n, nms_thresh, scratch=None, out=None,
+                  scores_ready=False, max_workgroups=0):
     """interpret_output + filter_prediction (top-N branch) in one call (sqdet_detect_filter): preds [N,gh,gw,K*(C+5)] ->
-    the five filter_prediction outputs; det_boxes / det_class are never materialised."""
+    the five filter_prediction outputs; det_boxes / det_class are never materialised.
+    scores_ready: `scratch` already holds det_probs (written by the ConvDet epilogue: convdet / NetPlan.forward(scores=)) --
+    sqdet_detect_filter_scored, the filter launch only."""
     n, gh, gw, ch = [int(v) for v in preds.shape]
     A = gh * gw * anchors_per_grid
     dev = preds.device
@@ -334,11 +337,36 @@ def detect_filter(preds, anchors_f32, classes, anchors_per_grid, img_w, img_h, e
         oc = torch.empty((n, M), dtype=torch.int32, device=dev)
         oi = torch.empty((n, M), dtype=torch.int32, device=dev)
         cnt = torch.empty((n,), dtype=torch.int32, device=dev)
-    check(lib().sqdet_detect_filter(_dev(preds, "preds"), _dev(anchors_f32, "anchors", torch.float32), _dev(scratch, "scratch", torch.float32),
-                                    _dev(ob, "ob"), _dev(op, "op"), _dev(oc, "oc"), _dev(oi, "oi"), _dev(cnt, "cnt"), n, gh, gw,
-                                    int(anchors_per_grid), int(classes), float(img_w), float(img_h), float(exp_thresh), M, int(ob.shape[1]),
-                                    float(nms_thresh), dtype_code(preds.dtype), stream_ptr()), "sqdet_detect_filter")
+    if scores_ready and (scratch is None or tuple(scratch.shape) != (n, A)):
+        raise _lib.SqdetError("detect_filter: scores_ready needs the [N, A] float32 score tensor as `scratch`")
+    args = (_dev(preds, "preds"), _dev(anchors_f32, "anchors", torch.float32), _dev(scratch, "scratch", torch.float32),
+            _dev(ob, "ob"), _dev(op, "op"), _dev(oc, "oc"), _dev(oi, "oi"), _dev(cnt, "cnt"), n, gh, gw,
+            int(anchors_per_grid), int(classes), float(img_w), float(img_h), float(exp_thresh), M, int(ob.shape[1]),
+            float(nms_thresh), dtype_code(preds.dtype))
+    if scores_ready:     # max_workgroups > 0: the images are walked by at most that many workgroups
+        check(lib().sqdet_detect_filter_scored(*args, int(max_workgroups), stream_ptr()), "sqdet_detect_filter_scored")
+    else:
+        check(lib().sqdet_detect_filter(*args, stream_ptr()), "sqdet_detect_filter")
     return ob, op, oc, oi, cnt
+
+
+def convdet_scores_supported(cin, anchors_per_grid, classes, dtype):
+    return bool(lib().sqdet_convdet_scores_supported(int(cin), int(anchors_per_grid), int(classes), dtype_code(dtype)))
+
+
+def convdet(x, packed, bias, anchors_per_grid, classes, preds=None, scores=None):
+    """The ConvDet head + interpret_output's det_probs in one launch (sqdet_convdet_fwd): x [N,H,W,Cin] float16 ->
+    (preds [N,H,W,K*(C+5)], scores [N, H*W*K] float32)."""
+    n, h, w, cin = [int(v) for v in x.shape]
+    cout = int(anchors_per_grid) * (int(classes) + 5)
+    if packed.k != 3 or packed.cin != cin or packed.cout != cout or packed.dtype != x.dtype:
+        raise _lib.SqdetError("convdet: packed kernel does not match x / the head's %d channels" % cout)
+    preds = torch.empty((n, h, w, cout), dtype=x.dtype, device=x.device) if preds is None else preds
+    scores = torch.empty((n, h * w * int(anchors_per_grid)), dtype=torch.float32, device=x.device) if scores is None else scores
+    check(lib().sqdet_convdet_fwd(_dev(x, "x"), _dev(packed.data, "packed"), _dev(bias, "bias", torch.float32), _dev(preds, "preds"),
+                                  _dev(scores, "scores", torch.float32), n, h, w, cin, int(anchors_per_grid), int(classes),
+                                  dtype_code(x.dtype), stream_ptr()), "sqdet_convdet_fwd")
+    return preds, scores
 
 
 # ---------------------------------------------------------------- training (float32)
@@ -633,6 +661,7 @@ class NetPlan:
 
     def __init__(self, arch, dtype, batch, img_h, img_w, classes, anchors_per_grid, device):
         self.arch, self.dtype, self.batch, self.img_h, self.img_w = arch, dtype, batch, img_h, img_w
+        self.classes, self.anchors_per_grid = int(classes), int(anchors_per_grid)
         self.device = torch.device(device)
         self._h = C.c_void_p()
         check(lib().sqdet_net_create(C.byref(self._h), self.ARCH[arch], dtype_code(dtype), batch, img_h, img_w,
@@ -668,15 +697,57 @@ class NetPlan:
         check(lib().sqdet_net_set_param(self._h, name.encode(), _dev(v, name), stream_ptr()), "sqdet_net_set_param(%s)" % name)
         torch.cuda.current_stream().synchronize()  # `v` may be a temporary
 
-    def forward(self, image_input, preds=None):
+    def overlap_layer(self):
+        """Index of the launch beside which side work is cheapest (first fire_chain launch), or -1."""
+        return int(lib().sqdet_net_overlap_layer(self._h))
+
+    def set_signal(self, layer_index, event):
+        """Every following forward records `event` (a torch.cuda.Event that has been recorded once, so that its handle
+        exists; None: no signal) right before the launch of layer `layer_index` (sqdet_net_set_signal)."""
+        h = None if event is None else C.c_void_p(event.cuda_event)
+        check(lib().sqdet_net_set_signal(self._h, int(layer_index), h), "sqdet_net_set_signal")
+
+    def rider_capacity(self):
+        """Images the plan's fire_chain launches can carry as riders (sqdet_net_rider_capacity); 0 = none."""
+        return int(lib().sqdet_net_rider_capacity(self._h))
+
+    def set_post_job(self, preds, scores, anchors_f32, out, classes, anchors_per_grid, img_w, img_h, exp_thresh, top_n, nms_thresh):
+        """The decode + filter of a PREVIOUS batch (its preds / scores; out = the five output tensors of filter_prediction,
+        device or pinned host) rides in the next forward's fire_chain launches (sqdet_net_set_post_job).  One-shot."""
+        n, gh, gw, ch = [int(v) for v in preds.shape]
+        ob, op, oc, oi, cnt = out
+        ptr = lambda t: C.c_void_p(t.data_ptr())          # (pinned host tensors are device-accessible at the same address)
+        for t in out:
+            if not (t.is_cuda or t.is_pinned()):
+                raise _lib.SqdetError("set_post_job: outputs must be device or pinned host tensors")
+        check(lib().sqdet_net_set_post_job(self._h, _dev(preds, "preds"), _dev(scores, "scores", torch.float32),
+                                           _dev(anchors_f32, "anchors", torch.float32), ptr(ob), ptr(op), ptr(oc), ptr(oi), ptr(cnt),
+                                           n, gh, gw, int(anchors_per_grid), int(classes), float(img_w), float(img_h), float(exp_thresh),
+                                           int(top_n), int(ob.shape[1]), float(nms_thresh), dtype_code(preds.dtype)), "sqdet_net_set_post_job")
+
+    def scores_supported(self):
+        """The plan's ConvDet launch can also write interpret_output's det_probs (float16 SqueezeDet-style head)."""
+        return bool(lib().sqdet_net_scores_supported(self._h))
+
+    def forward(self, image_input, preds=None, scores=None):
+        """scores: float32 [batch, A] -- when given, the ConvDet launch's epilogue also writes det_probs there
+        (sqdet_net_set_scores); follow with detect_filter(..., scratch=scores, scores_ready=True)."""
         exp = (self.batch, self.img_h, self.img_w, 3)
         if tuple(image_input.shape) != exp or image_input.dtype != self.dtype:
             raise _lib.SqdetError("forward: image_input must be %s %s, got %s %s"
                                   % (exp, self.dtype, tuple(image_input.shape), image_input.dtype))
         if preds is None:
             preds = torch.empty((self.batch, self.gh, self.gw, self.out_ch), dtype=self.dtype, device=self.device)
-        check(lib().sqdet_net_forward(self._h, _dev(image_input, "image_input"), _dev(preds, "preds"), stream_ptr()),
-              "sqdet_net_forward")
+        if scores is not None:
+            if scores.numel() * self.out_ch != preds.numel() * self.anchors_per_grid or scores.dtype != torch.float32:
+                raise _lib.SqdetError("forward: scores must be float32 [batch, gh*gw*anchors_per_grid]")
+            check(lib().sqdet_net_set_scores(self._h, _dev(scores, "scores", torch.float32)), "sqdet_net_set_scores")
+        try:
+            check(lib().sqdet_net_forward(self._h, _dev(image_input, "image_input"), _dev(preds, "preds"), stream_ptr()),
+                  "sqdet_net_forward")
+        finally:
+            if scores is not None:
+                lib().sqdet_net_set_scores(self._h, None)
         return preds
 
     def layer_table(self):

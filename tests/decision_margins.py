@@ -76,7 +76,7 @@ def run(size, dtype_name, nimg=16, seed=40, device="cuda:0", planted=False, batc
     xd = x.to(device, tdt)
     outs = m.run([m.det_boxes, m.det_probs, m.det_class, m.pred_class_probs, m.pred_conf], {m.image_input: xd})
     if pipelined:
-        ob, op, oc, oi, cnt = [t.clone() for t in m.detect_filter_pipelined(xd, to_host=True)]
+        ob, op, oc, oi, cnt = m.detect_filter_pipelined(xd, to_host=True)      # pinned host rows, complete after the sync below
     else:
         ob, op, oc, oi, cnt = m.filter_prediction_batch(outs[0], outs[1], outs[2])
     torch.cuda.synchronize()

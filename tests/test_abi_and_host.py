@@ -243,3 +243,17 @@ def test_bench_launch_roofline_picks_the_bound_by_intensity():
     r = bench.launch_roofline(14.8e9, 119e6, 0.0735, "fp16")          # the stem launch: 124 flop/B
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["achieved"] - 119e6 / 0.0735e-3 / 1e9) < 1e-1
     assert bench.launch_roofline(59.6e9, 102e6, 0.0632, "fp32")["bound"] == "hbm"   # the dense peak quoted is float16's
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """libsqdet_hip.so loaded BEFORE torch must not pull the system libamdhip64 in beside torch's bundled one (two runtimes:
+    the second sees no device -- `python __graft_entry__.py smoke` after build() failed that way): _lib.lib() imports
+    torch first.  Checked in a fresh interpreter, library first."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from squeezedet_amd import _lib\n_lib.lib()\nimport torch\n"
+            "print(len({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}))" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == "1", r.stdout

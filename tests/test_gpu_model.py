@@ -106,6 +106,32 @@ def test_native_plan_equals_builder_graph_and_oracle(dtype):
     _check_layers(p_plan, ref, dtype, "preds")
 
 
+def test_native_plan_scores_from_the_convdet_epilogue():
+    """NetPlan.forward(scores=): the plan's ConvDet launch also writes interpret_output's det_probs (sqdet_net_set_scores);
+    preds are bitwise those of the plain forward, scores bitwise sqdet_interpret_output's on those preds; a float32 plan
+    reports no support and refuses; unbinding restores the plain launch."""
+    from squeezedet_amd import _lib, ops
+    m, mc, params, storage = _model("squeezeDet", torch.float16, 3, (375, 1242))
+    x = O.synthetic_images(3, 375, 1242, seed=12, storage=storage).to(DEV, torch.float16)
+    plan = m._native_plan(3)
+    assert plan.scores_supported()
+    p0 = plan.forward(x).clone()
+    scores = torch.full((3, mc.ANCHORS), -1.0, dtype=torch.float32, device=DEV)
+    p1 = plan.forward(x, scores=scores)
+    probs = ops.interpret_output(p1, m.anchors_f32(), mc.CLASSES, mc.ANCHOR_PER_GRID, mc.IMAGE_WIDTH, mc.IMAGE_HEIGHT, mc.EXP_THRESH)[1]
+    torch.cuda.synchronize()
+    assert torch.equal(p0, p1) and torch.equal(scores, probs) and float(scores.min()) >= 0.0
+    scores.fill_(-1.0)
+    p2 = plan.forward(x)                     # unbound again: the buffer is not touched
+    torch.cuda.synchronize()
+    assert torch.equal(p2, p0) and float(scores.max()) == -1.0
+    m32 = _model("squeezeDet", torch.float32, 1, (128, 256))[0]
+    plan32 = m32._native_plan(1)
+    assert not plan32.scores_supported()
+    with pytest.raises(_lib.SqdetUnsupported):
+        plan32.forward(torch.zeros((1, 128, 256, 3), device=DEV), scores=torch.zeros((1, plan32.gh * plan32.gw * 9), device=DEV))
+
+
 @pytest.mark.parametrize("shape", [(3, 200, 600), (1, 97, 333), (5, 130, 236), (2, 64, 1000)], ids=lambda v: "x".join(map(str, v)))
 def test_native_plan_other_sizes_and_batches_fp16_vs_oracle(shape):
     """The chained fp16 plan (stem + fire2's squeeze, squeeze-tensor launches through the pools, chain launches with two
@@ -224,6 +250,77 @@ def test_pipelined_step_equals_sequential():
         for i in range(4):
             for t in range(4):
                 assert torch.equal(got[t][i, :n[i]], want[t][i, :n[i]])
+
+
+@pytest.mark.parametrize("mode", ["ride", "signal"])
+@pytest.mark.parametrize("batch", [32, 5])
+def test_deferred_pipelined_step_equals_sequential(mode, batch, monkeypatch):
+    """defer=True (bench.py's step): the decode + filter of call k is carried out by call k+1 -- "ride": as rider workgroups
+    of that forward's fire_chain launches (sqdet_net_set_post_job: same stream, rows written straight to pinned host
+    memory; 512-thread form of the filter body); "signal": on the side stream behind that forward's mid-point event, the
+    images walked by 16 workgroups -- and flush_pipeline() carries out the last one.  Every step's rows, read after the
+    NEXT call (or the flush), equal detect -> filter_prediction_batch exactly."""
+    monkeypatch.setenv("SQDET_POST_DEFER", mode)
+    m, mc, params, storage = _model("squeezeDet", torch.float16, batch, (375, 1242))
+    xs = [O.synthetic_images(batch, 375, 1242, seed=s, storage=storage).to(DEV, torch.float16) for s in (3, 4, 5)]
+    seq = []
+    for x in xs:
+        b, p, c = m.detect(x)
+        seq.append([t.clone() for t in m.filter_prediction_batch(b, p, c)])
+    torch.cuda.synchronize()
+    plan = m._native_plan(batch)
+    assert plan.overlap_layer() >= 0 and plan.scores_supported() and plan.rider_capacity() >= batch
+    outs, prev = [], None
+    for x in xs + xs:
+        out = m.detect_filter_pipelined(x, to_host=True, defer=True)
+        if prev is not None:                                    # the previous call's rows: enqueued by THIS call
+            torch.cuda.synchronize()
+            outs.append([t.clone() for t in prev])
+        prev = out
+    m.flush_pipeline()
+    torch.cuda.synchronize()
+    outs.append([t.clone() for t in prev])
+    seq = seq + seq
+    assert len(outs) == 6
+    for got, want in zip(outs, seq):
+        n = want[4].cpu().numpy()
+        assert np.array_equal(got[4].numpy(), n)
+        for i in range(batch):
+            for t in range(4):
+                assert torch.equal(got[t][i, :n[i]], want[t][i, :n[i]].cpu())
+
+
+def test_post_job_riders_equal_the_filter_launch():
+    """sqdet_net_set_post_job: the previous batch's decode + filter as riders of the next forward's fire_chain launches gives
+    exactly sqdet_detect_filter's outputs (device outputs here), is consumed by ONE forward, and a plan without fire_chain
+    launches (float32) refuses."""
+    from squeezedet_amd import _lib, ops
+    m, mc, params, storage = _model("squeezeDet", torch.float16, 32, (375, 1242))
+    plan = m._native_plan(32)
+    assert plan.rider_capacity() == 96                                   # 6 fire_chain launches x 16 idle CUs
+    x = O.synthetic_images(32, 375, 1242, seed=8, storage=storage).to(DEV, torch.float16)
+    scores = torch.empty((32, mc.ANCHORS), dtype=torch.float32, device=DEV)
+    preds = plan.forward(x, scores=scores).clone()
+    want = ops.detect_filter(preds, m.anchors_f32(), mc.CLASSES, mc.ANCHOR_PER_GRID, mc.IMAGE_WIDTH, mc.IMAGE_HEIGHT, mc.EXP_THRESH,
+                             mc.TOP_N_DETECTION, mc.NMS_THRESH, scratch=scores, scores_ready=True)
+    out = [torch.full_like(t, -7) for t in want]
+    plan.set_post_job(preds, scores, m.anchors_f32(), out, mc.CLASSES, mc.ANCHOR_PER_GRID, mc.IMAGE_WIDTH, mc.IMAGE_HEIGHT,
+                      mc.EXP_THRESH, mc.TOP_N_DETECTION, mc.NMS_THRESH)
+    p2 = plan.forward(x)                                                  # carries the riders
+    torch.cuda.synchronize()
+    assert torch.equal(p2, preds)
+    for g_, w_ in zip(out, want):
+        assert torch.equal(g_, w_)
+    for t in out:
+        t.fill_(-7)
+    plan.forward(x)                                                       # one-shot: no riders this time
+    torch.cuda.synchronize()
+    assert all(int((t == -7).all()) for t in out)
+    m32 = _model("squeezeDet", torch.float32, 2, (128, 256))[0]
+    assert m32._native_plan(2).rider_capacity() == 0
+    with pytest.raises(_lib.SqdetUnsupported):
+        m32._native_plan(2).set_post_job(preds[:2], scores[:2], m.anchors_f32(), [t[:2] for t in out], mc.CLASSES, mc.ANCHOR_PER_GRID,
+                                         mc.IMAGE_WIDTH, mc.IMAGE_HEIGHT, mc.EXP_THRESH, mc.TOP_N_DETECTION, mc.NMS_THRESH)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])

@@ -724,3 +724,48 @@ def test_detect_filter_one_launch(dtype, ties):
     for g_, w_ in zip(got, want):
         assert torch.equal(g_, w_)
     assert int(got[4].min()) >= 1
+
+
+@pytest.mark.parametrize("shape", [(3, 24, 78), (2, 22, 76), (1, 5, 19), (32, 22, 76)], ids=lambda s: "%dx%dx%d" % s)
+def test_convdet_score_epilogue_bitwise(shape):
+    """sqdet_convdet_fwd (the ConvDet launch with the score half of interpret_output in its epilogue): preds are BITWISE those
+    of sqdet_conv2d_nhwc_fwd, scores are BITWISE the det_probs sqdet_interpret_output computes from those preds (one shared
+    float expression, postproc.h), and sqdet_detect_filter_scored on them gives exactly sqdet_detect_filter's outputs --
+    full 22x76 / 24x78 maps, a ragged 5x19 map (edge tiles only), and the benchmark's batch 32."""
+    ops = _ops()
+    mc = O.kitti_squeezeDet_config()
+    n, gh, gw = shape
+    K, C = mc.ANCHOR_PER_GRID, mc.CLASSES
+    rs = np.random.RandomState(101 + n)
+    x = torch.from_numpy(np.maximum(rs.randn(n, gh, gw, 768), 0).astype(np.float32)).to(DEV, torch.float16)
+    w = torch.from_numpy((rs.randn(3, 3, 768, 72) * 0.03).astype(np.float32)).to(DEV)
+    b = torch.from_numpy((rs.randn(72) * 0.5).astype(np.float32)).to(DEV)
+    packed = ops.pack_conv_weights(w, torch.float16)
+    assert ops.convdet_scores_supported(768, K, C, torch.float16)
+    assert not ops.convdet_scores_supported(768, K, C, torch.float32) and not ops.convdet_scores_supported(768, K, 4, torch.float16)
+    want_preds = ops.conv2d_nhwc(x, packed, b, 1, "SAME", False)
+    preds, scores = ops.convdet(x, packed, b, K, C)
+    torch.cuda.synchronize()
+    assert torch.equal(preds, want_preds)
+    # anchors of a gh x gw grid are only needed for boxes: any [A,4] array serves the score / pick comparison
+    A = gh * gw * K
+    anchors = torch.from_numpy(np.abs(rs.randn(A, 4)).astype(np.float32) * 50 + 10).to(DEV)
+    probs = ops.interpret_output(preds, anchors, C, K, mc.IMAGE_WIDTH, mc.IMAGE_HEIGHT, mc.EXP_THRESH)[1]
+    assert scores.shape == probs.shape and torch.equal(scores, probs)
+    assert float(scores.max()) > 0.3 and float(scores.min()) >= 0.0
+    want = ops.detect_filter(preds, anchors, C, K, mc.IMAGE_WIDTH, mc.IMAGE_HEIGHT, mc.EXP_THRESH, mc.TOP_N_DETECTION, mc.NMS_THRESH)
+    got = ops.detect_filter(preds, anchors, C, K, mc.IMAGE_WIDTH, mc.IMAGE_HEIGHT, mc.EXP_THRESH, mc.TOP_N_DETECTION, mc.NMS_THRESH,
+                            scratch=scores, scores_ready=True)
+    torch.cuda.synchronize()
+    for g_, w_ in zip(got, want):
+        assert torch.equal(g_, w_)
+
+
+def test_convdet_score_epilogue_rejects_other_heads():
+    ops = _ops()
+    from squeezedet_amd import _lib
+    x = torch.zeros((1, 8, 16, 768), dtype=torch.float32, device=DEV)
+    w = torch.zeros((3, 3, 768, 72), dtype=torch.float32, device=DEV)
+    packed = ops.pack_conv_weights(w, torch.float32)
+    with pytest.raises(_lib.SqdetUnsupported):
+        ops.convdet(x, packed, torch.zeros(72, device=DEV), 9, 3)
