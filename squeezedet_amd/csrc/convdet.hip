@@ -325,21 +325,22 @@ __global__ __launch_bounds__(256) void convdet_kernel(TileArgs a, int ntiles, in
       const unsigned char* sw = lds + CD_LDS + wave * CD_SC_WAVE;
       const int cells = a.c.H * a.c.W;
       int l2 = lz;                      // nothing of the 5 iterations' index arithmetic is hoisted out of the tile loop
-#pragma unroll 1
+      // (unrolled: five independent ~150-instruction dependency chains interleave; rolled, the pass was latency-bound and cost
+      // the launch 5 us)
+#pragma unroll
       for (int it = 0; it < 5; ++it) {
-        const int idx = it * 64 + l2;                       // (row mm, pixel px, anchor k) = idx / 144, (idx % 144) / 9, idx % 9
-        const int mm = idx >= 144 ? 1 : 0;
+        const int idx0 = it * 64 + l2;                      // (row mm, pixel px, anchor k) = idx / 144, (idx % 144) / 9, idx % 9
+        const int idx = idx0 < 288 ? idx0 : 287;            // computed unconditionally (no branch between the five chains),
+        const int mm = idx >= 144 ? 1 : 0;                  // stored under the predicate
         const int r = idx - mm * 144;
         const int px = (int)(__umul24((unsigned)r, 57u) >> 9);   // r / 9 for r < 144
         const int k = r - px * 9;
         const int oy = coy0 + wave * MO + mm, oxx = cox0 + px;
-        if (idx < 288 && oy < a.c.H && oxx < a.c.W) {
-          const f16* hp = reinterpret_cast<const f16*>(sw + (mm * 16 + px) * CD_SC_PIX);
-          const float lg[3] = {(float)hp[3 * k], (float)hp[3 * k + 1], (float)hp[3 * k + 2]};
-          int bc;
-          const float sc = score_from_logits(lg, 3, (float)hp[27 + k], &bc);
-          a.c.scores[((size_t)cn * cells + (size_t)oy * a.c.W + oxx) * 9 + k] = sc;
-        }
+        const f16* hp = reinterpret_cast<const f16*>(sw + (mm * 16 + px) * CD_SC_PIX);
+        const float lg[3] = {(float)hp[3 * k], (float)hp[3 * k + 1], (float)hp[3 * k + 2]};
+        int bc;
+        const float sc = score_from_logits(lg, 3, (float)hp[27 + k], &bc);
+        if (idx0 < 288 && oy < a.c.H && oxx < a.c.W) a.c.scores[((size_t)cn * cells + (size_t)oy * a.c.W + oxx) * 9 + k] = sc;
       }
     }
     CT_MARK(6);
