@@ -780,55 +780,4 @@ class NetPlan:
 
 
 # ---------------------------------------------------------------- torch.ops.sqdet.*
-def _register_custom_ops():
-    try:
-        from torch.library import custom_op
-    except Exception:  # pragma: no cover - very old torch
-        return
-
-    @custom_op("sqdet::maxpool_nhwc", mutates_args=())
-    def _maxpool(x: torch.Tensor, size: int, stride: int, same: bool) -> torch.Tensor:
-        return maxpool_nhwc(x, size, stride, "SAME" if same else "VALID")
-
-    @_maxpool.register_fake
-    def _(x, size, stride, same):
-        p = "SAME" if same else "VALID"
-        return x.new_empty((x.shape[0], _out_size(x.shape[1], size, stride, p), _out_size(x.shape[2], size, stride, p), x.shape[3]))
-
-    @custom_op("sqdet::conv2d_nhwc", mutates_args=())
-    def _conv(x: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, k: int, cout: int, stride: int, same: bool,
-              relu: bool) -> torch.Tensor:
-        pc = PackedConv.__new__(PackedConv)
-        pc.k, pc.cin, pc.cout, pc.dtype, pc.data = k, int(x.shape[3]), cout, x.dtype, packed
-        return conv2d_nhwc(x, pc, bias, stride, "SAME" if same else "VALID", relu)
-
-    @_conv.register_fake
-    def _(x, packed, bias, k, cout, stride, same, relu):
-        p = "SAME" if same else "VALID"
-        return x.new_empty((x.shape[0], _out_size(x.shape[1], k, stride, p), _out_size(x.shape[2], k, stride, p), cout))
-
-    @custom_op("sqdet::interpret_output", mutates_args=())
-    def _interp(preds: torch.Tensor, anchors: torch.Tensor, classes: int, apg: int, img_w: float, img_h: float,
-                exp_thresh: float) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        return interpret_output(preds, anchors, classes, apg, img_w, img_h, exp_thresh)
-
-    @_interp.register_fake
-    def _(preds, anchors, classes, apg, img_w, img_h, exp_thresh):
-        n, A = preds.shape[0], anchors.shape[0]
-        return (preds.new_empty((n, A, 4), dtype=torch.float32), preds.new_empty((n, A), dtype=torch.float32),
-                preds.new_empty((n, A), dtype=torch.int64))
-
-    @custom_op("sqdet::filter_prediction", mutates_args=())
-    def _filt(boxes: torch.Tensor, probs: torch.Tensor, cls: torch.Tensor, classes: int, top_n: int, nms_thresh: float,
-              prob_thresh: float, max_out: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-        return filter_prediction(boxes, probs, cls, classes, top_n, nms_thresh, prob_thresh, max_out)
-
-    @_filt.register_fake
-    def _(boxes, probs, cls, classes, top_n, nms_thresh, prob_thresh, max_out):
-        n = probs.shape[0]
-        return (probs.new_empty((n, max_out, 4)), probs.new_empty((n, max_out)),
-                probs.new_empty((n, max_out), dtype=torch.int32), probs.new_empty((n, max_out), dtype=torch.int32),
-                probs.new_empty((n,), dtype=torch.int32))
-
-
-_register_custom_ops()
+from . import torch_ops as _torch_ops  # noqa: E402,F401  (registers the custom ops; see that module)
