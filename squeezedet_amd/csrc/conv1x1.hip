@@ -20,7 +20,14 @@ struct C1Args {
   int nstreams;    // waves per cout group
 };
 
-template <typename T, int NCH, int NT, int MT>
+// PERM (every cout group full: Cout % (16*NT) == 0): the wave gathers its A-fragment rows from the standard packing in ANOTHER
+// order, so that MFMA row i of tile n is cout 32*(n>>1) + 8*(i>>2) + 4*(n&1) + (i&3) of the group (float16; a leftover odd
+// tile and float32 keep 16-cout blocks: 16*n + 4*(i>>2) + (i&3)).  A lane group then holds the 8 consecutive couts of a tile
+// PAIR: one 16-byte store per pixel, the four lane groups of a pixel 64 CONTIGUOUS bytes per store instruction -- with the
+// standard order (a lane owns 4*NT consecutive couts) the four 16-byte pieces of an instruction lie 8*NT bytes apart, which
+// streams at about half the rate (tools/microbench/store_patterns.hip; fire2/expand1x1 stand-alone: 39 us for 150 MB).
+// Same products in the same order per cout: bitwise the same results.
+template <typename T, int NCH, int NT, int MT, bool PERM>
 __global__ __launch_bounds__(256) void conv1x1_stream(C1Args a) {
   constexpr int KG = Tr<T>::KG;
   constexpr int KC = 4 * KG;
@@ -35,16 +42,33 @@ __global__ __launch_bounds__(256) void conv1x1_stream(C1Args a) {
   i32x4 af[NCH][NT];
   {
     const i32x4* wp = reinterpret_cast<const i32x4*>(a.c.wp) + (size_t)group * NCH * NT * 64 + lane;
+    if constexpr (PERM) {
+      const i32x4* wg = reinterpret_cast<const i32x4*>(a.c.wp) + (size_t)group * NCH * NT * 64;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
+      for (int t = 0; t < NT; ++t) {
+        const bool pair = sizeof(T) == 2 && (t | 1) < NT;
+        const int cd = pair ? 32 * (t >> 1) + 8 * (j >> 2) + 4 * (t & 1) + (j & 3) : 16 * t + 4 * (j >> 2) + (j & 3);   // the cout this row computes
+        const int tn = (cd % (4 * NT)) >> 2, ti = 4 * (cd / (4 * NT)) + (cd & 3);                                         // where the packing keeps it
 #pragma unroll
-      for (int t = 0; t < NT; ++t) af[c][t] = wp[(c * NT + t) * 64];
+        for (int c = 0; c < NCH; ++c) af[c][t] = wg[(c * NT + tn) * 64 + 16 * g + ti];
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) af[c][t] = wp[(c * NT + t) * 64];
+    }
   }
-  const int cb = group * 16 * NT + g * 4 * NT;
+  const int cb = group * 16 * NT + (PERM ? 0 : g * 4 * NT);
+  // channel offset (within the group) of this lane's 4 couts of tile t
+  auto coff = [&](int t) {
+    if constexpr (!PERM) return t * 4;
+    else return (sizeof(T) == 2 && (t | 1) < NT) ? 32 * (t >> 1) + 8 * g + 4 * (t & 1) : 16 * t + 4 * g;
+  };
   f32x4 bias[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
-    bias[t] = cb + t * 4 < a.c.Cout ? *reinterpret_cast<const f32x4*>(a.c.bias + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bias[t] = cb + coff(t) < a.c.Cout ? *reinterpret_cast<const f32x4*>(a.c.bias + cb + coff(t)) : f32x4{0.f, 0.f, 0.f, 0.f};
   // couts this lane may store: Cout is a multiple of 4, whole tiles beyond Cout are skipped
   int nt_valid = 0;
 #pragma unroll
@@ -101,7 +125,22 @@ __global__ __launch_bounds__(256) void conv1x1_stream(C1Args a) {
           }
         }
         T* dst = y + (size_t)p * a.c.y_cstride + a.c.y_coffset + cb;
-        store_couts<T, NT>(dst, v, nt_valid);
+        if constexpr (PERM) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            if (sizeof(T) == 2 && (t | 1) < NT) {
+              if ((t & 1) == 0) {
+                const f16x8 h = {(f16)v[t][0], (f16)v[t][1], (f16)v[t][2], (f16)v[t][3],
+                                 (f16)v[t + 1 < NT ? t + 1 : t][0], (f16)v[t + 1 < NT ? t + 1 : t][1], (f16)v[t + 1 < NT ? t + 1 : t][2], (f16)v[t + 1 < NT ? t + 1 : t][3]};
+                *reinterpret_cast<f16x8*>(dst + coff(t)) = h;
+              }
+            } else {
+              store4<T>(dst + coff(t), v[t]);
+            }
+          }
+        } else {
+          store_couts<T, NT>(dst, v, nt_valid);
+        }
       }
     }
     if (nxt < a.ntiles) {
@@ -127,7 +166,11 @@ static void launch_c1(C1Args& a, hipStream_t st) {
   if (streams < 1) streams = 1;
   a.nstreams = streams;
   const int waves = streams * a.c.ngroups;
-  hipLaunchKernelGGL((conv1x1_stream<T, NCH, NT, MT>), dim3((waves + 3) / 4), dim3(256), 0, st, a);
+  // PERM: whole cout groups and 16-byte aligned rows (float16 pairs store 16 bytes at 16-byte channel offsets)
+  const bool perm = a.c.Cout % (16 * NT) == 0 && a.c.y_cstride % 8 == 0 && a.c.y_coffset % 8 == 0 &&
+                    (reinterpret_cast<uintptr_t>(a.c.y) & 15) == 0 && tune(TUNE_DBG) != 50;
+  if (perm) hipLaunchKernelGGL((conv1x1_stream<T, NCH, NT, MT, true>), dim3((waves + 3) / 4), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv1x1_stream<T, NCH, NT, MT, false>), dim3((waves + 3) / 4), dim3(256), 0, st, a);
 }
 
 template <typename T, int NCH, int NT>

@@ -66,8 +66,25 @@ def run(args):
         en.synchronize()
         us = st.elapsed_time(en) / ITERS * 1e3
         alg = (args.batch * h * w * (cin + cout) + cin * cout) * 2 + 4 * cout
-        plan.append(dict(layer=name, launches=WARM + ITERS, warm=WARM, alg_bytes=alg, h=h, w=w, cin=cin, cout=cout, event_us=us))
-        print("%-22s %9.2f %9.1f %8.0f %8.3f" % (name, us, alg / 1e6, alg / us / 1e3, alg / us / 1e3 / HBM_PEAK))
+        # the size bound: a plain copy kernel (sqdet_copy_channels) moving the SAME number of bytes -- a [pixels, 64] float16
+        # tensor of (in + out) / 2 bytes read and written once, sources rotating the same way
+        cp_pix = (in_bytes + args.batch * h * w * cout * 2) // 2 // 128
+        csrc = [torch.empty((cp_pix, 64), dtype=torch.float16, device=dev).zero_() for _ in range(max(2, int(np.ceil(1.3 * (256 << 20) / (cp_pix * 128)))))]
+        cdst = torch.empty((cp_pix, 64), dtype=torch.float16, device=dev)
+        for i in range(WARM):
+            ops.copy_channels(csrc[i % len(csrc)], cdst, 0)
+        torch.cuda.synchronize()
+        st.record()
+        for i in range(ITERS):
+            ops.copy_channels(csrc[(WARM + i) % len(csrc)], cdst, 0)
+        en.record()
+        en.synchronize()
+        cp_us = st.elapsed_time(en) / ITERS * 1e3
+        del csrc, cdst
+        plan.append(dict(layer=name, launches=WARM + ITERS, warm=WARM, alg_bytes=alg, h=h, w=w, cin=cin, cout=cout, event_us=us,
+                         copy_us=cp_us, copy_bytes=cp_pix * 256))
+        print("%-22s %9.2f %9.1f %8.0f %8.3f   copy of the same bytes: %6.2f us = %5.0f GB/s" % (name, us, alg / 1e6, alg / us / 1e3, alg / us / 1e3 / HBM_PEAK,
+                                                                                             cp_us, cp_pix * 256 / cp_us / 1e3))
         del xs, y
         torch.cuda.empty_cache()
     if args.plan:
@@ -98,7 +115,9 @@ def summarize(plan_path, trace_csv, fetch_csv=None, write_csv=None):
     print("# alg = input + output + weights, each touched once; traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes) from separate")
     print("# rocprofv3 --pmc passes of the same command (gfx950 correction, MI355X_MICROARCH.md); frac = alg GB/s / 8000.")
     print("# In the benchmarked plan these convs are not launches: a module is one fused kernel (DESIGN.md section 3).")
-    print("%-22s %-34s %8s %8s %8s %7s %10s %8s" % ("layer", "kernel", "us", "alg MB", "GB/s", "frac", "traffic MB", "traf/alg"))
+    print("# copy = sqdet_copy_channels moving the same number of bytes (HIP events, same rotation): what a plain streaming kernel")
+    print("# reaches at this launch SIZE -- below ~100 MB a launch is ramp + tail, not bandwidth.")
+    print("%-22s %-34s %8s %8s %8s %7s %10s %8s %9s %9s" % ("layer", "kernel", "us", "alg MB", "GB/s", "frac", "traffic MB", "traf/alg", "copy us", "copy GB/s"))
     i = 0
     for p in plan:
         rows = tr[i + p["warm"]: i + p["launches"]]
@@ -112,8 +131,9 @@ def summarize(plan_path, trace_csv, fetch_csv=None, write_csv=None):
             w = sum(pmc[1][i + p["warm"]: i + p["launches"]]) / len(rows)
             tb = 2 * f * 1024 + w * 1024
             traf, ratio = "%10.1f" % (tb / 1e6), "%8.2f" % (tb / p["alg_bytes"])
-        print("%-22s %-34s %8.2f %8.1f %8.0f %7.3f %10s %8s" % (p["layer"], kn, us, p["alg_bytes"] / 1e6, p["alg_bytes"] / us / 1e3,
-                                                                p["alg_bytes"] / us / 1e3 / HBM_PEAK, traf, ratio))
+        print("%-22s %-34s %8.2f %8.1f %8.0f %7.3f %10s %8s %9.2f %9.0f" % (p["layer"], kn, us, p["alg_bytes"] / 1e6, p["alg_bytes"] / us / 1e3,
+                                                                            p["alg_bytes"] / us / 1e3 / HBM_PEAK, traf, ratio, p.get("copy_us", 0.0),
+                                                                            p.get("copy_bytes", 0) / max(p.get("copy_us", 1.0), 1e-9) / 1e3))
         i += p["launches"]
 
 
