@@ -2,7 +2,8 @@
 // conv1 + pool1 of SqueezeDet (reference src/nets/squeezeDet.py:40-44: 3x3/s2 SAME + pool SAME), SqueezeDet+
 // (src/nets/squeezeDetPlus.py:40-44: 7x7/s2 VALID + pool VALID) and ResNet50 (src/nets/resnet50_convDet.py:41-45: 7x7/s2,
 // 64 couts, pool VALID).  Unfused, conv1 writes 188x621x64 and pool1 reads it back -- 36.4 MB of the 133 MB per image
-// (fp16); fused, the conv activations never leave the CU.  Kernels: stem3.hip (persistent; fp16 3x3) and stem2.hip (strip
+// (fp16); fused, the conv activations never leave the CU.  Kernels: stem3.hip (persistent; fp16 3x3), stem4.hip (the same with
+// lane-local pooling over three column phases: opt-in, "stem_algo" 4 -- faster alone, no gain inside the forward) and stem2.hip (strip
 // kernel with the pool in registers; every other shape / dtype).  (The round-1 LDS-conv-tile kernel that lived here -- conv
 // tile written to LDS, pooled from LDS -- was superseded by both and is gone.)
 #include "stem.h"
@@ -29,7 +30,11 @@ int stem_launch(const void* x, const void* w_packed, const float* bias, void* y,
   a.y_cstride = y_cstride; a.y_coffset = y_coffset;
   a.ws2 = nullptr; a.bs2 = nullptr; a.s_out = nullptr;
   if (a.Hp <= 0 || a.Wp <= 0) return SQDET_OK;
-  if (tune(TUNE_STEM_ALGO) == 0) {  // default for the fp16 3x3 stem: the persistent kernel (stem3.hip)
+  if (tune(TUNE_STEM_ALGO) == 4) {  // "stem_algo" 4: the phase kernel (stem4.hip; wide images only, else the kernels below)
+    const int rc4 = stem_phase_launch(a, k, dtype, st, handled);
+    if (rc4 != SQDET_OK || *handled) return rc4;
+  }
+  if (tune(TUNE_STEM_ALGO) == 0 || tune(TUNE_STEM_ALGO) == 3 || tune(TUNE_STEM_ALGO) == 4) {  // default for the fp16 3x3 stem: the persistent kernel (stem3.hip)
     const int rc3 = stem_pers_launch(a, k, dtype, st, handled);
     if (rc3 != SQDET_OK || *handled) return rc3;
   }
@@ -44,7 +49,7 @@ int stem_squeeze_launch(const void* x, const void* w_packed, const float* bias, 
                         void* s_out, int n, int h, int w, int cout, int k, int conv_pad, int pool_pad, int s2, int dtype,
                         hipStream_t st, bool* handled) {
   *handled = false;
-  if (conv_algo() != 0 || tune(TUNE_STEM_ALGO) != 0 || k != 3 || cout != 64 || s2 != 16 || dtype != SQDET_F16) return SQDET_OK;
+  if (conv_algo() != 0 || (tune(TUNE_STEM_ALGO) != 0 && tune(TUNE_STEM_ALGO) < 3) || k != 3 || cout != 64 || s2 != 16 || dtype != SQDET_F16) return SQDET_OK;
   const ConvGeom g = conv_geom(k, 3, cout, dtype), gs = conv_geom(1, cout, s2, dtype);
   if (!g.gather || g.ngroups != 1 || gs.gather || gs.nchunk != 2 || gs.nt != 1 || gs.ngroups != 1) return SQDET_OK;
   StemArgs a;
@@ -59,11 +64,15 @@ int stem_squeeze_launch(const void* x, const void* w_packed, const float* bias, 
   a.y_cstride = cout; a.y_coffset = 0;
   a.ws2 = ws2_packed; a.bs2 = bs2; a.s_out = s_out;
   if (a.Hp <= 0 || a.Wp <= 0) return SQDET_OK;
+  if (tune(TUNE_STEM_ALGO) == 4) {
+    const int rc4 = stem_phase_launch(a, k, dtype, st, handled);
+    if (rc4 != SQDET_OK || *handled) return rc4;
+  }
   return stem_pers_launch(a, k, dtype, st, handled);
 }
 
 bool stem_squeeze_eligible(int h, int w, int cout, int k, int conv_pad, int pool_pad, int s2, int dtype, int n) {
-  if (conv_algo() != 0 || tune(TUNE_STEM_ALGO) != 0 || k != 3 || cout != 64 || s2 != 16 || dtype != SQDET_F16) return false;
+  if (conv_algo() != 0 || (tune(TUNE_STEM_ALGO) != 0 && tune(TUNE_STEM_ALGO) < 3) || k != 3 || cout != 64 || s2 != 16 || dtype != SQDET_F16) return false;
   const int plc = pad_before(w, k, 2, conv_pad);
   const int hc = out_size(h, k, 2, conv_pad), wc = out_size(w, k, 2, conv_pad);
   const int hp = out_size(hc, 3, 2, pool_pad), wp = out_size(wc, 3, 2, pool_pad);

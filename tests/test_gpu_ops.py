@@ -769,3 +769,34 @@ def test_convdet_score_epilogue_rejects_other_heads():
     packed = ops.pack_conv_weights(w, torch.float32)
     with pytest.raises(_lib.SqdetUnsupported):
         ops.convdet(x, packed, torch.zeros(72, device=DEV), 9, 3)
+
+
+PHASE_STEM_CASES = [(2, 375, 1242, "SAME", "SAME"), (1, 384, 1248, "SAME", "SAME"), (3, 97, 600, "SAME", "SAME"), (1, 64, 1000, "SAME", "VALID"),
+                    (2, 31, 524, "VALID", "SAME"), (1, 200, 2050, "SAME", "SAME"), (5, 19, 786, "VALID", "VALID")]
+
+
+@pytest.mark.parametrize("sq", [False, True], ids=["plain", "squeeze"])
+@pytest.mark.parametrize("case", PHASE_STEM_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_phase_stem_equals_persistent_stem(case, sq):
+    """stem4.hip (opt-in, stem_algo = 4: lane = pooled column, three column phases, lane-local pooling; images >= 523 wide)
+    BITWISE against stem3.hip's persistent strip-lane kernel (the default), plain and squeeze forms: full KITTI sizes,
+    several images, ragged right / bottom tiles, VALID paddings, an image wider than 32 tiles."""
+    ops = _ops()
+    N, H, W, cpad, ppad = case
+    rs = np.random.RandomState(H + 3 * W)
+    x = torch.from_numpy((rs.randint(0, 256, (N, H, W, 3)) - 110.0).astype(np.float32)).to(DEV, torch.float16)
+    w = torch.from_numpy((rs.randn(3, 3, 3, 64) * (2.0 / 27) ** 0.5 / 64).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(rs.uniform(-0.5, 0.5, 64).astype(np.float32)).to(DEV)
+    ws = torch.from_numpy((rs.randn(1, 1, 64, 16) * 0.2).astype(np.float32)).to(DEV)
+    bs = torch.from_numpy(rs.uniform(-0.1, 0.1, 16).astype(np.float32)).to(DEV)
+    pk, pks = ops.pack_conv_weights(w, torch.float16), ops.pack_conv_weights(ws, torch.float16)
+    run = lambda: ops.stem_conv_pool_squeeze(x, pk, b, pks, bs, cpad, ppad) if sq else ops.stem_conv_pool(x, pk, b, cpad, ppad)
+    want = run()
+    ops.set_option("stem_algo", 4)
+    try:
+        got = run()
+    finally:
+        ops.set_option("stem_algo", 0)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape and float(want.float().abs().max()) > 0.1
+    assert torch.equal(got, want)
