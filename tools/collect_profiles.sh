@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): everything profiles/ needs for one build, into gpurun_out/$1/.
-#   gpurun -- 'bash tools/collect_profiles.sh r02_x'          (~2.3 GPU-minutes)
+#   gpurun -- 'bash tools/collect_profiles.sh r03_x'          (~3 GPU-minutes)
 #   gpurun -- 'FAST=1 bash tools/collect_profiles.sh r02_x'   (~1 GPU-minute: the headline's bench lines, layer table, kernel
 #       stats and the fingerprinted PMC traffic only -- what bench.py's roofline.traffic needs after a csrc change)
 set -u
@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench lines (driver-style short run of the headline too)
-CONFIGS="sqdet_infer sqdetplus_infer sqdet_train_fp32 res50_train_fp16"
+CONFIGS="sqdet_infer sqdet_infer_384 sqdet_sample_b1 sqdetplus_infer sqdet_train_fp32 res50_train_fp16 sqdet_train_fp16"
 [ "${FAST:-0}" = "1" ] && CONFIGS="sqdet_infer"
 for c in $CONFIGS; do
   python $R/bench.py --config $c > $OUT/bench_$c.json 2> $OUT/bench_$c.err
@@ -22,7 +22,7 @@ rocprofv3 --kernel-trace --stats -d $OUT/kstats -o ks --output-format csv -- pyt
 python $R/profiles/summarize.py $(find $OUT/kstats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline" >> $OUT/kstats.log 2>&1
 if [ "${FAST:-0}" != "1" ]; then
 # 2b. kernel stats of the other configs (which kernels carry SqueezeDet+, ResNet50 inference and the two training steps)
-for c in sqdetplus_infer sqdet_train_fp32 res50_train_fp16; do
+for c in sqdetplus_infer sqdet_train_fp32 res50_train_fp16 sqdet_train_fp16; do
   rocprofv3 --kernel-trace --stats -d $OUT/ks_$c -o ks --output-format csv -- python $R/bench.py --config $c --no-cpu-baseline --no-graph > $OUT/kstats_$c.log 2>&1
   python $R/profiles/summarize.py $(find $OUT/ks_$c -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$c.txt "rocprofv3 --kernel-trace --stats -- python bench.py --config $c --no-cpu-baseline --no-graph" >> $OUT/kstats_$c.log 2>&1
   rm -rf $OUT/ks_$c
