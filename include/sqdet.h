@@ -266,6 +266,17 @@ int sqdet_detect_filter_scored(const void* preds, const float* anchors, const fl
  * master weights, weight gradients and optimizer -- BASELINE.json configs[4] "fp16 training").
  */
 
+/* MANY kernels packed in ONE launch (a training step re-packs every trainable conv kernel twice after the optimizer step:
+ * forward fragment order = sqdet_conv_pack_weights, backward-data order = sqdet_conv_pack_weights_bwd_data; 62 launches in
+ * SqueezeDet's step).  sqdet_conv_pack_many_prepare fills a HOST table of sqdet_conv_pack_many_table_bytes(n) bytes from
+ * per-item arrays (device pointers of the float32 HWIO kernels and of the packed outputs, k / cin / cout, bwd_data flags)
+ * and reports the grid; the caller copies the table to the device once; sqdet_conv_pack_many runs it (same bytes as the
+ * per-kernel entry points produce). */
+size_t sqdet_conv_pack_many_table_bytes(int nitems);
+int sqdet_conv_pack_many_prepare(const float* const* w_hwio_f32, void* const* packed, const int* k, const int* cin, const int* cout,
+                                 const int* bwd_data, int nitems, int dtype, void* table_host, int* total_blocks);
+int sqdet_conv_pack_many(const void* table_dev, int nitems, int total_blocks, int dtype, sqdet_stream_t stream);
+
 /* Backward-data: dx = conv(dy, rot180(W)^T).  pack: float32 HWIO [k,k,cin,cout] -> fragment order
  * of the [k,k,cout,cin] kernel (same size as sqdet_conv_packed_bytes(k, cout, cin, dtype)).
  * dy is channels [dy_coffset, +cout) of rows dy_cstride wide (a fire module's concat gradient);

@@ -57,6 +57,9 @@ SIGNATURES = {
     "sqdet_net_set_scores": (ci, [vp, vp]),
     "sqdet_net_scores_supported": (ci, [vp]),
     "sqdet_conv_pack_weights_bwd_data": (ci, [vp, vp, ci, ci, ci, ci, vp]),
+    "sqdet_conv_pack_many_table_bytes": (sz, [ci]),
+    "sqdet_conv_pack_many_prepare": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, vp, C.POINTER(ci)]),
+    "sqdet_conv_pack_many": (ci, [vp, ci, ci, ci, vp]),
     "sqdet_conv2d_nhwc_bwd_data": (ci, [vp, vp, vp] + [ci] * 10 + [vp]),
     "sqdet_conv2d_nhwc_bwd_data_relu": (ci, [vp, vp, vp, vp] + [ci] * 10 + [vp]),
     "sqdet_conv2d_bwd_filter_workspace_bytes": (sz, [ci] * 6),

@@ -384,6 +384,52 @@ class PackedConvBwd:
                                                      self.cout, code, stream_ptr()), "sqdet_conv_pack_weights_bwd_data")
 
 
+class PackPlan:
+    """Every trainable conv kernel of a trainer packed in ONE launch (sqdet_conv_pack_many): the forward fragment order
+    (PackedConv) and, for the convs whose input needs a gradient, the backward-data conv's order (PackedConvBwd), into
+    persistent buffers.  weights: {name: float32 HWIO tensor (a VIEW whose storage does not move: the trainer's flat
+    parameter buffer)}; run() re-packs all of them from their current values."""
+
+    def __init__(self, weights, dtype, bwd_names=()):
+        self.dtype = dtype
+        code = dtype_code(dtype)
+        self.fwd, self.bwd = {}, {}
+        items = []
+        for name, w in weights.items():
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                raise _lib.SqdetError("PackPlan: %s must be a contiguous float32 HWIO tensor" % name)
+            k, k2, cin, cout = [int(v) for v in w.shape]
+            pc = PackedConv.__new__(PackedConv)
+            pc.k, pc.cin, pc.cout, pc.dtype = k, cin, cout, dtype
+            pc.data = torch.empty(int(lib().sqdet_conv_packed_bytes(k, cin, cout, code)), dtype=torch.uint8, device=w.device)
+            self.fwd[name] = pc
+            items.append((w, pc.data, k, cin, cout, 0))
+            if name in bwd_names:
+                pb = PackedConvBwd.__new__(PackedConvBwd)
+                pb.k, pb.cin, pb.cout, pb.dtype = k, cin, cout, dtype
+                pb.data = torch.empty(int(lib().sqdet_conv_packed_bytes(k, cout, cin, code)), dtype=torch.uint8, device=w.device)
+                self.bwd[name] = pb
+                items.append((w, pb.data, k, cin, cout, 1))
+        n = len(items)
+        self.n = n
+        self._keep = items
+        dev = items[0][0].device
+        arr = lambda vals, ct: (ct * n)(*vals)
+        wp = arr([it[0].data_ptr() for it in items], C.c_void_p)
+        op = arr([it[1].data_ptr() for it in items], C.c_void_p)
+        ks, cis, cos, bw = [arr([it[j] for it in items], C.c_int) for j in (2, 3, 4, 5)]
+        nbytes = int(lib().sqdet_conv_pack_many_table_bytes(n))
+        host = (C.c_ubyte * nbytes)()
+        blocks = C.c_int()
+        check(lib().sqdet_conv_pack_many_prepare(wp, op, ks, cis, cos, bw, n, code, host, C.byref(blocks)), "sqdet_conv_pack_many_prepare")
+        self.blocks = int(blocks.value)
+        self.table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
+
+    def run(self):
+        check(lib().sqdet_conv_pack_many(_dev(self.table, "table"), self.n, self.blocks, dtype_code(self.dtype), stream_ptr()),
+              "sqdet_conv_pack_many")
+
+
 def conv2d_bwd_data(dy, packed_bwd, dx=None, dy_coffset=0, accumulate=False, relu_of=None):
     """dx = conv(dy[..., dy_coffset:dy_coffset+cout], rot180(W)^T) (stride-1 SAME convs).  dy [N,H,W,Ctot].
     relu_of [N,H,W,cin]: the ReLU output dx is the gradient of -- dx (after the accumulation) is zeroed where it is <= 0

@@ -240,6 +240,11 @@ class SqueezeDetTrainer(_TrainerBase):
     def __init__(self, model, process_group=None, **kw):
         _TrainerBase.__init__(self, model, process_group, **kw)
         self.layers = self._layer_list()
+        # every trainable kernel is re-packed (forward order; backward-data order for all but the lowest trainable conv) by
+        # ONE launch at the top of a step instead of 62 (ops.PackPlan); the frozen conv1 is packed once
+        kernels = collections.OrderedDict((n[:-len("/kernels")], self.view[n]) for n in self.names if n.endswith("/kernels"))
+        self.packplan = ops.PackPlan(kernels, self.adt, bwd_names=set(kernels))
+        self._frozen_packed = {}
 
     # ---- the forward graph as a list (nets/squeezeDet.py:30-79) ----
     def _layer_list(self):
@@ -264,7 +269,13 @@ class SqueezeDetTrainer(_TrainerBase):
         return seq
 
     def _pack(self, name):
-        return ops.pack_conv_weights(self.model.params[name + "/kernels"], self.adt)
+        if name in self.packplan.fwd:
+            return self.packplan.fwd[name]
+        w = self.model.params[name + "/kernels"]     # frozen layers (conv1): re-packed only when someone wrote the variable (load_params)
+        hit = self._frozen_packed.get(name)
+        if hit is None or hit[1] != w._version:
+            hit = self._frozen_packed[name] = (ops.pack_conv_weights(w, self.adt), w._version)
+        return hit[0]
 
     def step(self, images, input_mask, box_delta_input, box_input, labels, dropout_mask=None, apply_update=True,
              keep_activations=False, num_objects=None):
@@ -284,6 +295,7 @@ class SqueezeDetTrainer(_TrainerBase):
         no host round trip (hipGraph-capturable).  _finish_step (all-reduce + update) completes the step."""
         m, mc, P = self.model, self.mc, self.model.params
         acts = {}
+        self.packplan.run()          # the variables may have changed since the last step (optimizer, load_params): one launch
         x = m._to_input(images)
         B = int(x.shape[0])
         t, mask, delta, box, lab, num_objects = self._labels(B, input_mask, box_delta_input, box_input, labels, num_objects, num_objects_is_global)
@@ -350,7 +362,7 @@ class SqueezeDetTrainer(_TrainerBase):
         # ---------------- backward ----------------
         self.flat_grads.zero_()
         gs = 1.0 / self.loss_scale      # g: gradient w.r.t. the current layer's OUTPUT (pre-activation mask applied below)
-        bwd = lambda name: ops.PackedConvBwd(P[name + "/kernels"], self.adt)
+        bwd = lambda name: self.packplan.bwd[name] if name in self.packplan.bwd else ops.PackedConvBwd(P[name + "/kernels"], self.adt)
 
         def has_trainable(rec):
             if rec[0] == "conv":

@@ -584,3 +584,24 @@ def test_build_labels_vs_reference_golden(name):
             assert dm[b, a] == 1 and dl[b, a, int(label[b, k])] == 1 and dl[b, a].sum() == 1
             np.testing.assert_allclose(dd[b, a], delta[b, k], rtol=1e-6, atol=1e-7)
             assert np.array_equal(db[b, a], bbox[b, k].astype(np.float32))
+
+
+def test_pack_many_equals_the_per_kernel_packers():
+    """sqdet_conv_pack_many (ops.PackPlan: every trainable kernel of a step packed by one launch, forward and backward-data
+    orders) writes exactly the bytes of sqdet_conv_pack_weights / sqdet_conv_pack_weights_bwd_data, float16 and float32,
+    for SqueezeDet's kernel shapes incl. ragged channel counts -- and re-packs in place after the weights changed."""
+    import collections
+    ops = _ops()
+    rs = np.random.RandomState(9)
+    shapes = [(1, 64, 16), (1, 16, 64), (3, 16, 64), (1, 256, 48), (3, 48, 192), (1, 768, 96), (3, 96, 384), (3, 768, 72), (3, 24, 40)]
+    for tdt in (torch.float16, torch.float32):
+        ws = collections.OrderedDict(("k%d" % i, torch.from_numpy(rs.randn(k, k, ci, co).astype(np.float32)).to(DEV)) for i, (k, ci, co) in enumerate(shapes))
+        plan = ops.PackPlan(ws, tdt, bwd_names=set(ws))
+        for rep in range(2):
+            plan.run()
+            torch.cuda.synchronize()
+            for n, w in ws.items():
+                assert torch.equal(plan.fwd[n].data, ops.pack_conv_weights(w, tdt).data), (n, tdt)
+                assert torch.equal(plan.bwd[n].data, ops.PackedConvBwd(w, tdt).data), (n, tdt)
+            for w in ws.values():
+                w.mul_(-0.5)                       # in place: the plan reads the same storage
