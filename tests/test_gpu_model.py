@@ -378,3 +378,38 @@ def test_zz_report_observed_errors(capsys):
         print("\nobserved max-error / tensor-scale vs the oracle:")
         for k in sorted(OBSERVED):
             print("  %-40s %.3e" % (k, OBSERVED[k]))
+
+
+def test_sample_png_config0_picks_vs_oracle():
+    """BASELINE configs[0]: the reference's data/sample.png (tests/golden/sample.png) through demo.py:186-199's path -- BGR
+    uint8 -> sqdet_preprocess_bgr (resize to 1248x384, mean subtraction) -> float32 SqueezeDet at batch 1 -> picks -- against
+    the oracle on the same file (its own preprocessing restatement, forward, interpret_output, filter_prediction).  The
+    prepared input agrees to float32 rounding, preds to 1e-3 (north_star), and the picks are identical when every decision has
+    a margin above the measured noise (else their overlap is reported and must still be high)."""
+    import os
+    from PIL import Image
+    from oracle import preproc_oracle as PO
+    from squeezedet_amd import ops
+    from tests import decision_margins as DM
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sample.png")
+    bgr = np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+    assert bgr.shape == (375, 1242, 3)
+    m, mc, params, storage = _model("squeezeDet", torch.float32, 1, None)
+    omc = O.kitti_squeezeDet_config()
+    x_ref = PO.preprocess_bgr(bgr, omc.IMAGE_HEIGHT, omc.IMAGE_WIDTH, omc.BGR_MEANS)[None]
+    x_dev = ops.preprocess_bgr(torch.from_numpy(bgr).to(DEV)[None], mc.IMAGE_HEIGHT, mc.IMAGE_WIDTH, mc.BGR_MEANS, torch.float32)
+    np.testing.assert_allclose(x_dev.cpu().numpy(), x_ref, rtol=0, atol=2e-4)
+    outs = m.run([m.preds, m.det_boxes, m.det_probs, m.det_class], {m.image_input: x_dev})
+    ob, op, oc, oi, cnt = m.filter_prediction_batch(outs[1], outs[2], outs[3])
+    torch.cuda.synchronize()
+    preds_ref, ref, dets = O.detect("squeezeDet", omc, params, torch.from_numpy(x_ref))
+    err = np.abs(outs[0].cpu().numpy() - preds_ref).max() / np.abs(preds_ref).max()
+    assert err < 1e-3, err
+    r = {k: ref[k][0] for k in ("det_boxes", "det_probs", "det_class", "pred_class_probs", "pred_conf")}
+    g = dict(det_boxes=outs[1][0].cpu().numpy(), det_probs=outs[2][0].cpu().numpy(), det_class=outs[3][0].cpu().numpy())
+    row = DM.image_margins(omc, r, g)
+    got, want = oi[0, :int(cnt[0])].cpu().tolist(), list(dets[0][3])
+    jac = len(set(got) & set(want)) / float(max(len(set(got) | set(want)), 1))
+    if row["decidable"]:
+        assert got == want, (row, got, want)
+    assert jac > 0.9, (row, jac)
