@@ -148,6 +148,11 @@ int sqdet_stem_conv_pool_squeeze_fwd(const void* x, const void* w_packed, const 
 int sqdet_fire_fwd(const void* x, const void* w_s, const float* b_s, const void* w_e1, const float* b_e1,
                    const void* w_e3, const float* b_e3, void* sq_scratch, void* y,
                    int n, int h, int w, int cin, int s1x1, int e1x1, int e3x3, int dtype, sqdet_stream_t stream);
+/* sqdet_fire_fwd that ALSO leaves the module's squeeze tensor relu(conv1x1(x)) in sq_out [n,h,w,s1x1] (training: the
+ * module's backward reads it); the fused kernels write it from their squeeze epilogue -- still one launch. */
+int sqdet_fire_fwd_keep(const void* x, const void* w_s, const float* b_s, const void* w_e1, const float* b_e1,
+                        const void* w_e3, const float* b_e3, void* sq_out, void* y, int n, int h, int w,
+                        int cin, int s1x1, int e1x1, int e3x3, int dtype, sqdet_stream_t stream);
 
 /* Fire module followed by max_pool 3x3 / stride 2 / SAME (fire3 -> pool3, fire5 -> pool5: nets/squeezeDet.py:49-57)
  * in one launch where the streaming kernel covers the shape: the pool is taken in registers and only the pooled

@@ -35,6 +35,7 @@ SIGNATURES = {
     "sqdet_stem_conv_pool_squeeze_supported": (ci, [ci] * 9),
     "sqdet_stem_conv_pool_squeeze_fwd": (ci, [vp] * 6 + [ci] * 9 + [vp]),
     "sqdet_fire_fwd": (ci, [vp] * 9 + [ci] * 8 + [vp]),
+    "sqdet_fire_fwd_keep": (ci, [vp] * 9 + [ci] * 8 + [vp]),
     "sqdet_fire_maxpool_fwd": (ci, [vp] * 10 + [ci] * 8 + [vp]),
     "sqdet_fire_expand_fwd": (ci, [vp] * 6 + [ci] * 8 + [vp]),
     "sqdet_fire_squeeze_next_supported": (ci, [ci] * 6),

@@ -94,6 +94,13 @@ int tune(int which);
 
 // fire2.hip: persistent streaming fused fire for the large, few-channel modules
 bool fire_stream_eligible(int cin, int s, int e1, int e3, int dtype);
+// (the *_keep forms also write the module's squeeze tensor: training)
+int fire_stream_launch_keep(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
+                            const float* b3, void* sq_out, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
+                            hipStream_t st, bool* handled);
+int fire_fused_launch_keep(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
+                           const float* b3, void* sq_out, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
+                           hipStream_t st, bool* handled);
 int fire_stream_launch(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
                        const float* b3, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
                        hipStream_t st, bool* handled);

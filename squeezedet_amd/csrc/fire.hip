@@ -42,6 +42,7 @@ struct FireArgs {
   int e_nt;        // tiles per packed group of the expand convs (same for both)
   int e1_tiles, e3_tiles;   // cout tiles (all groups) of expand1x1 / expand3x3
   unsigned x_bytes;         // size of the input tensor (32-bit buffer offsets)
+  void* sq_out;             // not NULL: the squeeze tensor [N,H,W,S] is ALSO written (training: its backward needs it)
 };
 
 // MT = tile rows per phase-B work item: 8 (a wave walks the whole tile per cout item) or 4 (two row
@@ -190,6 +191,11 @@ __global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused
             if (!inimg[mb]) v = f32x4{0.f, 0.f, 0.f, 0.f};   // SAME padding of the squeeze tensor
             unsigned char* dst = lds + (q >> 2) * FCHUNK + P[mb] * 64 + (((q & 3) ^ ((P[mb] >> 1) & 3)) << 4) + sub;
             store4<T>(reinterpret_cast<T*>(dst), v);
+            if (a.sq_out) {     // the tile's OWN 8 x 16 pixels (not the halo ring) that lie inside the image
+              const int hr = P[mb] / (FCOLS + 2), hc = P[mb] - hr * (FCOLS + 2);
+              if (inimg[mb] && hr >= 1 && hr <= FROWS && hc >= 1 && hc <= FCOLS)
+                store4<T>(reinterpret_cast<T*>(a.sq_out) + ((size_t)(n * a.H + oy0 + hr - 1) * a.W + ox0 + hc - 1) * a.S + ch0, v);
+            }
           }
         }
       }
@@ -410,10 +416,17 @@ bool fire_fused_eligible(int cin, int s, int e1, int e3, int dtype) {
 int fire_fused_launch(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
                       const float* b3, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
                       hipStream_t st, bool* handled) {
+  return fire_fused_launch_keep(x, ws, bs, w1, b1, w3, b3, nullptr, y, n, h, w, cin, s, e1, e3, dtype, st, handled);
+}
+
+// sq_out != NULL: the squeeze tensor is written as well (sqdet_fire_fwd_keep)
+int fire_fused_launch_keep(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
+                           const float* b3, void* sq_out, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
+                           hipStream_t st, bool* handled) {
   *handled = false;
   if (conv_algo() != 0) return SQDET_OK;
   if (tune(TUNE_FIRE_FUSE) != 3) {   // large maps with few channels: the persistent streaming kernel (fire2.hip)
-    const int rc = fire_stream_launch(x, ws, bs, w1, b1, w3, b3, y, n, h, w, cin, s, e1, e3, dtype, st, handled);
+    const int rc = fire_stream_launch_keep(x, ws, bs, w1, b1, w3, b3, sq_out, y, n, h, w, cin, s, e1, e3, dtype, st, handled);
     if (rc != SQDET_OK || *handled) return rc;
   }
   const int esz = dtype == SQDET_F16 ? 2 : 4;
@@ -436,6 +449,7 @@ int fire_fused_launch(const void* x, const void* ws, const float* bs, const void
   a.nch_x = gs.nchunk; a.x_pieces = cin * esz / 16; a.nch_s = g1.nchunk;
   a.e_nt = g1.nt; a.e1_tiles = e1_tiles; a.e3_tiles = e3_tiles;
   a.x_bytes = (unsigned)((long)n * h * w * cin * esz);
+  a.sq_out = sq_out;
   if ((long)n * a.tiles_x * a.tiles_y > 0x7fffffffL) return SQDET_OK;
   const bool ok = dtype == SQDET_F16 ? dispatch_fire<f16>(a, gs.nt, ntw, lds, st) : dispatch_fire<float>(a, gs.nt, ntw, lds, st);
   if (!ok) return SQDET_OK;

@@ -87,6 +87,8 @@ struct FireSArgs {
   const float* bs2;
   void* s_out;
   int S2;
+  // not NULL (whole-module, unpooled form only): the module's OWN squeeze tensor [N,H,W,S] is also written (training)
+  void* sq_keep;
 };
 
 // RS = row split: the tile rows are divided among RS waves per cout pair (NWAVES = cout pairs x RS).  POOL: a wave
@@ -312,6 +314,13 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
                 const int hr = P / (SCOLS + 2);
                 const int PL = hr * LW + (P - hr * (SCOLS + 2));   // position in the LDS tile (row pitch LW)
                 store4<T>(reinterpret_cast<T*>(sqb + PL * 64 + ((q ^ ((PL >> 1) & 3)) << 4) + sub), v);
+                if constexpr (!POOL && NTS2 == 0) {
+                  if (a.sq_keep) {    // the tile's own pixels (not the halo ring) inside the image
+                    const int hc = P - hr * (SCOLS + 2);
+                    if (inimg[mb] && hr >= 1 && hr <= Geo<POOL>::ROWS && hc >= 1 && hc <= SCOLS)
+                      store4<T>(reinterpret_cast<T*>(a.sq_keep) + ((size_t)(n * a.H + oy0 + hr - 1) * a.W + ox0 + hc - 1) * a.S + ch0, v);
+                  }
+                }
               }
             }
           }
@@ -662,16 +671,33 @@ int fire_stream_launch(const void* x, const void* ws, const float* bs, const voi
   return fire_stream_launch_ex(x, ws, bs, w1, b1, w3, b3, y, n, h, w, cin, s, e1, e3, dtype, 0, st, handled);
 }
 
+static int fire_stream_launch_full(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
+                                   const float* b3, void* sq_keep, void* y, int n, int h, int w, int cin, int s, int e1, int e3,
+                                   int dtype, int pool, hipStream_t st, bool* handled);
+
+// the whole module with its squeeze tensor written as well (sq_out != NULL; the unpooled form)
+int fire_stream_launch_keep(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
+                            const float* b3, void* sq_out, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
+                            hipStream_t st, bool* handled) {
+  return fire_stream_launch_full(x, ws, bs, w1, b1, w3, b3, sq_out, y, n, h, w, cin, s, e1, e3, dtype, 0, st, handled);
+}
+
 // pool != 0: the module is followed by max_pool 3x3 / stride 2 / SAME and y is the POOLED tensor [n, ceil(h/2), ceil(w/2), e1+e3]
 int fire_stream_launch_ex(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
                           const float* b3, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
                           int pool, hipStream_t st, bool* handled) {
+  return fire_stream_launch_full(x, ws, bs, w1, b1, w3, b3, nullptr, y, n, h, w, cin, s, e1, e3, dtype, pool, st, handled);
+}
+
+static int fire_stream_launch_full(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
+                                   const float* b3, void* sq_keep, void* y, int n, int h, int w, int cin, int s, int e1, int e3,
+                                   int dtype, int pool, hipStream_t st, bool* handled) {
   *handled = false;
   int nchx, nts, nwaves;
   if (!stream_shape(cin, s, e1, e3, dtype, &nchx, &nts, &nwaves)) return SQDET_OK;
   FireSArgs a;
   a.x = x; a.y = y; a.ws = ws; a.w1 = w1; a.w3 = w3; a.bs = bs; a.b1 = b1; a.b3 = b3;
-  a.ws2 = nullptr; a.bs2 = nullptr; a.s_out = nullptr; a.S2 = 0;
+  a.ws2 = nullptr; a.bs2 = nullptr; a.s_out = nullptr; a.S2 = 0; a.sq_keep = pool ? nullptr : sq_keep;
   a.N = n; a.H = h; a.W = w; a.Cin = cin; a.S = s; a.E = e1;
   a.Hp = out_size(h, 3, 2, SQDET_PAD_SAME); a.Wp = out_size(w, 3, 2, SQDET_PAD_SAME);
   a.ptp = pad_before(h, 3, 2, SQDET_PAD_SAME); a.plp = pad_before(w, 3, 2, SQDET_PAD_SAME);
@@ -739,7 +765,7 @@ int fire_expand_squeeze_next_launch(const void* sq_in, const void* w1, const flo
   if (!fire_expand_squeeze_next_eligible(s, e1, e3, s2, pool, dtype)) return SQDET_OK;
   FireSArgs a;
   a.x = sq_in; a.y = nullptr; a.ws = nullptr; a.w1 = w1; a.w3 = w3; a.bs = nullptr; a.b1 = b1; a.b3 = b3;
-  a.ws2 = ws2; a.bs2 = bs2; a.s_out = s_out; a.S2 = s2;
+  a.ws2 = ws2; a.bs2 = bs2; a.s_out = s_out; a.S2 = s2; a.sq_keep = nullptr;
   a.N = n; a.H = h; a.W = w; a.Cin = s; a.S = s; a.E = e1;
   a.Hp = out_size(h, 3, 2, SQDET_PAD_SAME); a.Wp = out_size(w, 3, 2, SQDET_PAD_SAME);
   a.ptp = pad_before(h, 3, 2, SQDET_PAD_SAME); a.plp = pad_before(w, 3, 2, SQDET_PAD_SAME);
@@ -769,7 +795,7 @@ int fire_squeeze_next_launch(const void* x, const void* ws, const float* bs, con
   if (!fire_squeeze_next_eligible(cin, s, e1, e3, s2, dtype)) return SQDET_OK;
   FireSArgs a;
   a.x = x; a.y = nullptr; a.ws = ws; a.w1 = w1; a.w3 = w3; a.bs = bs; a.b1 = b1; a.b3 = b3;
-  a.ws2 = ws2; a.bs2 = bs2; a.s_out = s_out; a.S2 = s2;
+  a.ws2 = ws2; a.bs2 = bs2; a.s_out = s_out; a.S2 = s2; a.sq_keep = nullptr;
   a.N = n; a.H = h; a.W = w; a.Cin = cin; a.S = s; a.E = e1;
   a.Hp = a.Wp = a.ptp = a.plp = 0;
   a.tiles_x = (w + SCOLS - 1) / SCOLS; a.tiles_y = (h + 7) / 8;
@@ -802,7 +828,7 @@ int fire_expand_stream_launch(const void* sq_in, const void* w1, const float* b1
   if (!fire_expand_stream_eligible(s, e1, e3, dtype)) return SQDET_OK;
   FireSArgs a;
   a.x = sq_in; a.y = y; a.ws = nullptr; a.w1 = w1; a.w3 = w3; a.bs = nullptr; a.b1 = b1; a.b3 = b3;
-  a.ws2 = nullptr; a.bs2 = nullptr; a.s_out = nullptr; a.S2 = 0;
+  a.ws2 = nullptr; a.bs2 = nullptr; a.s_out = nullptr; a.S2 = 0; a.sq_keep = nullptr;
   a.N = n; a.H = h; a.W = w; a.Cin = s; a.S = s; a.E = e1;
   a.Hp = out_size(h, 3, 2, SQDET_PAD_SAME); a.Wp = out_size(w, 3, 2, SQDET_PAD_SAME);
   a.ptp = pad_before(h, 3, 2, SQDET_PAD_SAME); a.plp = pad_before(w, 3, 2, SQDET_PAD_SAME);

@@ -31,6 +31,9 @@ int stem_squeeze_launch(const void* x, const void* w_packed, const float* bias, 
                         void* s_out, int n, int h, int w, int cout, int k, int conv_pad, int pool_pad, int s2, int dtype,
                         hipStream_t st, bool* handled);
 bool stem_squeeze_eligible(int h, int w, int cout, int k, int conv_pad, int pool_pad, int s2, int dtype, int n);
+int fire_fused_launch_keep(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
+                           const float* b3, void* sq_out, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
+                           hipStream_t st, bool* handled);
 int fire_fused_launch(const void* x, const void* ws, const float* bs, const void* w1, const float* b1, const void* w3,
                       const float* b3, void* y, int n, int h, int w, int cin, int s, int e1, int e3, int dtype,
                       hipStream_t st, bool* handled);
@@ -1014,15 +1017,32 @@ extern "C" int sqdet_net_forward_timed(sqdet_net_t* net, const void* image_input
   return SQDET_OK;
 }
 
+static int fire_fwd_impl(const void* x, const void* w_s, const float* b_s, const void* w_e1, const float* b_e1,
+                         const void* w_e3, const float* b_e3, void* sq_scratch, void* y, int n, int h, int w,
+                         int cin, int s1x1, int e1x1, int e3x3, int dtype, bool keep, sqdet_stream_t stream);
+
 extern "C" int sqdet_fire_fwd(const void* x, const void* w_s, const float* b_s, const void* w_e1, const float* b_e1,
                               const void* w_e3, const float* b_e3, void* sq_scratch, void* y, int n, int h, int w,
                               int cin, int s1x1, int e1x1, int e3x3, int dtype, sqdet_stream_t stream) {
-  SQDET_REQUIRE(sq_scratch, "fire_fwd: null scratch");
+  return fire_fwd_impl(x, w_s, b_s, w_e1, b_e1, w_e3, b_e3, sq_scratch, y, n, h, w, cin, s1x1, e1x1, e3x3, dtype, false, stream);
+}
+
+extern "C" int sqdet_fire_fwd_keep(const void* x, const void* w_s, const float* b_s, const void* w_e1, const float* b_e1,
+                                   const void* w_e3, const float* b_e3, void* sq_out, void* y, int n, int h, int w,
+                                   int cin, int s1x1, int e1x1, int e3x3, int dtype, sqdet_stream_t stream) {
+  return fire_fwd_impl(x, w_s, b_s, w_e1, b_e1, w_e3, b_e3, sq_out, y, n, h, w, cin, s1x1, e1x1, e3x3, dtype, true, stream);
+}
+
+static int fire_fwd_impl(const void* x, const void* w_s, const float* b_s, const void* w_e1, const float* b_e1,
+                         const void* w_e3, const float* b_e3, void* sq_scratch, void* y, int n, int h, int w,
+                         int cin, int s1x1, int e1x1, int e3x3, int dtype, bool keep, sqdet_stream_t stream) {
+  SQDET_REQUIRE(sq_scratch, "fire_fwd: null squeeze buffer");
   hipStream_t st = as_stream(stream);
   bool handled = false;
   int rc = SQDET_OK;
-  if (tune(3) != 2) {  // one fused launch when eligible (the squeeze scratch is then untouched)
-    rc = fire_fused_launch(x, w_s, b_s, w_e1, b_e1, w_e3, b_e3, y, n, h, w, cin, s1x1, e1x1, e3x3, dtype, st, &handled);
+  if (tune(3) != 2) {  // one fused launch when eligible (keep: its squeeze epilogue also writes the squeeze tensor)
+    rc = fire_fused_launch_keep(x, w_s, b_s, w_e1, b_e1, w_e3, b_e3, keep ? sq_scratch : nullptr, y, n, h, w, cin, s1x1, e1x1, e3x3,
+                                dtype, st, &handled);
     if (rc != SQDET_OK || handled) return rc;
   }
   rc = conv2d_launch(x, w_s, b_s, sq_scratch, n, h, w, cin, s1x1, 1, 1, SQDET_PAD_SAME, 1, dtype, s1x1, 0, st);

@@ -136,17 +136,19 @@ def stem_conv_pool_squeeze(x, packed, bias, p_next_s, b_next_s, conv_padding="SA
     return so
 
 
-def fire(x, p_s, b_s, p_e1, b_e1, p_e3, b_e3):
-    """SqueezeDet._fire_layer (nets/squeezeDet.py:81-106)."""
+def fire(x, p_s, b_s, p_e1, b_e1, p_e3, b_e3, keep_squeeze=False):
+    """SqueezeDet._fire_layer (nets/squeezeDet.py:81-106).  keep_squeeze: returns (y, squeeze tensor) -- sqdet_fire_fwd_keep,
+    the fused launch also writes the squeeze tensor its backward needs."""
     n, h, w, cin = [int(v) for v in x.shape]
     sq = torch.empty((n, h, w, p_s.cout), dtype=x.dtype, device=x.device)
     y = torch.empty((n, h, w, p_e1.cout + p_e3.cout), dtype=x.dtype, device=x.device)
-    check(lib().sqdet_fire_fwd(_dev(x, "x"), _dev(p_s.data, "w_s"), _dev(b_s, "b_s", torch.float32),
+    fn = lib().sqdet_fire_fwd_keep if keep_squeeze else lib().sqdet_fire_fwd
+    check(fn(_dev(x, "x"), _dev(p_s.data, "w_s"), _dev(b_s, "b_s", torch.float32),
                                _dev(p_e1.data, "w_e1"), _dev(b_e1, "b_e1", torch.float32),
                                _dev(p_e3.data, "w_e3"), _dev(b_e3, "b_e3", torch.float32),
                                _dev(sq, "sq"), _dev(y, "y"), n, h, w, cin, p_s.cout, p_e1.cout, p_e3.cout,
                                dtype_code(x.dtype), stream_ptr()), "sqdet_fire_fwd")
-    return y
+    return (y, sq) if keep_squeeze else y
 
 
 def fire_maxpool(x, p_s, b_s, p_e1, b_e1, p_e3, b_e3):

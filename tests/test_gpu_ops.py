@@ -800,3 +800,26 @@ def test_phase_stem_equals_persistent_stem(case, sq):
     torch.cuda.synchronize()
     assert got.shape == want.shape and float(want.float().abs().max()) > 0.1
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("case", [("fire2", 64, 16, 64, 94, 311, 2), ("fire4", 128, 32, 128, 47, 156, 3), ("fire6", 256, 48, 192, 24, 78, 2),
+                                  ("fire10", 512, 96, 384, 22, 76, 1), ("ragged", 128, 32, 128, 13, 21, 2)], ids=lambda c: c[0])
+def test_fire_keep_squeeze(case, dtype):
+    """sqdet_fire_fwd_keep: the fused fire launch that ALSO writes its squeeze tensor (the training forward) -- y is bitwise
+    sqdet_fire_fwd's, the squeeze tensor bitwise the stand-alone squeeze conv's, streaming and tile kernels, both dtypes,
+    full and ragged maps."""
+    ops = _ops()
+    name, cin, s, e, H, W, N = case
+    tdt = torch.float16 if dtype == "fp16" else torch.float32
+    rs = np.random.RandomState(H + W + cin)
+    x = torch.from_numpy(np.maximum(rs.randn(N, H, W, cin), 0).astype(np.float32)).to(DEV, tdt).contiguous()
+    mk = lambda k, ci, co: torch.from_numpy((rs.randn(k, k, ci, co) * (2.0 / (k * k * ci)) ** 0.5).astype(np.float32)).to(DEV)
+    ws, w1, w3 = mk(1, cin, s), mk(1, s, e), mk(3, s, e)
+    bs, b1, b3 = [torch.from_numpy(rs.uniform(-0.2, 0.2, c).astype(np.float32)).to(DEV) for c in (s, e, e)]
+    ps, p1, p3 = [ops.pack_conv_weights(w_, tdt) for w_ in (ws, w1, w3)]
+    y, sq = ops.fire(x, ps, bs, p1, b1, p3, b3, keep_squeeze=True)
+    y0 = ops.fire(x, ps, bs, p1, b1, p3, b3)
+    sq0 = ops.conv2d_nhwc(x, ps, bs, 1, "SAME", True)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0) and torch.equal(sq, sq0)
