@@ -18,6 +18,7 @@ num_objects lives on the device (sqdet_sum_f32 of the mask) and the overflow fla
 loss + backward of a step has no host round trip and can be replayed as one hipGraph (GraphedStep below).
 """
 import collections
+import os
 
 import numpy as np
 import torch
@@ -66,7 +67,7 @@ class _TrainerBase:
     the optimizer kernel and halves the scale; `growth_interval` clean steps double it."""
 
     def __init__(self, model, process_group=None, loss_scale=1024.0, growth_interval=200, lazy_overflow_check=None,
-                 global_num_objects=False, seed=0):
+                 global_num_objects=False, seed=0, overlap_wgrad=True):
         if model.dtype not in (torch.float32, torch.float16):
             raise SqdetError("training runs in float32 (the reference's training dtype) or float16 (mixed precision)")
         self.adt = model.dtype                       # activation dtype
@@ -90,6 +91,12 @@ class _TrainerBase:
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
         self.global_num_objects = bool(global_num_objects)
+        # overlap_wgrad: a layer's backward-filter launches (weight gradient + its slab reduction, BN-fold backward) run on a
+        # side stream beside the backward-data chain -- the two only share inputs.  On the late 24 x 78 maps a launch cannot
+        # fill the chip (15-37 k pixels), so the pair really runs concurrently; inside a captured step the fork / join
+        # become graph edges.  Same kernels, same order per buffer: bitwise the sequential results.
+        self.overlap_wgrad = bool(overlap_wgrad) and os.environ.get("SQDET_WGRAD_OVERLAP", "1") != "0"
+        self._wg_stream, self._wg_keep = None, []
         # dropout masks are independent across the global batch (one tf.nn.dropout over all samples in the reference,
         # nets/squeezeDet.py:74): every replica draws from its own counter stream -- only parameters and momentum must
         # match across ranks, masks must not
@@ -123,6 +130,33 @@ class _TrainerBase:
         if self.world > 1:      # replicas start from rank 0's variables and momentum: they stay bit-identical from here on
             torch.distributed.broadcast(self.flat_params, src=torch.distributed.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
             torch.distributed.broadcast(self.flat_accum, src=torch.distributed.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+
+    def _wgrad(self, fn, *reads):
+        """Runs fn() -- weight-gradient launches writing into the flat gradient bucket -- behind everything issued so far,
+        on the side stream when overlap_wgrad; `reads`: tensors it reads that the caller is about to drop (kept alive
+        until _join_wgrad)."""
+        if not self.overlap_wgrad:
+            fn()
+            return
+        if self._wg_stream is None:
+            self._wg_stream = torch.cuda.Stream(device=self.dev)
+        cur = torch.cuda.current_stream()
+        self._wg_stream.wait_stream(cur)
+        with torch.cuda.stream(self._wg_stream):
+            fn()
+        self._wg_keep.extend(reads)
+
+    def _before_inplace(self, t):
+        """The caller is about to write `t` in place on its stream: if a pending side-stream weight gradient reads it, wait for
+        the side stream first (ResNet's residual gradients are shared by the branch and the shortcut and accumulated into)."""
+        if self._wg_stream is not None and any(t is r for r in self._wg_keep):
+            torch.cuda.current_stream().wait_stream(self._wg_stream)
+            self._wg_keep = []
+
+    def _join_wgrad(self):
+        if self._wg_stream is not None and self.overlap_wgrad:
+            torch.cuda.current_stream().wait_stream(self._wg_stream)
+        self._wg_keep = []
 
     def learning_rate(self):
         mc = self.mc
@@ -400,7 +434,8 @@ class SqueezeDetTrainer(_TrainerBase):
                     ops.relu_bwd(y, g)
                 k = node.attrs["size"]
                 cin, cout = int(xin.shape[3]), int(y.shape[3])
-                ops.conv2d_bwd_filter(xin, g, k, cin, cout, dw=self.gview[name + "/kernels"], db=self.gview[name + "/biases"], grad_scale=gs)
+                self._wgrad(lambda xin=xin, g=g, k=k, cin=cin, cout=cout, name=name: ops.conv2d_bwd_filter(
+                    xin, g, k, cin, cout, dw=self.gview[name + "/kernels"], db=self.gview[name + "/biases"], grad_scale=gs), g)
                 masked = False
                 if need_dx:
                     if name == "conv12" and keep != 1.0:
@@ -418,15 +453,19 @@ class SqueezeDetTrainer(_TrainerBase):
                 ne1, ne3, ns = e1.shape[3], e3.shape[3], sq.shape[3]
                 if not masked:
                     ops.relu_bwd(y, g)      # both expand convs end in ReLU
-                ops.conv2d_bwd_filter(s, g, 1, ns, ne1, dy_coffset=0, dw=self.gview[e1.name + "/kernels"], db=self.gview[e1.name + "/biases"], grad_scale=gs)
-                ops.conv2d_bwd_filter(s, g, 3, ns, ne3, dy_coffset=ne1, dw=self.gview[e3.name + "/kernels"], db=self.gview[e3.name + "/biases"], grad_scale=gs)
+                def expand_wgrads(s=s, g=g, ns=ns, ne1=ne1, ne3=ne3, e1=e1, e3=e3):
+                    ops.conv2d_bwd_filter(s, g, 1, ns, ne1, dy_coffset=0, dw=self.gview[e1.name + "/kernels"], db=self.gview[e1.name + "/biases"], grad_scale=gs)
+                    ops.conv2d_bwd_filter(s, g, 3, ns, ne3, dy_coffset=ne1, dw=self.gview[e3.name + "/kernels"], db=self.gview[e3.name + "/biases"], grad_scale=gs)
+                self._wgrad(expand_wgrads, g)
                 ds = ops.conv2d_bwd_data(g, bwd(e1.name), dy_coffset=0)
                 ops.conv2d_bwd_data(g, bwd(e3.name), dx=ds, dy_coffset=ne1, accumulate=True, relu_of=s)   # + the squeeze's ReLU backward
-                ops.conv2d_bwd_filter(xin, ds, 1, int(xin.shape[3]), ns, dw=self.gview[sq.name + "/kernels"], db=self.gview[sq.name + "/biases"], grad_scale=gs)
+                self._wgrad(lambda xin=xin, ds=ds, ns=ns, sq=sq: ops.conv2d_bwd_filter(
+                    xin, ds, 1, int(xin.shape[3]), ns, dw=self.gview[sq.name + "/kernels"], db=self.gview[sq.name + "/biases"], grad_scale=gs), ds)
                 masked = False
                 if need_dx:
                     g = ops.conv2d_bwd_data(ds, bwd(sq.name), relu_of=below)
                     masked = below is not None
+        self._join_wgrad()
         out = collections.OrderedDict(class_loss=losses[0], conf_loss=losses[1], bbox_loss=losses[2], ious=ious, preds=preds,
                                       dpreds=dpreds, num_objects=num_objects)
         if keep_activations:
@@ -528,6 +567,7 @@ class ResNet50ConvDetTrainer(_TrainerBase):
             if node is self.boundary:
                 return
             if node in g:
+                self._before_inplace(g[node])
                 ops.conv2d_bwd_data(dy, packed_bwd, dx=g[node], accumulate=True)
             else:
                 g[node] = ops.conv2d_bwd_data(dy, packed_bwd)
@@ -537,13 +577,16 @@ class ResNet50ConvDetTrainer(_TrainerBase):
             if n.op == "conv":
                 x = val[n.inputs[0]]
                 if n.attrs["relu"]:
+                    self._before_inplace(gy)
                     ops.relu_bwd(val[n], gy)
                 k, cin, cout = n.attrs["size"], int(x.shape[3]), int(n.shape[3])
-                ops.conv2d_bwd_filter(x, gy, k, cin, cout, dw=self.gview[n.name + "/kernels"], db=self.gview[n.name + "/biases"], grad_scale=gs)
+                self._wgrad(lambda x=x, gy=gy, k=k, cin=cin, cout=cout, n=n: ops.conv2d_bwd_filter(
+                    x, gy, k, cin, cout, dw=self.gview[n.name + "/kernels"], db=self.gview[n.name + "/biases"], grad_scale=gs), gy, x)
                 give(n.inputs[0], gy, ops.PackedConvBwd(P[n.name + "/kernels"], self.adt))
             elif n.op == "dropout":
                 g[n.inputs[0]] = ops.scale_mask(gy, aux[n], 1.0 / n.attrs["keep_prob"])
             elif n.op == "add_relu":
+                self._before_inplace(gy)
                 ops.relu_bwd(val[n], gy)
                 sc, br = n.inputs
                 g[br] = gy                              # both summands receive the same gradient;
@@ -552,6 +595,7 @@ class ResNet50ConvDetTrainer(_TrainerBase):
             elif n.op == "conv_bn":
                 x = val[n.inputs[0]]
                 if n.attrs["relu"]:
+                    self._before_inplace(gy)
                     ops.relu_bwd(val[n], gy)
                 k, stride = n.attrs["size"], n.attrs["stride"]
                 cin, cout = int(x.shape[3]), int(n.shape[3])
@@ -559,12 +603,15 @@ class ResNet50ConvDetTrainer(_TrainerBase):
                     if k != 1 or n.inputs[0] is not self.boundary:
                         raise SqdetError("ResNet50ConvDetTrainer: strided conv %s needs an input gradient" % n.name)
                     x = ops.subsample_nhwc(x, stride)
-                dwf, dbf = ops.conv2d_bwd_filter(x, gy, k, cin, cout, grad_scale=gs)
-                ops.fold_batchnorm_bwd(P[n.name + "/kernels"], dwf, dbf, None, P[n.name + "/gamma"], P[n.name + "/mean"],
-                                       P[n.name + "/var"], eps, dw=self.gview[n.name + "/kernels"],
-                                       dgamma=self.gview[n.name + "/gamma"], dbeta=self.gview[n.name + "/beta"])
+                def bn_wgrad(x=x, gy=gy, k=k, cin=cin, cout=cout, n=n):
+                    dwf, dbf = ops.conv2d_bwd_filter(x, gy, k, cin, cout, grad_scale=gs)
+                    ops.fold_batchnorm_bwd(P[n.name + "/kernels"], dwf, dbf, None, P[n.name + "/gamma"], P[n.name + "/mean"],
+                                           P[n.name + "/var"], eps, dw=self.gview[n.name + "/kernels"],
+                                           dgamma=self.gview[n.name + "/gamma"], dbeta=self.gview[n.name + "/beta"])
+                self._wgrad(bn_wgrad, gy, x)
                 if stride == 1:
                     give(n.inputs[0], gy, ops.PackedConvBwd(aux[n], self.adt))
+        self._join_wgrad()
         out = collections.OrderedDict(class_loss=losses[0], conf_loss=losses[1], bbox_loss=losses[2], ious=ious, preds=preds,
                                       dpreds=dpreds, num_objects=num_objects)
         if keep_activations:     # names as oracle/resnet_oracle.py forward_train's `override`

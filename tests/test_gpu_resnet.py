@@ -280,3 +280,20 @@ def test_resnet50_training_reduces_loss():
     tr.model.keep_prob = 1.0
     (p,) = tr.model.run([tr.model.preds], {tr.model.image_input: x})
     assert torch.isfinite(p).all()
+
+
+def test_resnet50_side_stream_weight_gradients_equal_the_serial_order():
+    """Weight-gradient (+ folded-BN gradient) launches on a second stream: same bits as the single-stream order."""
+    from oracle import train_oracle as TO
+    size, B = (96, 160), 2
+    res = []
+    for overlap in (False, True):
+        tr, mc, params = _trainer(size, B, seed=2, overlap_wgrad=overlap)
+        tr.seed = 5
+        x = O.synthetic_images(B, size[0], size[1], seed=51)
+        mask, delta, box, labels = TO.synthetic_labels(mc, B, seed=52)
+        for _ in range(2):
+            tr.step(x, mask, delta, box, labels)
+        torch.cuda.synchronize()
+        res.append((tr.flat_grads.clone(), tr.flat_params.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])

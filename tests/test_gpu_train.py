@@ -416,6 +416,24 @@ def test_training_reduces_loss_on_fixed_batch():
     assert min(hist[-3:]) < hist[0], hist
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_side_stream_weight_gradients_equal_the_serial_order(dtype):
+    """overlap_wgrad=True issues the weight-gradient launches on a second stream beside the backward-data chain: three
+    steps from the same start must leave bit-identical gradients and variables to the single-stream order."""
+    omc = O.squeezeDet_config_for_input(128, 256)
+    x = O.synthetic_images(2, 128, 256, seed=41)
+    mask, delta, box, labels = TO.synthetic_labels(omc, 2, seed=42)
+    res = []
+    for overlap in (False, True):
+        tr, mc, params = _trainer(seed=5, dtype=dtype, overlap_wgrad=overlap)
+        tr.seed = 77
+        for _ in range(3):
+            tr.step(x, mask, delta, box, labels)
+        torch.cuda.synchronize()
+        res.append((tr.flat_grads.clone(), tr.flat_params.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 def test_momentum_clip_optimizer_vs_oracle():
     ops = _ops()
     mc = O.kitti_squeezeDet_config()
