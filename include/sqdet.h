@@ -123,6 +123,11 @@ int sqdet_subsample_nhwc(const void* x, void* y, int n, int h, int w, int c, int
  * SAME-padded cells never win.  x: [n,h,w,c] -> y: [n,ho,wo,c]. */
 int sqdet_maxpool_nhwc_fwd(const void* x, void* y, int n, int h, int w, int c, int k, int stride, int pad_mode,
                            int dtype, sqdet_stream_t stream);
+/* The training forward's pool (k = 3): also records, per output element, which window cell won -- one byte,
+ * 3 * row + column of the FIRST maximum in row-major order (tf.nn.max_pool's gradient convention), 255 if none did --
+ * for sqdet_maxpool_nhwc_bwd_idx.  window_index: [n,ho,wo,c] uint8. */
+int sqdet_maxpool_nhwc_fwd_idx(const void* x, void* y, unsigned char* window_index, int n, int h, int w, int c, int k,
+                               int stride, int pad_mode, int dtype, sqdet_stream_t stream);
 
 /* ------------------------------------------------------------------ stem --
  * conv1 + pool1 in one launch: relu(conv2d(x, W, stride 2) + b) followed by max_pool 3x3/s2
@@ -310,6 +315,21 @@ int sqdet_conv2d_nhwc_bwd_filter(const void* x, const void* dy, float* dw_hwio, 
                                  const float* w_hwio_for_decay, float weight_decay, float grad_scale, float* workspace,
                                  int n, int h, int w, int cin, int cout, int k, int x_cstride, int x_coffset,
                                  int dy_cstride, int dy_coffset, int dtype, sqdet_stream_t stream);
+/* The two halves apart, for a step that takes MANY weight gradients: sqdet_conv2d_nhwc_bwd_filter_partial writes only the
+ * partial slabs of one conv into its own workspace (same size query), and ONE sqdet_slab_reduce_many launch at the end of
+ * the backward pass sums the slabs of all of them (a SqueezeDet step: 31 reductions, each a 10 us launch behind its
+ * gradient kernel).  prepare() fills a host table (sqdet_slab_reduce_many_table_bytes(n_items) bytes; the caller copies it
+ * to the device once) from the per-item workspace / dW / dbias (NULL: none) / decay-weight (NULL: none) pointers and the
+ * conv shapes the partial launches used; per item the arithmetic is sqdet_conv2d_nhwc_bwd_filter's, bit for bit. */
+int sqdet_conv2d_nhwc_bwd_filter_partial(const void* x, const void* dy, float* workspace, int want_bias, int n, int h, int w,
+                                         int cin, int cout, int k, int x_cstride, int x_coffset, int dy_cstride,
+                                         int dy_coffset, int dtype, sqdet_stream_t stream);
+size_t sqdet_slab_reduce_many_table_bytes(int n_items);
+int sqdet_slab_reduce_many_prepare(const float* const* workspaces, float* const* dws, float* const* dbiases,
+                                   const float* const* w_for_decay, const float* decays, const int* n, const int* h,
+                                   const int* w, const int* cin, const int* cout, const int* k, int n_items,
+                                   void* table_host, int* total_blocks);
+int sqdet_slab_reduce_many(const void* table_dev, int n_items, int total_blocks, float grad_scale, sqdet_stream_t stream);
 
 /* dy *= (y > 0)  (tf.nn.relu gradient; count elements, a multiple of 16 bytes). */
 int sqdet_relu_bwd(const void* y, void* dy_inout, size_t count, int dtype, sqdet_stream_t stream);
@@ -328,6 +348,11 @@ int sqdet_maxpool_nhwc_bwd(const void* x, const void* dy, void* dx, int n, int h
  * x <= 0, i.e. the ReLU backward of the layer below is taken here instead of in a pass of its own. */
 int sqdet_maxpool_nhwc_bwd_relu(const void* x, const void* dy, void* dx, int n, int h, int w, int c, int k, int stride,
                                 int pad_mode, int dtype, sqdet_stream_t stream);
+/* Both from the window index of sqdet_maxpool_nhwc_fwd_idx (k = 3, stride 2) instead of x: reads three quarter-size
+ * maps (index, dy and -- relu != 0 -- the pooled y, whose sign is the sign of x at every cell that receives anything)
+ * and writes dx [n,h,w,c]; bitwise the results of the two functions above. */
+int sqdet_maxpool_nhwc_bwd_idx(const unsigned char* window_index, const void* y, const void* dy, void* dx, int n, int h,
+                               int w, int c, int k, int stride, int pad_mode, int dtype, int relu, sqdet_stream_t stream);
 
 /* Loss forward + backward.  Inputs as the reference's placeholders (nn_skeleton.py:86-97):
  * input_mask [B,A], box_delta_input [B,A,4], box_input [B,A,4] (cx,cy,w,h), labels [B,A,C];

@@ -31,6 +31,8 @@ SIGNATURES = {
     "sqdet_fold_batchnorm_bwd": (ci, [vp] * 7 + [cf, vp, vp, vp, vp, ci, ci, ci, vp]),
     "sqdet_subsample_nhwc": (ci, [vp, vp] + [ci] * 6 + [vp]),
     "sqdet_maxpool_nhwc_fwd": (ci, [vp, vp] + [ci] * 8 + [vp]),
+    "sqdet_maxpool_nhwc_fwd_idx": (ci, [vp, vp, vp] + [ci] * 8 + [vp]),
+    "sqdet_maxpool_nhwc_bwd_idx": (ci, [vp, vp, vp, vp] + [ci] * 9 + [vp]),
     "sqdet_stem_conv_pool_fwd": (ci, [vp, vp, vp, vp] + [ci] * 8 + [vp]),
     "sqdet_stem_conv_pool_squeeze_supported": (ci, [ci] * 9),
     "sqdet_stem_conv_pool_squeeze_fwd": (ci, [vp] * 6 + [ci] * 9 + [vp]),
@@ -65,6 +67,10 @@ SIGNATURES = {
     "sqdet_conv2d_nhwc_bwd_data_relu": (ci, [vp, vp, vp, vp] + [ci] * 10 + [vp]),
     "sqdet_conv2d_bwd_filter_workspace_bytes": (sz, [ci] * 6),
     "sqdet_conv2d_nhwc_bwd_filter": (ci, [vp, vp, vp, vp, vp, cf, cf, vp] + [ci] * 11 + [vp]),
+    "sqdet_conv2d_nhwc_bwd_filter_partial": (ci, [vp, vp, vp] + [ci] * 12 + [vp]),
+    "sqdet_slab_reduce_many_table_bytes": (sz, [ci]),
+    "sqdet_slab_reduce_many_prepare": (ci, [vp] * 11 + [ci, vp, vp]),
+    "sqdet_slab_reduce_many": (ci, [vp, ci, ci, cf, vp]),
     "sqdet_relu_bwd": (ci, [vp, vp, sz, ci, vp]),
     "sqdet_convert_scale": (ci, [vp, ci, vp, ci, cf, sz, vp]),
     "sqdet_scale_mask": (ci, [vp, vp, vp, cf, sz, ci, vp]),

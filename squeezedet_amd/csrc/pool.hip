@@ -89,6 +89,83 @@ __global__ __launch_bounds__(256) void maxpool3_kernel(const T* __restrict__ x, 
   }
 }
 
+// The training forward's pool: maxpool3_kernel that also records WHICH cell won -- 3 * (window row) + (window column) of the
+// FIRST maximum in row-major order (tf.nn.max_pool's gradient convention, the rule maxpool3s2_bwd_kernel re-derives from
+// x), one byte per output element -- so that the backward pass reads idx + y + dy (a quarter-size map each) instead of
+// searching the full-resolution input again.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3_idx_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                           unsigned char* __restrict__ widx, int N, int H, int W, int C,
+                                                           int stride, int pt, int pl, int Ho, int Wo) {
+  constexpr int V = PoolTr<T>::V;
+  typedef typename PoolTr<T>::vec vec;
+  const int cv = C / V;
+  const size_t total = (size_t)N * Ho * Wo * cv;
+  const unsigned per = (gridDim.x + 7) / 8;
+  const size_t slice = (size_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const size_t idx = slice * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % cv);
+  size_t p = idx / cv;
+  const int ox = (int)(p % Wo); p /= Wo;
+  const int oy = (int)(p % Ho);
+  const int n = (int)(p / Ho);
+  const int y0 = oy * stride - pt, x0 = ox * stride - pl;
+  vec v[9];
+  bool ok[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int iy = y0 + t / 3, ix = x0 + t % 3;
+    ok[t] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+    v[t] = *reinterpret_cast<const vec*>(x + (((size_t)n * H + cy) * W + cx) * C + c * V);
+  }
+  vec m;
+  unsigned char pos[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { m[e] = (T)(-__builtin_huge_valf()); pos[e] = 255; }
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < V; ++e)
+      if (ok[t] && v[t][e] > m[e]) { m[e] = v[t][e]; pos[e] = (unsigned char)t; }
+  *reinterpret_cast<vec*>(y + idx * V) = m;
+  if constexpr (V == 8) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 o;
+    o[0] = pos[0] | (pos[1] << 8) | (pos[2] << 16) | ((unsigned)pos[3] << 24);
+    o[1] = pos[4] | (pos[5] << 8) | (pos[6] << 16) | ((unsigned)pos[7] << 24);
+    *reinterpret_cast<u32x2*>(widx + idx * V) = o;
+  } else {
+    *reinterpret_cast<unsigned int*>(widx + idx * V) = pos[0] | (pos[1] << 8) | (pos[2] << 16) | ((unsigned)pos[3] << 24);
+  }
+}
+
+int maxpool_idx_launch(const void* x, void* y, unsigned char* widx, int n, int h, int w, int c, int k, int stride, int pad_mode,
+                       int dtype, hipStream_t st) {
+  SQDET_REQUIRE(x && y && widx, "maxpool_idx: null pointer");
+  SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "maxpool_idx: bad dtype %d", dtype);
+  SQDET_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && stride > 0, "maxpool_idx: bad dims");
+  SQDET_REQUIRE(pad_mode == SQDET_PAD_SAME || pad_mode == SQDET_PAD_VALID, "maxpool_idx: bad pad_mode");
+  SQDET_UNSUPPORTED(k != 3, "maxpool_idx: 3x3 windows only (every pool of the reference's nets)");
+  SQDET_REQUIRE(pad_mode == SQDET_PAD_SAME || (h >= k && w >= k), "maxpool_idx: VALID needs h,w >= k");
+  const int V = dtype == SQDET_F16 ? 8 : 4;
+  SQDET_UNSUPPORTED(c % V != 0, "maxpool_idx: channels %d not a multiple of %d", c, V);
+  const int Ho = out_size(h, k, stride, pad_mode), Wo = out_size(w, k, stride, pad_mode);
+  const int pt = pad_before(h, k, stride, pad_mode), pl = pad_before(w, k, stride, pad_mode);
+  const size_t total = (size_t)n * Ho * Wo * (c / V);
+  const size_t blocks = ((total + 255) / 256 + 7) / 8 * 8;
+  SQDET_UNSUPPORTED(blocks > 0x7fffffffULL, "maxpool_idx: too many outputs");
+  if (dtype == SQDET_F16)
+    hipLaunchKernelGGL(maxpool3_idx_kernel<f16>, dim3((unsigned)blocks), dim3(256), 0, st, (const f16*)x, (f16*)y, widx, n, h,
+                       w, c, stride, pt, pl, Ho, Wo);
+  else
+    hipLaunchKernelGGL(maxpool3_idx_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (float*)y, widx,
+                       n, h, w, c, stride, pt, pl, Ho, Wo);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
 int maxpool_launch(const void* x, void* y, int n, int h, int w, int c, int k, int stride, int pad_mode, int dtype,
                    hipStream_t st) {
   SQDET_REQUIRE(x && y, "maxpool: null pointer");
@@ -127,4 +204,9 @@ int maxpool_launch(const void* x, void* y, int n, int h, int w, int c, int k, in
 extern "C" int sqdet_maxpool_nhwc_fwd(const void* x, void* y, int n, int h, int w, int c, int k, int stride,
                                       int pad_mode, int dtype, sqdet_stream_t stream) {
   return sqdet::maxpool_launch(x, y, n, h, w, c, k, stride, pad_mode, dtype, sqdet::as_stream(stream));
+}
+
+extern "C" int sqdet_maxpool_nhwc_fwd_idx(const void* x, void* y, unsigned char* window_index, int n, int h, int w, int c, int k,
+                                          int stride, int pad_mode, int dtype, sqdet_stream_t stream) {
+  return sqdet::maxpool_idx_launch(x, y, window_index, n, h, w, c, k, stride, pad_mode, dtype, sqdet::as_stream(stream));
 }

@@ -233,6 +233,78 @@ __global__ void maxpool3s2_bwd_kernel(const T* __restrict__ x, const T* __restri
   }
 }
 
+// The same from the window index the training forward recorded (pool.hip maxpool3_idx_kernel): per 2x2 cell block four
+// windows' idx (one byte per channel) + dy -- and, for the fused ReLU backward, the POOLED y: a cell that receives anything is
+// the argmax of a window whose output y equals the cell's x, so (x > 0) == (y > 0) for every contribution it sums -- instead
+// of 25 full-resolution 16-byte cells of x.  Same window order and the same sums as maxpool3s2_bwd_kernel: bitwise equal.
+template <typename T>
+__global__ void maxpool3s2_bwd_idx_kernel(const unsigned char* __restrict__ widx, const T* __restrict__ y,
+                                          const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C, int pt,
+                                          int pl, int Ho, int Wo, int BA, int BB, int relu) {
+  typedef typename Vec16<T>::type V;
+  constexpr int EV = 16 / sizeof(T);
+  const int cvn = C / EV;
+  const size_t total = (size_t)N * BA * BB * cvn;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(idx % cvn);
+    size_t p = idx / cvn;
+    const int b = (int)(p % BB); p /= BB;
+    const int a = (int)(p % BA);
+    const int n = (int)(p / BA);
+    float g[4][EV];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < EV; ++e) g[q][e] = 0.f;
+#pragma unroll
+    for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+      for (int wx = 0; wx < 2; ++wx) {
+        const int oy = a - wy, ox = b - wx;
+        if (oy < 0 || oy >= Ho || ox < 0 || ox >= Wo) continue;
+        const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + cv * EV;
+        unsigned char bp[EV];
+        if constexpr (EV == 8) {
+          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 w2 = *reinterpret_cast<const u32x2*>(widx + o);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bp[e] = (unsigned char)(w2[e >> 2] >> (8 * (e & 3)));
+        } else {
+          const unsigned int w1 = *reinterpret_cast<const unsigned int*>(widx + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bp[e] = (unsigned char)(w1 >> (8 * e));
+        }
+        V d = *reinterpret_cast<const V*>(dy + o);
+        if (relu) {
+          const V yv = *reinterpret_cast<const V*>(y + o);
+#pragma unroll
+          for (int e = 0; e < EV; ++e) d[e] = yv[e] > (T)0 ? d[e] : (T)0;
+        }
+#pragma unroll
+        for (int du = 0; du < 2; ++du)
+#pragma unroll
+          for (int dv = 0; dv < 2; ++dv) {
+            const int r = 2 * wy + du, c = 2 * wx + dv;
+            if (r > 2 || c > 2) continue;
+#pragma unroll
+            for (int e = 0; e < EV; ++e)
+              if (bp[e] == 3 * r + c) g[du * 2 + dv][e] += (float)d[e];
+          }
+      }
+#pragma unroll
+    for (int du = 0; du < 2; ++du)
+#pragma unroll
+      for (int dv = 0; dv < 2; ++dv) {
+        const int iy = 2 * a + du - pt, ix = 2 * b + dv - pl;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        V o;
+#pragma unroll
+        for (int e = 0; e < EV; ++e) o[e] = (T)g[du * 2 + dv][e];
+        *reinterpret_cast<V*>(dx + ((((size_t)n * H + iy) * W + ix) * C + cv * EV)) = o;
+      }
+  }
+}
+
 // max-pool backward, generic gather form (deterministic): an input cell receives dy of every window whose
 // FIRST maximum (row-major scan, as tf.nn.max_pool's argmax) it is.
 template <typename T>
@@ -471,7 +543,15 @@ __global__ __launch_bounds__(1024) void sum_f32_kernel(const float* __restrict__
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
   const size_t nv = vec ? n / 4 : 0;
-  for (size_t i = threadIdx.x; i < nv; i += 1024) {
+  size_t i = threadIdx.x;
+  for (; i + 7 * 1024 < nv; i += 8 * 1024) {      // eight loads in flight (one at a time, 337 k floats took 36 us); same add order
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const f32x4*>(x)[i + u * 1024];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s0 += v[u][0]; s1 += v[u][1]; s2 += v[u][2]; s3 += v[u][3]; }
+  }
+  for (; i < nv; i += 1024) {
     const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
     s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
   }
@@ -694,6 +774,27 @@ static int maxpool_bwd_launch(const void* x, const void* dy, void* dx, int n, in
   else
     hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy,
                        (float*)dx, n, h, w, c, k, stride, pt, pl, Ho, Wo, relu);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_maxpool_nhwc_bwd_idx(const unsigned char* window_index, const void* y, const void* dy, void* dx, int n, int h,
+                                          int w, int c, int k, int stride, int pad_mode, int dtype, int relu,
+                                          sqdet_stream_t stream) {
+  SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "maxpool_bwd_idx: bad dtype");
+  const int ev = 16 / (int)dtype_size(dtype);
+  SQDET_REQUIRE(window_index && dy && dx && (y || !relu) && n > 0 && h > 0 && w > 0 && c > 0 && c % ev == 0, "maxpool_bwd_idx: bad arguments");
+  SQDET_UNSUPPORTED(k != 3 || stride != 2, "maxpool_bwd_idx: 3x3 / stride-2 pools only (every pool of the reference's nets)");
+  const int Ho = out_size(h, k, stride, pad_mode), Wo = out_size(w, k, stride, pad_mode);
+  const int pt = pad_before(h, k, stride, pad_mode), pl = pad_before(w, k, stride, pad_mode);
+  const int BA = (h + pt + 1) / 2, BB = (w + pl + 1) / 2;
+  const dim3 grid(grid_for((size_t)n * BA * BB * (c / ev), 16384));
+  if (dtype == SQDET_F16)
+    hipLaunchKernelGGL(maxpool3s2_bwd_idx_kernel<f16>, grid, dim3(256), 0, as_stream(stream), window_index, (const f16*)y,
+                       (const f16*)dy, (f16*)dx, n, h, w, c, pt, pl, Ho, Wo, BA, BB, relu);
+  else
+    hipLaunchKernelGGL(maxpool3s2_bwd_idx_kernel<float>, grid, dim3(256), 0, as_stream(stream), window_index, (const float*)y,
+                       (const float*)dy, (float*)dx, n, h, w, c, pt, pl, Ho, Wo, BA, BB, relu);
   SQDET_CHECK_HIP(hipGetLastError());
   return SQDET_OK;
 }

@@ -237,14 +237,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile(WgArgs a) {
 // Four lanes share an element (lane q of the group takes slabs q, q + 4, ...), eight loads in flight each, then two xor
 // steps: ((q0 + q1) + (q2 + q3)).  (One thread per element with four loads in flight walked up to 128 dependent L2 round
 // trips: 15 us per launch, 31 launches = 0.48 ms of a 3.8 ms mixed-precision SqueezeDet step.)
-__global__ void slab_reduce2_kernel(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ dbias,
-                                    const float* __restrict__ w, float decay, float scale, size_t count, int cout,
-                                    size_t stride, int nslabs) {
+__device__ __forceinline__ void slab_reduce_body(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ dbias,
+                                                 const float* __restrict__ w, float decay, float scale, size_t count, int cout,
+                                                 size_t stride, int nslabs, unsigned block, unsigned nblocks) {
   const size_t total = count + (dbias ? (size_t)cout : 0);
   const int q = threadIdx.x & 3;
-  const size_t nthr = (size_t)gridDim.x * (blockDim.x >> 2);
+  const size_t nthr = (size_t)nblocks * (blockDim.x >> 2);
   // every lane of a 4-lane group runs the same trip count (the shuffles below are wave-wide): elements rounded up per group
-  for (size_t e0 = (size_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2); e0 < ((total + nthr - 1) / nthr) * nthr; e0 += nthr) {
+  for (size_t e0 = (size_t)block * (blockDim.x >> 2) + (threadIdx.x >> 2); e0 < ((total + nthr - 1) / nthr) * nthr; e0 += nthr) {
     const bool live = e0 < total;
     const size_t e = live ? e0 : 0;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -269,6 +269,37 @@ __global__ void slab_reduce2_kernel(const float* __restrict__ partial, float* __
       }
     }
   }
+}
+
+__global__ void slab_reduce2_kernel(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ dbias,
+                                    const float* __restrict__ w, float decay, float scale, size_t count, int cout,
+                                    size_t stride, int nslabs) {
+  slab_reduce_body(partial, dw, dbias, w, decay, scale, count, cout, stride, nslabs, blockIdx.x, gridDim.x);
+}
+
+// The slab reductions of MANY backward-filter launches in one launch (a training step's 31: each was a launch of its own
+// behind its wgrad_tile, 10 us apiece): workgroup b serves the item whose block range holds b, with exactly the arithmetic
+// of slab_reduce2_kernel for that item's own block count -- bitwise the per-layer results.
+struct ReduceItem {
+  const float* partial;
+  float* dw;
+  float* dbias;
+  const float* w;
+  size_t count, stride;
+  float decay;
+  int cout, nslabs;
+  unsigned first_block, nblocks;
+};
+
+__global__ void slab_reduce_many_kernel(const ReduceItem* __restrict__ items, int n, float scale) {
+  int lo = 0, hi = n - 1;           // the last item whose first_block <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].first_block <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const ReduceItem it = items[lo];
+  slab_reduce_body(it.partial, it.dw, it.dbias, it.w, it.decay, scale, it.count, it.cout, it.stride, it.nslabs,
+                   blockIdx.x - it.first_block, it.nblocks);
 }
 
 namespace {
@@ -347,11 +378,16 @@ extern "C" size_t sqdet_conv2d_bwd_filter_workspace_bytes(int n, int h, int w, i
   return (size_t)p.ksplit * p.slab_stride * sizeof(float);
 }
 
-extern "C" int sqdet_conv2d_nhwc_bwd_filter(const void* x, const void* dy, float* dw_hwio, float* dbias,
-                                            const float* w_hwio_for_decay, float weight_decay, float grad_scale,
-                                            float* workspace, int n, int h, int w, int cin, int cout, int k, int x_cstride,
-                                            int x_coffset, int dy_cstride, int dy_coffset, int dtype, sqdet_stream_t stream) {
-  SQDET_REQUIRE(x && dy && dw_hwio && workspace, "conv2d_bwd_filter: null pointer");
+static int reduce_blocks(size_t total) {
+  int blocks = (int)((total + 63) / 64);   // 64 elements (x 4 lanes) per 256-thread workgroup
+  return blocks > 4096 ? 4096 : blocks;
+}
+
+// dw_hwio == NULL: the partial slabs only (sqdet_conv2d_nhwc_bwd_filter_partial)
+static int bwd_filter_impl(const void* x, const void* dy, float* dw_hwio, float* dbias, int want_bias, const float* w_hwio_for_decay,
+                           float weight_decay, float grad_scale, float* workspace, int n, int h, int w, int cin, int cout, int k,
+                           int x_cstride, int x_coffset, int dy_cstride, int dy_coffset, int dtype, sqdet_stream_t stream) {
+  SQDET_REQUIRE(x && dy && workspace, "conv2d_bwd_filter: null pointer");
   SQDET_REQUIRE((k == 1 || k == 3) && n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "conv2d_bwd_filter: bad dims");
   SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "conv2d_bwd_filter: bad dtype");
   const int ev = dtype == SQDET_F16 ? 8 : 4;
@@ -367,7 +403,7 @@ extern "C" int sqdet_conv2d_nhwc_bwd_filter(const void* x, const void* dy, float
   a.H = h; a.W = w; a.Cin = cin; a.Cout = cout; a.k = k;
   a.x_cstride = x_cstride; a.x_coffset = x_coffset; a.dy_cstride = dy_cstride; a.dy_coffset = dy_coffset;
   a.BY = p.BY; a.BX = p.BX; a.nstages = p.nstages; a.ksplit = p.ksplit; a.ci_tiles = p.ci_tiles;
-  a.do_bias = dbias != nullptr;
+  a.do_bias = want_bias;
   a.x_bytes = (unsigned)(P * x_cstride * es);
   a.dy_bytes = (unsigned)(P * dy_cstride * es);
   a.slab_stride = p.slab_stride;
@@ -375,11 +411,60 @@ extern "C" int sqdet_conv2d_nhwc_bwd_filter(const void* x, const void* dy, float
   if (dtype == SQDET_F16) launch_variant<f16>(p, grid, st, a);
   else launch_variant<float>(p, grid, st, a);
   SQDET_CHECK_HIP(hipGetLastError());
-  const size_t total = p.count + (dbias ? (size_t)cout : 0);
-  int blocks = (int)((total + 63) / 64);   // 64 elements (x 4 lanes) per 256-thread workgroup
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(slab_reduce2_kernel, dim3(blocks), dim3(256), 0, st, workspace, dw_hwio, dbias, w_hwio_for_decay,
-                     weight_decay, grad_scale, p.count, cout, p.slab_stride, p.ksplit);
+  if (!dw_hwio) return SQDET_OK;
+  hipLaunchKernelGGL(slab_reduce2_kernel, dim3(reduce_blocks(p.count + (dbias ? (size_t)cout : 0))), dim3(256), 0, st, workspace,
+                     dw_hwio, dbias, w_hwio_for_decay, weight_decay, grad_scale, p.count, cout, p.slab_stride, p.ksplit);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_conv2d_nhwc_bwd_filter(const void* x, const void* dy, float* dw_hwio, float* dbias,
+                                            const float* w_hwio_for_decay, float weight_decay, float grad_scale,
+                                            float* workspace, int n, int h, int w, int cin, int cout, int k, int x_cstride,
+                                            int x_coffset, int dy_cstride, int dy_coffset, int dtype, sqdet_stream_t stream) {
+  SQDET_REQUIRE(dw_hwio, "conv2d_bwd_filter: null pointer");
+  return bwd_filter_impl(x, dy, dw_hwio, dbias, dbias != nullptr, w_hwio_for_decay, weight_decay, grad_scale, workspace, n, h, w,
+                         cin, cout, k, x_cstride, x_coffset, dy_cstride, dy_coffset, dtype, stream);
+}
+
+extern "C" int sqdet_conv2d_nhwc_bwd_filter_partial(const void* x, const void* dy, float* workspace, int want_bias, int n, int h,
+                                                    int w, int cin, int cout, int k, int x_cstride, int x_coffset,
+                                                    int dy_cstride, int dy_coffset, int dtype, sqdet_stream_t stream) {
+  return bwd_filter_impl(x, dy, nullptr, nullptr, want_bias != 0, nullptr, 0.f, 1.f, workspace, n, h, w, cin, cout, k, x_cstride,
+                         x_coffset, dy_cstride, dy_coffset, dtype, stream);
+}
+
+extern "C" size_t sqdet_slab_reduce_many_table_bytes(int n_items) {
+  return n_items > 0 ? (size_t)n_items * sizeof(ReduceItem) : 0;
+}
+
+extern "C" int sqdet_slab_reduce_many_prepare(const float* const* workspaces, float* const* dws, float* const* dbiases,
+                                              const float* const* w_for_decay, const float* decays, const int* n, const int* h,
+                                              const int* w, const int* cin, const int* cout, const int* k, int n_items,
+                                              void* table_host, int* total_blocks) {
+  SQDET_REQUIRE(workspaces && dws && dbiases && w_for_decay && decays && n && h && w && cin && cout && k && table_host &&
+                    total_blocks && n_items > 0, "slab_reduce_many_prepare: bad arguments");
+  ReduceItem* t = static_cast<ReduceItem*>(table_host);
+  unsigned next = 0;
+  for (int i = 0; i < n_items; ++i) {
+    SQDET_REQUIRE(workspaces[i] && dws[i] && (k[i] == 1 || k[i] == 3) && n[i] > 0 && h[i] > 0 && w[i] > 0 && cin[i] > 0 && cout[i] > 0,
+                  "slab_reduce_many_prepare: bad item %d", i);
+    const WgPlan p = wgrad_plan(n[i], h[i], w[i], cin[i], cout[i], k[i]);
+    ReduceItem& it = t[i];
+    it.partial = workspaces[i]; it.dw = dws[i]; it.dbias = dbiases[i]; it.w = w_for_decay[i];
+    it.count = p.count; it.stride = p.slab_stride; it.decay = decays[i]; it.cout = cout[i]; it.nslabs = p.ksplit;
+    it.first_block = next;
+    it.nblocks = (unsigned)reduce_blocks(p.count + (dbiases[i] ? (size_t)cout[i] : 0));
+    next += it.nblocks;
+  }
+  *total_blocks = (int)next;
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_slab_reduce_many(const void* table_dev, int n_items, int total_blocks, float grad_scale, sqdet_stream_t stream) {
+  SQDET_REQUIRE(table_dev && n_items > 0 && total_blocks > 0, "slab_reduce_many: bad arguments");
+  hipLaunchKernelGGL(slab_reduce_many_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream),
+                     static_cast<const ReduceItem*>(table_dev), n_items, grad_scale);
   SQDET_CHECK_HIP(hipGetLastError());
   return SQDET_OK;
 }

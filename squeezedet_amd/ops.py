@@ -100,6 +100,18 @@ def maxpool_nhwc(x, size, stride, padding="SAME"):
     return y
 
 
+def maxpool_nhwc_idx(x, size, stride, padding="SAME"):
+    """maxpool_nhwc that also returns the uint8 window index of every output element (sqdet_maxpool_nhwc_fwd_idx): what
+    maxpool_bwd_idx needs instead of x."""
+    n, h, w, c = [int(v) for v in x.shape]
+    ho, wo = _out_size(h, size, stride, padding), _out_size(w, size, stride, padding)
+    y = torch.empty((n, ho, wo, c), dtype=x.dtype, device=x.device)
+    idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.device)
+    check(lib().sqdet_maxpool_nhwc_fwd_idx(_dev(x, "x"), _dev(y, "y"), _dev(idx, "idx"), n, h, w, c, int(size), int(stride),
+                                           pad_code(padding), dtype_code(x.dtype), stream_ptr()), "sqdet_maxpool_nhwc_fwd_idx")
+    return y, idx
+
+
 def stem_supported(cout, k):
     """Shapes the fused conv1 + pool1 launch covers (sqdet_stem_conv_pool_fwd): SqueezeDet, SqueezeDet+ and ResNet50 stems."""
     return (k == 3 and cout == 64) or (k == 7 and cout in (64, 96))
@@ -477,6 +489,52 @@ def conv2d_bwd_filter(x, dy, k, cin, cout, w_for_decay=None, weight_decay=0.0, x
     return dw, db
 
 
+class WgradPlan:
+    """The weight gradients of a whole backward pass with ONE slab reduction (sqdet_conv2d_nhwc_bwd_filter_partial per conv
+    into a workspace of its own, sqdet_slab_reduce_many at the end) instead of a reduction launch behind every gradient
+    kernel.  items: [(key, (n, h, w, cin, cout, k), dw, db or None, w_for_decay or None, weight_decay)] -- dw / db are
+    persistent float32 tensors (a trainer's flat gradient views).  Per conv the results are conv2d_bwd_filter's, bitwise."""
+
+    def __init__(self, items):
+        self.n = len(items)
+        self.shape, self.ws, self.has_bias, self._keep = {}, {}, {}, items
+        dev = items[0][2].device
+        for key, shp, dw, db, wd, decay in items:
+            n, h, w, cin, cout, k = [int(v) for v in shp]
+            if tuple(dw.shape) != (k, k, cin, cout) or dw.dtype != torch.float32 or not dw.is_contiguous():
+                raise _lib.SqdetError("WgradPlan: %s: dw must be a contiguous float32 [k,k,cin,cout] tensor" % (key,))
+            self.shape[key] = (n, h, w, cin, cout, k)
+            self.has_bias[key] = db is not None
+            self.ws[key] = torch.empty(int(lib().sqdet_conv2d_bwd_filter_workspace_bytes(n, h, w, cin, cout, k)) // 4 + 64,
+                                       dtype=torch.float32, device=dev)
+        arr = lambda vals, ct: (ct * self.n)(*vals)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        wsp = arr([self.ws[it[0]].data_ptr() for it in items], C.c_void_p)
+        dwp = arr([it[2].data_ptr() for it in items], C.c_void_p)
+        dbp = arr([ptr(it[3]) for it in items], C.c_void_p)
+        wdp = arr([ptr(it[4]) for it in items], C.c_void_p)
+        dec = arr([float(it[5]) for it in items], C.c_float)
+        dims = [arr([int(it[1][j]) for it in items], C.c_int) for j in range(6)]
+        host = (C.c_ubyte * int(lib().sqdet_slab_reduce_many_table_bytes(self.n)))()
+        blocks = C.c_int()
+        check(lib().sqdet_slab_reduce_many_prepare(wsp, dwp, dbp, wdp, dec, *dims, self.n, host, C.byref(blocks)), "sqdet_slab_reduce_many_prepare")
+        self.blocks = int(blocks.value)
+        self.table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
+
+    def partial(self, key, x, dy, x_coffset=0, dy_coffset=0):
+        """The gradient kernel of conv `key` on (x, dy): its partial slabs only."""
+        n, h, w, cin, cout, k = self.shape[key]
+        if tuple(x.shape[:3]) != (n, h, w) or tuple(dy.shape[:3]) != (n, h, w) or x.dtype != dy.dtype:
+            raise _lib.SqdetError("WgradPlan.partial: %s: tensors do not match the planned shape" % (key,))
+        check(lib().sqdet_conv2d_nhwc_bwd_filter_partial(_dev(x, "x"), _dev(dy, "dy"), _dev(self.ws[key], "ws"), int(self.has_bias[key]),
+                                                         n, h, w, cin, cout, k, int(x.shape[3]), int(x_coffset), int(dy.shape[3]),
+                                                         int(dy_coffset), dtype_code(x.dtype), stream_ptr()), "sqdet_conv2d_nhwc_bwd_filter_partial")
+
+    def reduce(self, grad_scale=1.0):
+        """dw / db of every item from the slabs its partial() wrote."""
+        check(lib().sqdet_slab_reduce_many(_dev(self.table, "table"), self.n, self.blocks, float(grad_scale), stream_ptr()), "sqdet_slab_reduce_many")
+
+
 def fold_batchnorm_bwd(w_hwio, dw_folded, db_folded, conv_bias, gamma, mean, var, eps, dw=None, dgamma=None, dbeta=None):
     """Gradients of kernels / gamma / beta of a _conv_bn_layer from the gradients of its folded kernel / bias
     (sqdet_fold_batchnorm_bwd).  Returns (dw, dgamma, dbeta); dw may be dw_folded itself (in place)."""
@@ -534,6 +592,17 @@ def maxpool_bwd(x, dy, size, stride, padding="SAME", relu=False):
     fn = lib().sqdet_maxpool_nhwc_bwd_relu if relu else lib().sqdet_maxpool_nhwc_bwd
     check(fn(_dev(x, "x"), _dev(dy, "dy", x.dtype), _dev(dx, "dx"), n, h, w, c, int(size), int(stride),
              pad_code(padding), dtype_code(x.dtype), stream_ptr()), "sqdet_maxpool_nhwc_bwd")
+    return dx
+
+
+def maxpool_bwd_idx(idx, y, dy, in_hw, size, stride, padding="SAME", relu=False):
+    """maxpool_bwd from the forward's window index (maxpool_nhwc_idx) and the pooled y; in_hw = (h, w) of the pool's input."""
+    n, ho, wo, c = [int(v) for v in dy.shape]
+    h, w = int(in_hw[0]), int(in_hw[1])
+    dx = torch.empty((n, h, w, c), dtype=dy.dtype, device=dy.device)
+    check(lib().sqdet_maxpool_nhwc_bwd_idx(_dev(idx, "idx", torch.uint8), _dev(y, "y", dy.dtype), _dev(dy, "dy"), _dev(dx, "dx"),
+                                           n, h, w, c, int(size), int(stride), pad_code(padding), dtype_code(dy.dtype),
+                                           1 if relu else 0, stream_ptr()), "sqdet_maxpool_nhwc_bwd_idx")
     return dx
 
 

@@ -97,6 +97,7 @@ class _TrainerBase:
         # become graph edges.  Same kernels, same order per buffer: bitwise the sequential results.
         self.overlap_wgrad = bool(overlap_wgrad) and os.environ.get("SQDET_WGRAD_OVERLAP", "1") != "0"
         self._wg_stream, self._wg_keep = None, []
+        self._wplans, self.plan_wgrads = {}, os.environ.get("SQDET_WGRAD_PLAN", "1") != "0"
         # dropout masks are independent across the global batch (one tf.nn.dropout over all samples in the reference,
         # nets/squeezeDet.py:74): every replica draws from its own counter stream -- only parameters and momentum must
         # match across ranks, masks must not
@@ -358,7 +359,7 @@ class SqueezeDetTrainer(_TrainerBase):
                         y = None        # e.g. set_option("conv_algo", 1): the separate conv + pool kernels below
                     if y is not None:
                         saved.append(("conv", node, cur, None))
-                        saved.append(("pool", nxt[2], None, y))
+                        saved.append(("pool", nxt[2], None, y, None))
                         acts[nxt[2].name] = y
                         cur = y
                         skip_pool = nxt[2]
@@ -377,8 +378,12 @@ class SqueezeDetTrainer(_TrainerBase):
                 cur = y
             elif item[0] == "pool":
                 node = item[2]
-                y = ops.maxpool_nhwc(cur, node.attrs["size"], node.attrs["stride"], node.attrs["padding"])
-                saved.append(("pool", node, cur, y))
+                if node.attrs["size"] == 3 and node.attrs["stride"] == 2:
+                    # the window index rides along: the backward reads it (+ y, dy) instead of searching x again
+                    y, widx = ops.maxpool_nhwc_idx(cur, 3, 2, node.attrs["padding"])
+                else:
+                    y, widx = ops.maxpool_nhwc(cur, node.attrs["size"], node.attrs["stride"], node.attrs["padding"]), None
+                saved.append(("pool", node, cur, y, widx))
                 acts[node.name] = y
                 cur = y
             else:
@@ -404,6 +409,21 @@ class SqueezeDetTrainer(_TrainerBase):
         self.flat_grads.zero_()
         gs = 1.0 / self.loss_scale      # g: gradient w.r.t. the current layer's OUTPUT (pre-activation mask applied below)
         bwd = lambda name: self.packplan.bwd[name] if name in self.packplan.bwd else ops.PackedConvBwd(P[name + "/kernels"], self.adt)
+        # weight gradients: every conv's gradient kernel writes its partial slabs into a workspace of its own and ONE launch
+        # at the end sums them all (ops.WgradPlan); the first step of an input shape runs the per-conv two-launch form and
+        # records what the plan needs
+        wkey = tuple(int(v) for v in x.shape)
+        wplan = self._wplans.get(wkey)
+        witems = []
+
+        def wg(name, xt, gt, k, cin, cout, dy_coffset=0):
+            if wplan is not None:
+                wplan.partial(name, xt, gt, dy_coffset=dy_coffset)
+                return
+            witems.append((name, (int(xt.shape[0]), int(xt.shape[1]), int(xt.shape[2]), cin, cout, k),
+                           self.gview[name + "/kernels"], self.gview[name + "/biases"], None, 0.0))
+            ops.conv2d_bwd_filter(xt, gt, k, cin, cout, dy_coffset=dy_coffset, dw=self.gview[name + "/kernels"],
+                                  db=self.gview[name + "/biases"], grad_scale=gs)
 
         def has_trainable(rec):
             if rec[0] == "conv":
@@ -434,8 +454,7 @@ class SqueezeDetTrainer(_TrainerBase):
                     ops.relu_bwd(y, g)
                 k = node.attrs["size"]
                 cin, cout = int(xin.shape[3]), int(y.shape[3])
-                self._wgrad(lambda xin=xin, g=g, k=k, cin=cin, cout=cout, name=name: ops.conv2d_bwd_filter(
-                    xin, g, k, cin, cout, dw=self.gview[name + "/kernels"], db=self.gview[name + "/biases"], grad_scale=gs), g)
+                self._wgrad(lambda xin=xin, g=g, k=k, cin=cin, cout=cout, name=name: wg(name, xin, g, k, cin, cout), g)
                 masked = False
                 if need_dx:
                     if name == "conv12" and keep != 1.0:
@@ -445,8 +464,11 @@ class SqueezeDetTrainer(_TrainerBase):
                         g = ops.conv2d_bwd_data(g, bwd(name), relu_of=below)
                         masked = below is not None
             elif rec[0] == "pool":
-                _, node, xin, y = rec
-                g = ops.maxpool_bwd(xin, g, node.attrs["size"], node.attrs["stride"], node.attrs["padding"], relu=below is not None)
+                _, node, xin, y, widx = rec
+                if widx is not None:
+                    g = ops.maxpool_bwd_idx(widx, y, g, xin.shape[1:3], 3, 2, node.attrs["padding"], relu=below is not None)
+                else:
+                    g = ops.maxpool_bwd(xin, g, node.attrs["size"], node.attrs["stride"], node.attrs["padding"], relu=below is not None)
                 masked = below is not None
             else:
                 _, (sq, e1, e3), xin, s, y = rec
@@ -454,18 +476,21 @@ class SqueezeDetTrainer(_TrainerBase):
                 if not masked:
                     ops.relu_bwd(y, g)      # both expand convs end in ReLU
                 def expand_wgrads(s=s, g=g, ns=ns, ne1=ne1, ne3=ne3, e1=e1, e3=e3):
-                    ops.conv2d_bwd_filter(s, g, 1, ns, ne1, dy_coffset=0, dw=self.gview[e1.name + "/kernels"], db=self.gview[e1.name + "/biases"], grad_scale=gs)
-                    ops.conv2d_bwd_filter(s, g, 3, ns, ne3, dy_coffset=ne1, dw=self.gview[e3.name + "/kernels"], db=self.gview[e3.name + "/biases"], grad_scale=gs)
+                    wg(e1.name, s, g, 1, ns, ne1, dy_coffset=0)
+                    wg(e3.name, s, g, 3, ns, ne3, dy_coffset=ne1)
                 self._wgrad(expand_wgrads, g)
                 ds = ops.conv2d_bwd_data(g, bwd(e1.name), dy_coffset=0)
                 ops.conv2d_bwd_data(g, bwd(e3.name), dx=ds, dy_coffset=ne1, accumulate=True, relu_of=s)   # + the squeeze's ReLU backward
-                self._wgrad(lambda xin=xin, ds=ds, ns=ns, sq=sq: ops.conv2d_bwd_filter(
-                    xin, ds, 1, int(xin.shape[3]), ns, dw=self.gview[sq.name + "/kernels"], db=self.gview[sq.name + "/biases"], grad_scale=gs), ds)
+                self._wgrad(lambda xin=xin, ds=ds, ns=ns, sq=sq: wg(sq.name, xin, ds, 1, int(xin.shape[3]), ns), ds)
                 masked = False
                 if need_dx:
                     g = ops.conv2d_bwd_data(ds, bwd(sq.name), relu_of=below)
                     masked = below is not None
         self._join_wgrad()
+        if wplan is not None:
+            wplan.reduce(gs)
+        elif self.plan_wgrads:
+            self._wplans[wkey] = ops.WgradPlan(witems)
         out = collections.OrderedDict(class_loss=losses[0], conf_loss=losses[1], bbox_loss=losses[2], ious=ious, preds=preds,
                                       dpreds=dpreds, num_objects=num_objects)
         if keep_activations:

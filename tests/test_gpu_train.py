@@ -74,6 +74,75 @@ def test_conv_backward_data_and_filter(case):
     _close(dbg, b.grad, what=name + " dbias")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+def test_wgrad_plan_one_reduction_for_many_convs(dtype):
+    """ops.WgradPlan (sqdet_conv2d_nhwc_bwd_filter_partial per conv + ONE sqdet_slab_reduce_many) against the per-conv
+    two-launch sqdet_conv2d_nhwc_bwd_filter: bitwise, with and without bias / weight decay, channel-sliced dy, twice."""
+    ops = _ops()
+    ev = 8 if dtype == torch.float16 else 4
+    cases = [c for c in BWD_CASES if c[4] % ev == 0 and c[5] % ev == 0 and c[0] in (
+        "e3_16_64", "convdet_768_72", "e3_32_128_9tap", "sq_512_96", "ragged_20_36", "ragged_40_24", "plus_e3_384_256", "e1_48_192")]
+    assert len(cases) >= 6
+    rs = np.random.RandomState(5)
+    items, data, want = [], {}, {}
+    for i, (name, N, H, W, cin, cout, k) in enumerate(cases):
+        x = torch.from_numpy(rs.randn(N, H, W, cin).astype(np.float32)).to(DEV, dtype)
+        off = ev * (i % 3)
+        dy = torch.from_numpy(rs.randn(N, H, W, cout + off + ev).astype(np.float32)).to(DEV, dtype)     # the conv reads a channel slice
+        w = torch.from_numpy(rs.randn(k, k, cin, cout).astype(np.float32)).to(DEV) if i % 2 else None
+        dw = torch.empty(k, k, cin, cout, dtype=torch.float32, device=DEV)
+        db = torch.empty(cout, dtype=torch.float32, device=DEV) if i % 3 else None
+        items.append((name, (N, H, W, cin, cout, k), dw, db, w, 1e-3 * i))
+        data[name] = (x, dy, off)
+        want[name] = ops.conv2d_bwd_filter(x, dy, k, cin, cout, w_for_decay=w, weight_decay=1e-3 * i, dy_coffset=off,
+                                           want_bias=db is not None, grad_scale=0.25)
+    plan = ops.WgradPlan(items)
+    for _ in range(2):
+        for name, _, dw, db, _, _ in items:
+            dw.fill_(float("nan"))
+            x, dy, off = data[name]
+            plan.partial(name, x, dy, dy_coffset=off)
+        plan.reduce(0.25)
+        torch.cuda.synchronize()
+        for name, _, dw, db, _, _ in items:
+            assert torch.equal(dw, want[name][0]), name
+            assert db is None or torch.equal(db, want[name][1]), name
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+def test_maxpool_window_index_forward_and_backward(dtype):
+    """sqdet_maxpool_nhwc_fwd_idx / sqdet_maxpool_nhwc_bwd_idx: y bitwise sqdet_maxpool_nhwc_fwd's, the index names the FIRST
+    maximum (ties included: quantised inputs), and dx -- with and without the fused ReLU backward -- bitwise the x-searching
+    kernels' (sqdet_maxpool_nhwc_bwd / _bwd_relu)."""
+    ops = _ops()
+    rs = np.random.RandomState(17)
+    ev = 8 if dtype == torch.float16 else 4
+    for (N, H, W, C, pad) in ((2, 47, 156, 4 * ev, "SAME"), (1, 94, 311, ev, "SAME"), (2, 20, 31, 2 * ev, "VALID"), (1, 7, 9, ev, "SAME")):
+        x = torch.from_numpy(np.maximum(np.round(rs.randn(N, H, W, C) * 2) / 2, 0).astype(np.float32)).to(DEV, dtype)   # many ties, ReLU-like
+        y0 = ops.maxpool_nhwc(x, 3, 2, pad)
+        y, idx = ops.maxpool_nhwc_idx(x, 3, 2, pad)
+        assert torch.equal(y, y0)
+        # the index against a direct scan on the host
+        xc, ic = x.float().cpu().numpy(), idx.cpu().numpy()
+        Ho, Wo = y.shape[1:3]
+        pt = max((Ho - 1) * 2 + 3 - H, 0) // 2 if pad == "SAME" else 0
+        pl = max((Wo - 1) * 2 + 3 - W, 0) // 2 if pad == "SAME" else 0
+        for (n, oy, ox) in [(0, 0, 0), (N - 1, Ho - 1, Wo - 1), (0, Ho // 2, Wo // 3), (N - 1, 1, Wo - 1), (0, Ho - 1, 0)]:
+            best, pos = np.full(C, -np.inf, np.float32), np.full(C, 255, np.int64)
+            for t in range(9):
+                iy, ix = 2 * oy - pt + t // 3, 2 * ox - pl + t % 3
+                if 0 <= iy < H and 0 <= ix < W:
+                    win = xc[n, iy, ix] > best
+                    best, pos = np.where(win, xc[n, iy, ix], best), np.where(win, t, pos)
+            np.testing.assert_array_equal(ic[n, oy, ox], pos)
+        dy = torch.from_numpy(rs.randn(*y.shape).astype(np.float32)).to(DEV, dtype)
+        for relu in (False, True):
+            want = ops.maxpool_bwd(x, dy, 3, 2, pad, relu=relu)
+            got = ops.maxpool_bwd_idx(idx, y, dy, (H, W), 3, 2, pad, relu=relu)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), (N, H, W, C, pad, relu)
+
+
 def test_fire_backward_channel_slices_and_accumulate():
     """A fire module's backward: dY is the concat gradient; expand1x1 / expand3x3 read its two channel
     ranges, and the squeeze tensor's gradient is the SUM of their backward-data results."""
@@ -418,20 +487,23 @@ def test_training_reduces_loss_on_fixed_batch():
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_side_stream_weight_gradients_equal_the_serial_order(dtype):
-    """overlap_wgrad=True issues the weight-gradient launches on a second stream beside the backward-data chain: three
-    steps from the same start must leave bit-identical gradients and variables to the single-stream order."""
+    """overlap_wgrad=True issues the weight-gradient launches on a second stream beside the backward-data chain, and from the
+    second step on their slab reductions are ONE launch: three steps from the same start must leave bit-identical gradients
+    and variables to the single-stream, reduction-per-conv order."""
     omc = O.squeezeDet_config_for_input(128, 256)
     x = O.synthetic_images(2, 128, 256, seed=41)
     mask, delta, box, labels = TO.synthetic_labels(omc, 2, seed=42)
     res = []
-    for overlap in (False, True):
+    for overlap, plan in ((False, False), (True, True), (True, False)):
         tr, mc, params = _trainer(seed=5, dtype=dtype, overlap_wgrad=overlap)
-        tr.seed = 77
+        tr.seed, tr.plan_wgrads = 77, plan        # plan: one slab reduction per step (ops.WgradPlan) from the second step on
         for _ in range(3):
             tr.step(x, mask, delta, box, labels)
         torch.cuda.synchronize()
+        assert bool(tr._wplans) == plan
         res.append((tr.flat_grads.clone(), tr.flat_params.clone()))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for r in res[1:]:
+        assert torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1])
 
 
 def test_momentum_clip_optimizer_vs_oracle():
