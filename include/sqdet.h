@@ -111,6 +111,19 @@ int sqdet_fold_batchnorm_bwd(const float* w_hwio, const float* dw_folded, const 
                              const float* conv_bias, const float* gamma, const float* mean, const float* var, float eps,
                              float* dw, float* dgamma, float* dbeta, float* workspace, int k, int cin, int cout,
                              sqdet_stream_t stream);
+/* The same for MANY convs in two launches (per conv the results are bitwise sqdet_fold_batchnorm_bwd's): prepare() fills
+ * a host table of sqdet_fold_batchnorm_bwd_many_table_bytes(n_items) bytes from per-item pointer arrays (conv_bias[i] may
+ * be NULL; workspace[i]: that conv's sqdet_fold_batchnorm_bwd_workspace_bytes) and reports the two grids; the caller copies
+ * the table to the device once. */
+size_t sqdet_fold_batchnorm_bwd_many_table_bytes(int n_items);
+int sqdet_fold_batchnorm_bwd_many_prepare(const float* const* w_hwio, const float* const* dw_folded,
+                                          const float* const* db_folded, const float* const* conv_bias,
+                                          const float* const* gamma, const float* const* mean, const float* const* var,
+                                          float* const* dw, float* const* dgamma, float* const* dbeta, float* const* workspace,
+                                          const int* k, const int* cin, const int* cout, int n_items, void* table_host,
+                                          int* blocks, int* finish_blocks);
+int sqdet_fold_batchnorm_bwd_many(const void* table_dev, int n_items, int blocks, int finish_blocks, float eps,
+                                  sqdet_stream_t stream);
 
 /* y[n,oy,ox,:] = x[n,oy*stride,ox*stride,:], y: [n,ceil(h/stride),ceil(w/stride),c] -- the pixels a 1x1
  * stride-s SAME conv reads (res3a/res4a branch1 and branch2a), so that their filter gradient can use
@@ -285,6 +298,14 @@ int sqdet_detect_filter_scored(const void* preds, const float* anchors, const fl
 size_t sqdet_conv_pack_many_table_bytes(int nitems);
 int sqdet_conv_pack_many_prepare(const float* const* w_hwio_f32, void* const* packed, const int* k, const int* cin, const int* cout,
                                  const int* bwd_data, int nitems, int dtype, void* table_host, int* total_blocks);
+/* With the batch norm of _conv_bn_layer convs folded on the way (items whose gamma[i] != NULL): what is packed is
+ * W[..., c] * gamma[c] / sqrt(var[c] + eps) -- sqdet_fold_batchnorm followed by the packer, bit for bit, without the folded
+ * float32 kernel ever being written -- and b_folded[i] (when not NULL) receives the folded bias.  The pointer arrays may be
+ * NULL altogether (= sqdet_conv_pack_many_prepare). */
+int sqdet_conv_pack_many_prepare_bn(const float* const* w_hwio_f32, void* const* packed, const int* k, const int* cin,
+                                    const int* cout, const int* bwd_data, const float* const* gamma, const float* const* beta,
+                                    const float* const* mean, const float* const* var, const float* const* conv_bias,
+                                    float* const* b_folded, float eps, int nitems, int dtype, void* table_host, int* total_blocks);
 int sqdet_conv_pack_many(const void* table_dev, int nitems, int total_blocks, int dtype, sqdet_stream_t stream);
 
 /* Backward-data: dx = conv(dy, rot180(W)^T).  pack: float32 HWIO [k,k,cin,cout] -> fragment order

@@ -29,6 +29,9 @@ SIGNATURES = {
     "sqdet_fold_batchnorm": (ci, [vp] * 6 + [cf, vp, vp, ci, ci, ci, vp]),
     "sqdet_fold_batchnorm_bwd_workspace_bytes": (sz, [ci] * 3),
     "sqdet_fold_batchnorm_bwd": (ci, [vp] * 7 + [cf, vp, vp, vp, vp, ci, ci, ci, vp]),
+    "sqdet_fold_batchnorm_bwd_many_table_bytes": (sz, [ci]),
+    "sqdet_fold_batchnorm_bwd_many_prepare": (ci, [vp] * 14 + [ci, vp, vp, vp]),
+    "sqdet_fold_batchnorm_bwd_many": (ci, [vp, ci, ci, ci, cf, vp]),
     "sqdet_subsample_nhwc": (ci, [vp, vp] + [ci] * 6 + [vp]),
     "sqdet_maxpool_nhwc_fwd": (ci, [vp, vp] + [ci] * 8 + [vp]),
     "sqdet_maxpool_nhwc_fwd_idx": (ci, [vp, vp, vp] + [ci] * 8 + [vp]),
@@ -62,6 +65,7 @@ SIGNATURES = {
     "sqdet_conv_pack_weights_bwd_data": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "sqdet_conv_pack_many_table_bytes": (sz, [ci]),
     "sqdet_conv_pack_many_prepare": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, vp, C.POINTER(ci)]),
+    "sqdet_conv_pack_many_prepare_bn": (ci, [vp] * 12 + [cf, ci, ci, vp, vp]),
     "sqdet_conv_pack_many": (ci, [vp, ci, ci, ci, vp]),
     "sqdet_conv2d_nhwc_bwd_data": (ci, [vp, vp, vp] + [ci] * 10 + [vp]),
     "sqdet_conv2d_nhwc_bwd_data_relu": (ci, [vp, vp, vp, vp] + [ci] * 10 + [vp]),

@@ -113,6 +113,63 @@ int fold_bn_bwd_launch(const float* w, const float* dwf, const float* dbf, const
   return SQDET_OK;
 }
 
+// The same for MANY _conv_bn_layer convs in two launches (a ResNet50 step has 19 trainable ones: 38 launches of 5-10 us
+// behind as many slab reductions): a table entry per conv, workgroup b of launch (1) serves the entry whose range holds b
+// with fold_bn_bwd_kernel's block shape and arithmetic, launch (2) likewise with fold_bn_bwd_finish_kernel's -- per conv the
+// results are bitwise sqdet_fold_batchnorm_bwd's.
+struct FoldBwdItem {
+  const float *w, *dwf, *dbf, *cbias, *gamma, *mean, *var;
+  float *dw, *dgamma, *dbeta, *partial;
+  int rows, cout, nblocks_y, blocks_x;
+  unsigned first_block, first_finish;     // launch (1): blocks_x * nblocks_y workgroups; launch (2): ceil(cout / 256)
+};
+
+__global__ __launch_bounds__(256) void fold_bn_bwd_many_kernel(const FoldBwdItem* __restrict__ items, int n, float eps) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].first_block <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const FoldBwdItem it = items[lo];
+  const unsigned local = blockIdx.x - it.first_block;
+  const int bx = (int)(local % (unsigned)it.blocks_x), by = (int)(local / (unsigned)it.blocks_x);
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, rp = threadIdx.x >> 6;
+  const int c = bx * 64 + cl;
+  const int r0 = by * FB_ROWS;
+  float s = 0.f;
+  if (c < it.cout) {
+    const float inv = it.gamma[c] * (1.f / sqrtf(it.var[c] + eps));
+    const int r1 = min(it.rows, r0 + FB_ROWS);
+    for (int row = r0 + rp; row < r1; row += 4) {
+      const size_t i = (size_t)row * it.cout + c;
+      const float g = it.dwf[i];
+      s += g * it.w[i];
+      it.dw[i] = g * inv;
+    }
+  }
+  part[rp][cl] = s;
+  __syncthreads();
+  if (rp == 0 && c < it.cout) it.partial[(size_t)by * it.cout + c] = ((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl];
+}
+
+__global__ void fold_bn_bwd_finish_many_kernel(const FoldBwdItem* __restrict__ items, int n, float eps) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].first_finish <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const FoldBwdItem it = items[lo];
+  const int c = (int)(blockIdx.x - it.first_finish) * blockDim.x + threadIdx.x;
+  if (c >= it.cout) return;
+  float tot = 0.f;
+  for (int b = 0; b < it.nblocks_y; ++b) tot += it.partial[(size_t)b * it.cout + c];
+  const float r = 1.f / sqrtf(it.var[c] + eps);
+  const float db = it.dbf[c];
+  it.dgamma[c] = r * (tot + ((it.cbias ? it.cbias[c] : 0.f) - it.mean[c]) * db);
+  it.dbeta[c] = db;
+}
+
 // y[n, oy, ox, :] = x[n, oy*stride, ox*stride, :]: the pixels a 1x1 / stride-s SAME conv reads (the
 // projection shortcut and branch2a of res3a / res4a, resnet50_convDet.py:71-73,150-156), gathered so the
 // stride-1 filter-gradient kernel can be used on them.  16 bytes per thread.
@@ -168,4 +225,48 @@ extern "C" int sqdet_fold_batchnorm(const float* w_hwio, const float* conv_bias,
                                     int k, int cin, int cout, sqdet_stream_t stream) {
   return sqdet::fold_bn_launch(w_hwio, conv_bias, gamma, beta, mean, var, eps, w_folded, b_folded, k, cin, cout,
                                sqdet::as_stream(stream));
+}
+
+extern "C" size_t sqdet_fold_batchnorm_bwd_many_table_bytes(int n_items) {
+  return n_items > 0 ? (size_t)n_items * sizeof(sqdet::FoldBwdItem) : 0;
+}
+
+extern "C" int sqdet_fold_batchnorm_bwd_many_prepare(const float* const* w_hwio, const float* const* dw_folded,
+                                                     const float* const* db_folded, const float* const* conv_bias,
+                                                     const float* const* gamma, const float* const* mean,
+                                                     const float* const* var, float* const* dw, float* const* dgamma,
+                                                     float* const* dbeta, float* const* workspace, const int* k, const int* cin,
+                                                     const int* cout, int n_items, void* table_host, int* blocks,
+                                                     int* finish_blocks) {
+  SQDET_REQUIRE(w_hwio && dw_folded && db_folded && conv_bias && gamma && mean && var && dw && dgamma && dbeta && workspace && k &&
+                    cin && cout && table_host && blocks && finish_blocks && n_items > 0, "fold_batchnorm_bwd_many_prepare: bad arguments");
+  sqdet::FoldBwdItem* t = static_cast<sqdet::FoldBwdItem*>(table_host);
+  unsigned nb = 0, nf = 0;
+  for (int i = 0; i < n_items; ++i) {
+    SQDET_REQUIRE(w_hwio[i] && dw_folded[i] && db_folded[i] && gamma[i] && mean[i] && var[i] && dw[i] && dgamma[i] && dbeta[i] &&
+                      workspace[i] && k[i] > 0 && cin[i] > 0 && cout[i] > 0, "fold_batchnorm_bwd_many_prepare: bad item %d", i);
+    sqdet::FoldBwdItem& it = t[i];
+    it.w = w_hwio[i]; it.dwf = dw_folded[i]; it.dbf = db_folded[i]; it.cbias = conv_bias[i]; it.gamma = gamma[i];
+    it.mean = mean[i]; it.var = var[i]; it.dw = dw[i]; it.dgamma = dgamma[i]; it.dbeta = dbeta[i]; it.partial = workspace[i];
+    it.rows = k[i] * k[i] * cin[i]; it.cout = cout[i];
+    it.nblocks_y = (it.rows + sqdet::FB_ROWS - 1) / sqdet::FB_ROWS;
+    it.blocks_x = (cout[i] + 63) / 64;
+    it.first_block = nb; it.first_finish = nf;
+    nb += (unsigned)(it.blocks_x * it.nblocks_y);
+    nf += (unsigned)((cout[i] + 255) / 256);
+  }
+  *blocks = (int)nb; *finish_blocks = (int)nf;
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_fold_batchnorm_bwd_many(const void* table_dev, int n_items, int blocks, int finish_blocks, float eps,
+                                             sqdet_stream_t stream) {
+  SQDET_REQUIRE(table_dev && n_items > 0 && blocks > 0 && finish_blocks > 0 && eps >= 0.f, "fold_batchnorm_bwd_many: bad arguments");
+  const sqdet::FoldBwdItem* t = static_cast<const sqdet::FoldBwdItem*>(table_dev);
+  hipLaunchKernelGGL(sqdet::fold_bn_bwd_many_kernel, dim3((unsigned)blocks), dim3(256), 0, sqdet::as_stream(stream), t, n_items, eps);
+  SQDET_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(sqdet::fold_bn_bwd_finish_many_kernel, dim3((unsigned)finish_blocks), dim3(256), 0, sqdet::as_stream(stream), t,
+                     n_items, eps);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
 }

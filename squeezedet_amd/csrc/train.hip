@@ -61,6 +61,11 @@ struct PackItem {
   int bwd;               // 0 forward order (pack_weights_kernel), 1 backward-data order (pack_bwd_data_kernel)
   unsigned long long total;
   int first_block, nblocks;
+  // gamma != NULL: the kernel of a _conv_bn_layer -- what is packed is the FOLDED kernel W[..., c] * gamma[c] / sqrt(var[c] + eps)
+  // (fold_bn_kernel's expression, bn.hip), and the item's first workgroup also writes the folded bias b_folded (when not NULL)
+  const float *gamma, *var, *beta, *mean, *cbias;
+  float* b_folded;
+  float eps;
 };
 
 template <typename T>
@@ -85,13 +90,21 @@ __global__ __launch_bounds__(256) void pack_many_kernel(const PackItem* __restri
     const int co = group * 16 * p.nt + (i >> 2) * 4 * p.nt + n * 4 + (i & 3);
     const int ci = chunk * KC + g * KG + e;
     float v = 0.f;
+    int oc = -1;             // the ORIGINAL output channel of the element (the batch-norm channel)
     if (!p.bwd) {            // exactly pack_weights_kernel (conv.hip)
-      if (co < p.cout && ci < p.kdim) v = w[((size_t)tap * p.kdim + ci) * p.cout + co];
+      if (co < p.cout && ci < p.kdim) { v = w[((size_t)tap * p.kdim + ci) * p.cout + co]; oc = co; }
     } else {                 // exactly pack_bwd_data_kernel: output channel of the dgrad = original cin, input = original cout
       const int ty = tap / p.k, tx = tap - ty * p.k;
-      if (co < p.cin && ci < p.cout) v = w[(((size_t)(p.k - 1 - ty) * p.k + (p.k - 1 - tx)) * p.cin + co) * p.cout + ci];
+      if (co < p.cin && ci < p.cout) { v = w[(((size_t)(p.k - 1 - ty) * p.k + (p.k - 1 - tx)) * p.cin + co) * p.cout + ci]; oc = ci; }
     }
+    if (p.gamma && oc >= 0) v = v * (p.gamma[oc] / sqrtf(p.var[oc] + p.eps));
     out[idx] = (T)v;
+  }
+  if (p.gamma && p.b_folded && (int)blockIdx.x == p.first_block) {
+    for (int c = threadIdx.x; c < p.cout; c += 256) {
+      const float inv = p.gamma[c] / sqrtf(p.var[c] + p.eps);
+      p.b_folded[c] = ((p.cbias ? p.cbias[c] : 0.f) - p.mean[c]) * inv + p.beta[c];
+    }
   }
 }
 
@@ -636,11 +649,14 @@ extern "C" int sqdet_conv_pack_weights_bwd_data(const float* w_hwio_f32, void* p
 
 extern "C" size_t sqdet_conv_pack_many_table_bytes(int nitems) { return (size_t)(nitems > 0 ? nitems : 0) * sizeof(sqdet::PackItem); }
 
-extern "C" int sqdet_conv_pack_many_prepare(const float* const* w_hwio_f32, void* const* packed, const int* k, const int* cin,
-                                            const int* cout, const int* bwd_data, int nitems, int dtype, void* table_host,
-                                            int* total_blocks) {
+extern "C" int sqdet_conv_pack_many_prepare_bn(const float* const* w_hwio_f32, void* const* packed, const int* k, const int* cin,
+                                               const int* cout, const int* bwd_data, const float* const* gamma,
+                                               const float* const* beta, const float* const* mean, const float* const* var,
+                                               const float* const* conv_bias, float* const* b_folded, float eps, int nitems,
+                                               int dtype, void* table_host, int* total_blocks) {
   SQDET_REQUIRE(w_hwio_f32 && packed && k && cin && cout && bwd_data && table_host && total_blocks && nitems > 0, "pack_many_prepare: bad arguments");
   SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "pack_many_prepare: bad dtype");
+  SQDET_REQUIRE(!gamma || (beta && mean && var && conv_bias && b_folded && eps >= 0.f), "pack_many_prepare: incomplete batch-norm arrays");
   sqdet::PackItem* t = reinterpret_cast<sqdet::PackItem*>(table_host);
   int blocks = 0;
   for (int i = 0; i < nitems; ++i) {
@@ -655,9 +671,21 @@ extern "C" int sqdet_conv_pack_many_prepare(const float* const* w_hwio_f32, void
     if (nb > 256) nb = 256;
     p.first_block = blocks; p.nblocks = nb;
     blocks += nb;
+    p.gamma = p.var = p.beta = p.mean = p.cbias = nullptr; p.b_folded = nullptr; p.eps = eps;
+    if (gamma && gamma[i]) {
+      SQDET_REQUIRE(beta[i] && mean[i] && var[i], "pack_many_prepare: item %d: gamma without beta / mean / var", i);
+      p.gamma = gamma[i]; p.beta = beta[i]; p.mean = mean[i]; p.var = var[i]; p.cbias = conv_bias[i]; p.b_folded = b_folded[i];
+    }
   }
   *total_blocks = blocks;
   return SQDET_OK;
+}
+
+extern "C" int sqdet_conv_pack_many_prepare(const float* const* w_hwio_f32, void* const* packed, const int* k, const int* cin,
+                                            const int* cout, const int* bwd_data, int nitems, int dtype, void* table_host,
+                                            int* total_blocks) {
+  return sqdet_conv_pack_many_prepare_bn(w_hwio_f32, packed, k, cin, cout, bwd_data, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                         nullptr, 0.f, nitems, dtype, table_host, total_blocks);
 }
 
 extern "C" int sqdet_conv_pack_many(const void* table_dev, int nitems, int total_blocks, int dtype, sqdet_stream_t stream) {

@@ -402,46 +402,87 @@ class PackPlan:
     """Every trainable conv kernel of a trainer packed in ONE launch (sqdet_conv_pack_many): the forward fragment order
     (PackedConv) and, for the convs whose input needs a gradient, the backward-data conv's order (PackedConvBwd), into
     persistent buffers.  weights: {name: float32 HWIO tensor (a VIEW whose storage does not move: the trainer's flat
-    parameter buffer)}; run() re-packs all of them from their current values."""
+    parameter buffer)}; run() re-packs all of them from their current values.
+    bn: {name: (gamma, beta, mean, var, conv_bias or None)} for the _conv_bn_layer convs among them -- their batch norm is
+    folded on the way (sqdet_conv_pack_many_prepare_bn: bitwise fold_batchnorm + the packer) and self.bias[name] receives
+    the folded bias."""
 
-    def __init__(self, weights, dtype, bwd_names=()):
+    def __init__(self, weights, dtype, bwd_names=(), bn=None, eps=0.0):
         self.dtype = dtype
         code = dtype_code(dtype)
-        self.fwd, self.bwd = {}, {}
+        bn = bn or {}
+        self.fwd, self.bwd, self.bias = {}, {}, {}
         items = []
         for name, w in weights.items():
             if w.dtype != torch.float32 or not w.is_contiguous():
                 raise _lib.SqdetError("PackPlan: %s must be a contiguous float32 HWIO tensor" % name)
             k, k2, cin, cout = [int(v) for v in w.shape]
+            fold = bn.get(name)
+            if fold is not None:
+                for t in fold[:4]:
+                    if t.dtype != torch.float32 or not t.is_contiguous() or int(t.numel()) != cout:
+                        raise _lib.SqdetError("PackPlan: %s: batch-norm vectors must be contiguous float32 [cout]" % name)
+                self.bias[name] = torch.empty(cout, dtype=torch.float32, device=w.device)
             pc = PackedConv.__new__(PackedConv)
             pc.k, pc.cin, pc.cout, pc.dtype = k, cin, cout, dtype
             pc.data = torch.empty(int(lib().sqdet_conv_packed_bytes(k, cin, cout, code)), dtype=torch.uint8, device=w.device)
             self.fwd[name] = pc
-            items.append((w, pc.data, k, cin, cout, 0))
+            items.append((w, pc.data, k, cin, cout, 0, fold, self.bias.get(name)))
             if name in bwd_names:
                 pb = PackedConvBwd.__new__(PackedConvBwd)
                 pb.k, pb.cin, pb.cout, pb.dtype = k, cin, cout, dtype
                 pb.data = torch.empty(int(lib().sqdet_conv_packed_bytes(k, cout, cin, code)), dtype=torch.uint8, device=w.device)
                 self.bwd[name] = pb
-                items.append((w, pb.data, k, cin, cout, 1))
+                items.append((w, pb.data, k, cin, cout, 1, fold, None))
         n = len(items)
         self.n = n
         self._keep = items
         dev = items[0][0].device
         arr = lambda vals, ct: (ct * n)(*vals)
+        ptr = lambda t: t.data_ptr() if t is not None else None
         wp = arr([it[0].data_ptr() for it in items], C.c_void_p)
         op = arr([it[1].data_ptr() for it in items], C.c_void_p)
         ks, cis, cos, bw = [arr([it[j] for it in items], C.c_int) for j in (2, 3, 4, 5)]
+        bnp = [arr([ptr(it[6][j]) if it[6] is not None else None for it in items], C.c_void_p) for j in range(5)]   # gamma beta mean var conv_bias
+        bfp = arr([ptr(it[7]) for it in items], C.c_void_p)
         nbytes = int(lib().sqdet_conv_pack_many_table_bytes(n))
         host = (C.c_ubyte * nbytes)()
         blocks = C.c_int()
-        check(lib().sqdet_conv_pack_many_prepare(wp, op, ks, cis, cos, bw, n, code, host, C.byref(blocks)), "sqdet_conv_pack_many_prepare")
+        check(lib().sqdet_conv_pack_many_prepare_bn(wp, op, ks, cis, cos, bw, bnp[0], bnp[1], bnp[2], bnp[3], bnp[4], bfp, float(eps), n,
+                                                    code, host, C.byref(blocks)), "sqdet_conv_pack_many_prepare_bn")
         self.blocks = int(blocks.value)
         self.table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
 
     def run(self):
         check(lib().sqdet_conv_pack_many(_dev(self.table, "table"), self.n, self.blocks, dtype_code(self.dtype), stream_ptr()),
               "sqdet_conv_pack_many")
+
+
+class FoldBwdPlan:
+    """sqdet_fold_batchnorm_bwd for MANY _conv_bn_layer convs in two launches.  items: [(w, dw_folded, db_folded, conv_bias or
+    None, gamma, mean, var, dw, dgamma, dbeta)] -- persistent float32 tensors; run() after the folded gradients are in place."""
+
+    def __init__(self, items, eps):
+        self.n, self.eps, self._keep = len(items), float(eps), items
+        dev = items[0][0].device
+        dims = [[int(v) for v in it[0].shape] for it in items]
+        self.ws = [torch.empty(int(lib().sqdet_fold_batchnorm_bwd_workspace_bytes(d[0], d[2], d[3])) // 4 + 16, dtype=torch.float32, device=dev)
+                   for d in dims]
+        arr = lambda vals, ct: (ct * self.n)(*vals)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        cols = [arr([ptr(it[j]) for it in items], C.c_void_p) for j in range(10)]
+        wsp = arr([t.data_ptr() for t in self.ws], C.c_void_p)
+        ks, cis, cos = [arr([d[j] for d in dims], C.c_int) for j in (0, 2, 3)]
+        host = (C.c_ubyte * int(lib().sqdet_fold_batchnorm_bwd_many_table_bytes(self.n)))()
+        b1, b2 = C.c_int(), C.c_int()
+        check(lib().sqdet_fold_batchnorm_bwd_many_prepare(*cols, wsp, ks, cis, cos, self.n, host, C.byref(b1), C.byref(b2)),
+              "sqdet_fold_batchnorm_bwd_many_prepare")
+        self.blocks, self.finish_blocks = int(b1.value), int(b2.value)
+        self.table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
+
+    def run(self):
+        check(lib().sqdet_fold_batchnorm_bwd_many(_dev(self.table, "table"), self.n, self.blocks, self.finish_blocks, self.eps, stream_ptr()),
+              "sqdet_fold_batchnorm_bwd_many")
 
 
 def conv2d_bwd_data(dy, packed_bwd, dx=None, dy_coffset=0, accumulate=False, relu_of=None):

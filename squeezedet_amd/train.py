@@ -531,6 +531,30 @@ class ResNet50ConvDetTrainer(_TrainerBase):
         for n in self.region:
             if n.op in ("conv", "conv_bn") and not has_tr(n):
                 raise SqdetError("frozen conv %s above the first trainable one is not supported" % n.name)
+        self._plans_for = None
+        self._build_plans()
+
+    def _bn_pointers(self):
+        P = self.model.params
+        return tuple(P[n.name + s].data_ptr() for n in self.region if n.op == "conv_bn" for s in ("/mean", "/var"))
+
+    def _build_plans(self):
+        """One launch per step for everything that is per-variable bookkeeping (was ~6 launches of 5-10 us for each of the 19
+        trainable convs): PackPlan folds the batch norms and packs every kernel in both orders; FoldBwdPlan turns the
+        folded gradients (staged in self.dwf / self.dbf by the weight-gradient kernels) into d(kernels), d(gamma), d(beta)."""
+        P, eps = self.model.params, self.mc.BATCH_NORM_EPSILON
+        convs = [n for n in self.region if n.op in ("conv", "conv_bn")]
+        kernels = collections.OrderedDict((n.name, self.view[n.name + "/kernels"]) for n in convs)
+        bn = {n.name: (P[n.name + "/gamma"], P[n.name + "/beta"], P[n.name + "/mean"], P[n.name + "/var"], None)
+              for n in convs if n.op == "conv_bn"}
+        bwd_names = set(n.name for n in convs if n.attrs["stride"] == 1 and n.inputs[0] is not self.boundary)
+        self.packplan = ops.PackPlan(kernels, self.adt, bwd_names=bwd_names, bn=bn, eps=eps)
+        self.dwf = {n.name: torch.empty_like(self.view[n.name + "/kernels"]) for n in convs if n.op == "conv_bn"}
+        self.dbf = {n.name: torch.empty(int(self.view[n.name + "/kernels"].shape[3]), dtype=torch.float32, device=self.dev) for n in convs if n.op == "conv_bn"}
+        self.foldplan = ops.FoldBwdPlan([(self.view[n.name + "/kernels"], self.dwf[n.name], self.dbf[n.name], None, P[n.name + "/gamma"],
+                                          P[n.name + "/mean"], P[n.name + "/var"], self.gview[n.name + "/kernels"],
+                                          self.gview[n.name + "/gamma"], self.gview[n.name + "/beta"]) for n in convs if n.op == "conv_bn"], eps)
+        self._plans_for = self._bn_pointers()
 
     def step(self, images, input_mask, box_delta_input, box_input, labels, dropout_mask=None, apply_update=True,
              keep_activations=False, num_objects=None):
@@ -543,6 +567,10 @@ class ResNet50ConvDetTrainer(_TrainerBase):
                          keep_activations=False, num_objects=None, num_objects_is_global=False):
         m, mc, P = self.model, self.mc, self.model.params
         eps = mc.BATCH_NORM_EPSILON
+        if self._plans_for != self._bn_pointers():     # load_params replaced the (non-trainable) moving statistics
+            self._build_plans()
+        self.packplan.run()     # every trainable kernel, batch norm folded, in both fragment orders + the folded biases: one launch
+        pk, pbias = self.packplan.fwd, self.packplan.bias
         (xb,) = m.run([self.boundary], {m.image_input: images}, use_plan=False)
         B = int(xb.shape[0])
         t, mask, delta, box, lab, num_objects = self._labels(B, input_mask, box_delta_input, box_input, labels, num_objects, num_objects_is_global)
@@ -551,21 +579,17 @@ class ResNet50ConvDetTrainer(_TrainerBase):
         for n in self.region:
             if n.op == "conv_bn":
                 x = val[n.inputs[0]]
-                wf, bf = ops.fold_batchnorm(P[n.name + "/kernels"], None, P[n.name + "/gamma"], P[n.name + "/beta"],
-                                            P[n.name + "/mean"], P[n.name + "/var"], eps)
-                aux[n], aux[(n, "bf")] = wf, bf
                 fused_add = len(n.readers) == 1 and n.readers[0].op == "add_relu" and n.readers[0].inputs[1] is n and not n.attrs["relu"]
                 if fused_add:
                     continue        # evaluated by its add_relu reader (residual epilogue)
-                val[n] = ops.conv2d_nhwc(x, ops.pack_conv_weights(wf, self.adt), bf, n.attrs["stride"], n.attrs["padding"], n.attrs["relu"])
+                val[n] = ops.conv2d_nhwc(x, pk[n.name], pbias[n.name], n.attrs["stride"], n.attrs["padding"], n.attrs["relu"])
             elif n.op == "add_relu":
                 sc, br = n.inputs
                 if br in val:
                     val[n] = ops.add_relu(val[sc], val[br])
                 else:
-                    wf, bf = aux[br], aux[(br, "bf")]
                     out = val[sc].clone()         # the shortcut is branch2a's input: its value is needed by the backward
-                    val[n] = ops.conv2d_nhwc(val[br.inputs[0]], ops.pack_conv_weights(wf, self.adt), bf, br.attrs["stride"],
+                    val[n] = ops.conv2d_nhwc(val[br.inputs[0]], pk[br.name], pbias[br.name], br.attrs["stride"],
                                              br.attrs["padding"], True, out=out, accumulate=True)
             elif n.op == "dropout":
                 x = val[n.inputs[0]]
@@ -576,8 +600,7 @@ class ResNet50ConvDetTrainer(_TrainerBase):
                 val[n] = ops.scale_mask(x, aux[n], 1.0 / keep)
             elif n.op == "conv":
                 x = val[n.inputs[0]]
-                val[n] = ops.conv2d_nhwc(x, ops.pack_conv_weights(P[n.name + "/kernels"], self.adt), P[n.name + "/biases"],
-                                         n.attrs["stride"], n.attrs["padding"], n.attrs["relu"])
+                val[n] = ops.conv2d_nhwc(x, pk[n.name], P[n.name + "/biases"], n.attrs["stride"], n.attrs["padding"], n.attrs["relu"])
             else:
                 raise SqdetError("ResNet50ConvDetTrainer: unsupported op %s in the trainable region" % n.op)
         preds = val[m.preds]
@@ -586,6 +609,20 @@ class ResNet50ConvDetTrainer(_TrainerBase):
         self.flat_grads.zero_()
         g = {m.preds: g0}
         gs = 1.0 / self.loss_scale
+        # weight gradients: partial slabs per conv, ONE reduction (ops.WgradPlan; the folded gradients of the conv_bn convs
+        # land in self.dwf / self.dbf), then ONE fold backward; the first step of an input shape runs the per-conv
+        # two-launch gradient and records what the plan needs
+        wkey = tuple(int(v) for v in xb.shape)
+        wplan = self._wplans.get(wkey)
+        witems = []
+
+        def wg(n, xt, gt, k, cin, cout):
+            dw, db = (self.dwf[n.name], self.dbf[n.name]) if n.op == "conv_bn" else (self.gview[n.name + "/kernels"], self.gview[n.name + "/biases"])
+            if wplan is not None:
+                wplan.partial(n.name, xt, gt)
+                return
+            witems.append((n.name, (int(xt.shape[0]), int(xt.shape[1]), int(xt.shape[2]), cin, cout, k), dw, db, None, 0.0))
+            ops.conv2d_bwd_filter(xt, gt, k, cin, cout, dw=dw, db=db, grad_scale=gs)
 
         def give(node, dy, packed_bwd):
             """d(input) of a stride-1 conv into g[node] (accumulating when the node already has a gradient)."""
@@ -605,9 +642,8 @@ class ResNet50ConvDetTrainer(_TrainerBase):
                     self._before_inplace(gy)
                     ops.relu_bwd(val[n], gy)
                 k, cin, cout = n.attrs["size"], int(x.shape[3]), int(n.shape[3])
-                self._wgrad(lambda x=x, gy=gy, k=k, cin=cin, cout=cout, n=n: ops.conv2d_bwd_filter(
-                    x, gy, k, cin, cout, dw=self.gview[n.name + "/kernels"], db=self.gview[n.name + "/biases"], grad_scale=gs), gy, x)
-                give(n.inputs[0], gy, ops.PackedConvBwd(P[n.name + "/kernels"], self.adt))
+                self._wgrad(lambda x=x, gy=gy, k=k, cin=cin, cout=cout, n=n: wg(n, x, gy, k, cin, cout), gy, x)
+                give(n.inputs[0], gy, self.packplan.bwd.get(n.name))
             elif n.op == "dropout":
                 g[n.inputs[0]] = ops.scale_mask(gy, aux[n], 1.0 / n.attrs["keep_prob"])
             elif n.op == "add_relu":
@@ -628,15 +664,15 @@ class ResNet50ConvDetTrainer(_TrainerBase):
                     if k != 1 or n.inputs[0] is not self.boundary:
                         raise SqdetError("ResNet50ConvDetTrainer: strided conv %s needs an input gradient" % n.name)
                     x = ops.subsample_nhwc(x, stride)
-                def bn_wgrad(x=x, gy=gy, k=k, cin=cin, cout=cout, n=n):
-                    dwf, dbf = ops.conv2d_bwd_filter(x, gy, k, cin, cout, grad_scale=gs)
-                    ops.fold_batchnorm_bwd(P[n.name + "/kernels"], dwf, dbf, None, P[n.name + "/gamma"], P[n.name + "/mean"],
-                                           P[n.name + "/var"], eps, dw=self.gview[n.name + "/kernels"],
-                                           dgamma=self.gview[n.name + "/gamma"], dbeta=self.gview[n.name + "/beta"])
-                self._wgrad(bn_wgrad, gy, x)
+                self._wgrad(lambda x=x, gy=gy, k=k, cin=cin, cout=cout, n=n: wg(n, x, gy, k, cin, cout), gy, x)
                 if stride == 1:
-                    give(n.inputs[0], gy, ops.PackedConvBwd(aux[n], self.adt))
+                    give(n.inputs[0], gy, self.packplan.bwd.get(n.name))
         self._join_wgrad()
+        if wplan is not None:
+            wplan.reduce(gs)
+        elif self.plan_wgrads:
+            self._wplans[wkey] = ops.WgradPlan(witems)
+        self.foldplan.run()      # d(kernels), d(gamma), d(beta) of every conv_bn conv from its folded gradients: two launches
         out = collections.OrderedDict(class_loss=losses[0], conf_loss=losses[1], bbox_loss=losses[2], ious=ious, preds=preds,
                                       dpreds=dpreds, num_objects=num_objects)
         if keep_activations:     # names as oracle/resnet_oracle.py forward_train's `override`

@@ -166,6 +166,46 @@ def test_fold_batchnorm_backward_and_subsample():
         assert torch.equal(ops.subsample_nhwc(x.to(DEV, dt), 2).cpu(), x.to(dt)[:, ::2, ::2, :])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+def test_pack_plan_folds_batchnorm_and_fold_backward_plan(dtype):
+    """ops.PackPlan with bn (sqdet_conv_pack_many_prepare_bn): the packed kernels and folded biases of many _conv_bn_layer convs
+    in one launch, bitwise fold_batchnorm + the per-kernel packers; ops.FoldBwdPlan (sqdet_fold_batchnorm_bwd_many): bitwise
+    fold_batchnorm_bwd per conv."""
+    from squeezedet_amd import ops
+    g = torch.Generator().manual_seed(23)
+    shapes = [("a", 1, 64, 256), ("b", 3, 64, 64), ("c", 1, 256, 64), ("d", 3, 24, 72), ("plain", 3, 32, 72)]
+    W, bn, fold_items, want = {}, {}, [], {}
+    for name, k, cin, cout in shapes:
+        W[name] = torch.randn(k, k, cin, cout, generator=g).to(DEV)
+        if name != "plain":
+            gamma, beta = (torch.rand(cout, generator=g) + 0.5).to(DEV), torch.randn(cout, generator=g).to(DEV)
+            mean, var = torch.randn(cout, generator=g).to(DEV), (torch.rand(cout, generator=g) + 0.5).to(DEV)
+            bn[name] = (gamma, beta, mean, var, None)
+            dwf, dbf = torch.randn(k, k, cin, cout, generator=g).to(DEV), torch.randn(cout, generator=g).to(DEV)
+            outs = [torch.empty_like(W[name]), torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)]
+            fold_items.append((W[name], dwf, dbf, None, gamma, mean, var) + tuple(outs))
+            want[name] = ops.fold_batchnorm_bwd(W[name], dwf, dbf, None, gamma, mean, var, R.BN_EPS)
+    plan = ops.PackPlan(W, dtype, bwd_names=("a", "b", "c", "plain"), bn=bn, eps=R.BN_EPS)
+    fplan = ops.FoldBwdPlan(fold_items, R.BN_EPS)
+    for _ in range(2):
+        plan.run()
+        fplan.run()
+        torch.cuda.synchronize()
+        for name, k, cin, cout in shapes:
+            if name in bn:
+                wf, bf = ops.fold_batchnorm(W[name], None, bn[name][0], bn[name][1], bn[name][2], bn[name][3], R.BN_EPS)
+                assert torch.equal(plan.bias[name], bf), name
+            else:
+                wf = W[name]
+            assert torch.equal(plan.fwd[name].data, ops.pack_conv_weights(wf, dtype).data), name
+            if name in plan.bwd:
+                assert torch.equal(plan.bwd[name].data, ops.PackedConvBwd(wf, dtype).data), name
+        for it in fold_items:
+            name = [n for n in W if W[n] is it[0]][0]
+            for got, ref in zip(it[7:], want[name]):
+                assert torch.equal(got, ref), name
+
+
 def _trainer(size=(96, 160), batch=2, seed=0, dtype=torch.float32, **kw):
     import squeezedet_amd as S
     from squeezedet_amd import nets
