@@ -358,6 +358,10 @@ int sqdet_relu_bwd(const void* y, void* dy_inout, size_t count, int dtype, sqdet
  * 1/keep_prob; nets/squeezeDet.py:74) and its backward.  x, mask, y share dtype. */
 int sqdet_scale_mask(const void* x, const void* mask, void* y, float scale, size_t count, int dtype,
                      sqdet_stream_t stream);
+/* The same with the ReLU backward of the layer below in the same pass: y = relu_of > 0 ? x * mask * scale : 0 (relu_of: the
+ * ReLU output x is the gradient of -- fire11's output under the dropout in front of conv12). */
+int sqdet_scale_mask_relu(const void* x, const void* mask, const void* relu_of, void* y, float scale, size_t count, int dtype,
+                          sqdet_stream_t stream);
 /* dst[i] = (dst_dtype)(src[i] * scale): the float16 <-> float32 hand-offs of mixed-precision training (float16
  * preds -> the float32 loss kernel; its float32 dpreds * loss_scale -> float16).  count a multiple of 4. */
 int sqdet_convert_scale(const void* src, int src_dtype, void* dst, int dst_dtype, float scale, size_t count,
@@ -398,6 +402,17 @@ int sqdet_loss_fwd_bwd_dev(const float* preds, const float* anchors, const float
                            float* workspace, int batch, int gh, int gw, int apg, int classes, float img_w, float img_h,
                            float exp_thresh, float epsilon, float coef_class, float coef_conf_pos, float coef_conf_neg,
                            float coef_bbox, const float* num_objects_dev, int global_batch, sqdet_stream_t stream);
+
+/* Mixed-precision form: preds are FLOAT16 (read as their float32 values) and, beside the float32 dpreds, the loss-scaled
+ * float16 gradient the float16 backward starts from is written in the same pass -- (float16)(dpreds * loss_scale), the
+ * expression of sqdet_convert_scale -- instead of a conversion launch either side of the loss.  num_objects_dev != NULL:
+ * the count is read from the device (num_objects ignored). */
+int sqdet_loss_fwd_bwd_mixed(const void* preds_f16, const float* anchors, const float* input_mask, const float* box_delta_input,
+                             const float* box_input, const float* labels, float* dpreds, void* dpreds_scaled_f16,
+                             float loss_scale, float* ious, float* losses3, float* workspace, int batch, int gh, int gw, int apg,
+                             int classes, float img_w, float img_h, float exp_thresh, float epsilon, float coef_class,
+                             float coef_conf_pos, float coef_conf_neg, float coef_bbox, float num_objects,
+                             const float* num_objects_dev, int global_batch, sqdet_stream_t stream);
 /* out[0] = sum(x[0..count)) in a fixed order (deterministic): tf.reduce_sum(self.input_mask), nn_skeleton.py:180. */
 int sqdet_sum_f32(const float* x, size_t count, float* out, sqdet_stream_t stream);
 /* y = max(a + b, 0): tf.nn.relu(shortcut + branch) (nets/resnet50_convDet.py:55) where the producing conv could not take

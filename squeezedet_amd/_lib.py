@@ -78,11 +78,13 @@ SIGNATURES = {
     "sqdet_relu_bwd": (ci, [vp, vp, sz, ci, vp]),
     "sqdet_convert_scale": (ci, [vp, ci, vp, ci, cf, sz, vp]),
     "sqdet_scale_mask": (ci, [vp, vp, vp, cf, sz, ci, vp]),
+    "sqdet_scale_mask_relu": (ci, [vp, vp, vp, vp, cf, sz, ci, vp]),
     "sqdet_maxpool_nhwc_bwd": (ci, [vp, vp, vp] + [ci] * 8 + [vp]),
     "sqdet_maxpool_nhwc_bwd_relu": (ci, [vp, vp, vp] + [ci] * 8 + [vp]),
     "sqdet_loss_workspace_bytes": (sz, []),
     "sqdet_loss_fwd_bwd": (ci, [vp] * 10 + [ci] * 5 + [cf] * 9 + [ci, vp]),
     "sqdet_loss_fwd_bwd_dev": (ci, [vp] * 10 + [ci] * 5 + [cf] * 8 + [vp, ci, vp]),
+    "sqdet_loss_fwd_bwd_mixed": (ci, [vp] * 8 + [cf] + [vp] * 3 + [ci] * 5 + [cf] * 9 + [vp, ci, vp]),
     "sqdet_sum_f32": (ci, [vp, sz, vp, vp]),
     "sqdet_add_relu": (ci, [vp, vp, vp, sz, ci, vp]),
     "sqdet_copy_channels": (ci, [vp, vp, sz, ci, ci, ci, ci, vp]),

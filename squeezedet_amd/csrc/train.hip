@@ -152,6 +152,27 @@ __global__ void scale_mask_kernel(const T* __restrict__ x, const T* __restrict__
   }
 }
 
+// the same followed by the ReLU backward of the tensor x is the gradient of (relu_of = that ReLU's output): the dropout
+// backward in front of conv12 and fire11's ReLU backward in one pass
+template <typename T>
+__global__ void scale_mask_relu_kernel(const T* __restrict__ x, const T* __restrict__ mask, const T* __restrict__ relu_of,
+                                       T* __restrict__ y, float scale, size_t nv) {
+  typedef typename Vec16<T>::type V;
+  constexpr int EV = 16 / sizeof(T);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+    const V v = reinterpret_cast<const V*>(x)[i];
+    const V m = reinterpret_cast<const V*>(mask)[i];
+    const V r = reinterpret_cast<const V*>(relu_of)[i];
+    V o;
+#pragma unroll
+    for (int e = 0; e < EV; ++e) {
+      const T t = (T)((float)v[e] * (float)m[e] * scale);
+      o[e] = r[e] > (T)0 ? t : (T)0;
+    }
+    reinterpret_cast<V*>(y)[i] = o;
+  }
+}
+
 // dst = (D)(src * scale): the float16 <-> float32 hand-offs of mixed-precision training (preds -> loss, dpreds * loss_scale)
 template <typename S, typename D>
 __global__ void convert_scale_kernel(const S* __restrict__ src, D* __restrict__ dst, float scale, size_t n4) {
@@ -379,13 +400,16 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict_
 
 // ------------------------------------------------------------------ loss forward + backward
 struct LossArgs {
-  const float* preds;      // [B, cells, K*(C+5)]
+  const void* preds;       // [B, cells, K*(C+5)], float32 or (mixed-precision form) float16
   const float* anchors;    // [A,4] float32
   const float* mask;       // [B,A]
   const float* delta_in;   // [B,A,4]
   const float* box_in;     // [B,A,4] (cx,cy,w,h)
   const float* labels;     // [B,A,C]
   float* dpreds;           // [B, cells, K*(C+5)]
+  f16* g16;                // mixed-precision form: (float16)(dpreds * gscale), the gradient the float16 backward starts from
+  float gscale;            // (the loss scale)
+  float* losses3;
   float* ious;             // [B,A]
   float* partial;          // [blocks][4]: class, conf, bbox loss partial sums (+ unused)
   int B, cells, K, C;
@@ -397,6 +421,7 @@ struct LossArgs {
   const float* num_obj_dev;   // ... or, when not NULL, read from the device (sqdet_sum_f32 of the mask: no host round trip)
 };
 
+template <typename PT>
 __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
   const float nobj = a.num_obj_dev ? a.num_obj_dev[0] : a.num_obj;
   __shared__ float red[3][256];
@@ -408,34 +433,41 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
     const int b = (int)(idx / A);
     const int an = (int)(idx - (long)b * A);
     const int cell = an / a.K, k = an - cell * a.K;
-    const float* p = a.preds + ((size_t)b * a.cells + cell) * ch;
+    const PT* p = reinterpret_cast<const PT*>(a.preds) + ((size_t)b * a.cells + cell) * ch;
     float* dp = a.dpreds + ((size_t)b * a.cells + cell) * ch;
+    f16* gp = a.g16 ? a.g16 + ((size_t)b * a.cells + cell) * ch : nullptr;
+    // float32 dpreds, and -- mixed precision -- its loss-scaled float16 copy (convert_scale_kernel's expression) in the same pass
+    auto put = [&](int off, float v) {
+      dp[off] = v;
+      if (sizeof(PT) == 2) gp[off] = (f16)(v * a.gscale);
+    };
     const float m = a.mask[idx];
     // class probabilities (softmax) and their loss (nn_skeleton.py:150-160, 292-299)
-    const float* lg = p + k * a.C;
-    float mx = lg[0];
-    for (int c = 1; c < a.C; ++c) mx = fmaxf(mx, lg[c]);
-    float sum = expf(lg[0] - mx);
-    for (int c = 1; c < a.C; ++c) sum = sum + expf(lg[c] - mx);
+    const PT* lg = p + k * a.C;
+    float mx = (float)lg[0];
+    for (int c = 1; c < a.C; ++c) mx = fmaxf(mx, (float)lg[c]);
+    float sum = expf((float)lg[0] - mx);
+    for (int c = 1; c < a.C; ++c) sum = sum + expf((float)lg[c] - mx);
     const float inv = 1.0f / sum;
     float gdotp = 0.f;
     for (int c = 0; c < a.C; ++c) {
-      const float pc = expf(lg[c] - mx) * inv;
+      const float pc = expf((float)lg[c] - mx) * inv;
       const float lab = a.labels[idx * a.C + c];
       l_class += (lab * (-logf(pc + a.eps)) + (1.0f - lab) * (-logf(1.0f - pc + a.eps))) * m * a.coef_class;
       const float gc = m * a.coef_class / nobj * (-lab / (pc + a.eps) + (1.0f - lab) / (1.0f - pc + a.eps));
       gdotp += gc * pc;
     }
     for (int c = 0; c < a.C; ++c) {
-      const float pc = expf(lg[c] - mx) * inv;
+      const float pc = expf((float)lg[c] - mx) * inv;
       const float lab = a.labels[idx * a.C + c];
       const float gc = m * a.coef_class / nobj * (-lab / (pc + a.eps) + (1.0f - lab) / (1.0f - pc + a.eps));
-      dp[k * a.C + c] = pc * (gc - gdotp);
+      put(k * a.C + c, pc * (gc - gdotp));
     }
     // decode (as interpret_output) -> IoU with the ground-truth box (nn_skeleton.py:240-269)
-    const float zc = p[a.K * a.C + k];
+    const float zc = (float)p[a.K * a.C + k];
     const float conf = 1.0f / (1.0f + expf(-zc));
-    const float* dl = p + a.K * (a.C + 1) + 4 * k;
+    const PT* dlp = p + a.K * (a.C + 1) + 4 * k;
+    const float dl[4] = {(float)dlp[0], (float)dlp[1], (float)dlp[2], (float)dlp[3]};
     const f32x4 anc = *reinterpret_cast<const f32x4*>(a.anchors + (size_t)an * 4);
     const float cx = anc[0] + dl[0] * anc[2];
     const float cy = anc[1] + dl[1] * anc[3];
@@ -460,12 +492,12 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
     const float wgt = m * a.coef_pos / nobj + (1.0f - m) * a.coef_neg / ((float)A - nobj);
     const float dc = iou - conf;
     l_conf += dc * dc * wgt / (float)a.Bmean;
-    dp[a.K * a.C + k] = 2.0f * (conf - iou) * wgt / (float)a.Bmean * conf * (1.0f - conf);
+    put(a.K * a.C + k, 2.0f * (conf - iou) * wgt / (float)a.Bmean * conf * (1.0f - conf));
     // bbox loss (:317-323)
     for (int d = 0; d < 4; ++d) {
       const float df = m * (dl[d] - a.delta_in[idx * 4 + d]);
       l_bbox += a.coef_bbox * df * df / nobj;
-      dp[a.K * (a.C + 1) + 4 * k + d] = 2.0f * a.coef_bbox * m * df / nobj;
+      put(a.K * (a.C + 1) + 4 * k + d, 2.0f * a.coef_bbox * m * df / nobj);
     }
   }
   l_class = l_class / nobj;
@@ -480,6 +512,18 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
     __syncthreads();
   }
   if (threadIdx.x < 4) a.partial[blockIdx.x * 4 + threadIdx.x] = threadIdx.x < 3 ? red[threadIdx.x][0] : 0.f;
+}
+
+// losses3[j] = sum over the loss kernel's workgroups of partial[b][j]: wave j of one workgroup, lane l takes b = l, l + 64, ..
+// in ascending order, then a fixed xor tree -- deterministic.  (One thread per output walking up to 512 dependent loads took
+// 40 us, and a device-to-device copy of the three floats followed it.)
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ partial, float* __restrict__ losses3, int blocks) {
+  const int j = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int b = lane; b < blocks; b += 64) s += partial[b * 4 + j];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0 && j < 3) losses3[j] = s;
 }
 
 // ------------------------------------------------------------------ optimizer
@@ -742,6 +786,22 @@ extern "C" int sqdet_scale_mask(const void* x, const void* mask, void* y, float 
   return SQDET_OK;
 }
 
+extern "C" int sqdet_scale_mask_relu(const void* x, const void* mask, const void* relu_of, void* y, float scale, size_t count,
+                                     int dtype, sqdet_stream_t stream) {
+  SQDET_REQUIRE(dtype == SQDET_F16 || dtype == SQDET_F32, "scale_mask_relu: bad dtype");
+  const size_t ev = 16 / dtype_size(dtype);
+  SQDET_REQUIRE(x && mask && relu_of && y && count % ev == 0, "scale_mask_relu: bad arguments (count must be a multiple of 16 bytes)");
+  const dim3 grid(grid_for(count / ev, 8192));
+  if (dtype == SQDET_F16)
+    hipLaunchKernelGGL(scale_mask_relu_kernel<f16>, grid, dim3(256), 0, as_stream(stream), (const f16*)x, (const f16*)mask,
+                       (const f16*)relu_of, (f16*)y, scale, count / ev);
+  else
+    hipLaunchKernelGGL(scale_mask_relu_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)mask,
+                       (const float*)relu_of, (float*)y, scale, count / ev);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
+
 extern "C" int sqdet_convert_scale(const void* src, int src_dtype, void* dst, int dst_dtype, float scale, size_t count,
                                    sqdet_stream_t stream) {
   SQDET_REQUIRE(src && dst && count % 4 == 0, "convert_scale: bad arguments (count must be a multiple of 4)");
@@ -874,12 +934,27 @@ extern "C" int sqdet_dropout_mask(void* mask, size_t count, float keep_prob, uin
   return SQDET_OK;
 }
 
-static int loss_fwd_bwd_impl(const float* preds, const float* anchors, const float* input_mask,
+static int loss_fwd_bwd_impl(const void* preds, const float* anchors, const float* input_mask,
                              const float* box_delta_input, const float* box_input, const float* labels,
                              float* dpreds, float* ious, float* losses3, float* workspace, int batch, int gh, int gw,
                              int apg, int classes, float img_w, float img_h, float exp_thresh, float epsilon,
                              float coef_class, float coef_conf_pos, float coef_conf_neg, float coef_bbox,
-                             float num_objects, const float* num_objects_dev, int global_batch, sqdet_stream_t stream);
+                             float num_objects, const float* num_objects_dev, int global_batch, sqdet_stream_t stream,
+                             void* g16 = nullptr, float gscale = 1.f);
+
+extern "C" int sqdet_loss_fwd_bwd_mixed(const void* preds_f16, const float* anchors, const float* input_mask,
+                                        const float* box_delta_input, const float* box_input, const float* labels,
+                                        float* dpreds, void* dpreds_scaled_f16, float loss_scale, float* ious, float* losses3,
+                                        float* workspace, int batch, int gh, int gw, int apg, int classes, float img_w,
+                                        float img_h, float exp_thresh, float epsilon, float coef_class, float coef_conf_pos,
+                                        float coef_conf_neg, float coef_bbox, float num_objects, const float* num_objects_dev,
+                                        int global_batch, sqdet_stream_t stream) {
+  SQDET_REQUIRE(dpreds_scaled_f16 && loss_scale > 0.f, "loss_fwd_bwd_mixed: bad arguments");
+  return loss_fwd_bwd_impl(preds_f16, anchors, input_mask, box_delta_input, box_input, labels, dpreds, ious, losses3, workspace,
+                           batch, gh, gw, apg, classes, img_w, img_h, exp_thresh, epsilon, coef_class, coef_conf_pos,
+                           coef_conf_neg, coef_bbox, num_objects_dev ? 1.0f : num_objects, num_objects_dev, global_batch, stream,
+                           dpreds_scaled_f16, loss_scale);
+}
 
 extern "C" int sqdet_loss_fwd_bwd_dev(const float* preds, const float* anchors, const float* input_mask,
                                       const float* box_delta_input, const float* box_input, const float* labels,
@@ -904,12 +979,13 @@ extern "C" int sqdet_loss_fwd_bwd(const float* preds, const float* anchors, cons
                            coef_conf_neg, coef_bbox, num_objects, nullptr, global_batch, stream);
 }
 
-static int loss_fwd_bwd_impl(const float* preds, const float* anchors, const float* input_mask,
+static int loss_fwd_bwd_impl(const void* preds, const float* anchors, const float* input_mask,
                                   const float* box_delta_input, const float* box_input, const float* labels,
                                   float* dpreds, float* ious, float* losses3, float* workspace, int batch, int gh, int gw,
                                   int apg, int classes, float img_w, float img_h, float exp_thresh, float epsilon,
                                   float coef_class, float coef_conf_pos, float coef_conf_neg, float coef_bbox,
-                                  float num_objects, const float* num_objects_dev, int global_batch, sqdet_stream_t stream) {
+                                  float num_objects, const float* num_objects_dev, int global_batch, sqdet_stream_t stream,
+                                  void* g16, float gscale) {
   SQDET_REQUIRE(preds && anchors && input_mask && box_delta_input && box_input && labels && dpreds && ious && losses3 &&
                     workspace, "loss_fwd_bwd: null pointer");
   SQDET_REQUIRE(batch > 0 && gh > 0 && gw > 0 && apg > 0 && classes > 0 && num_objects > 0.f, "loss_fwd_bwd: bad arguments");
@@ -917,6 +993,7 @@ static int loss_fwd_bwd_impl(const float* preds, const float* anchors, const flo
   LossArgs a;
   a.preds = preds; a.anchors = anchors; a.mask = input_mask; a.delta_in = box_delta_input; a.box_in = box_input;
   a.labels = labels; a.dpreds = dpreds; a.ious = ious; a.partial = workspace;
+  a.g16 = static_cast<f16*>(g16); a.gscale = gscale; a.losses3 = losses3;
   a.B = batch; a.Bmean = global_batch > 0 ? global_batch : batch; a.cells = gh * gw; a.K = apg; a.C = classes;
   a.w1 = img_w - 1.0f; a.h1 = img_h - 1.0f; a.thr = exp_thresh; a.slope = (float)exp((double)exp_thresh); a.eps = epsilon;
   a.coef_class = coef_class; a.coef_pos = coef_conf_pos; a.coef_neg = coef_conf_neg; a.coef_bbox = coef_bbox;
@@ -926,13 +1003,11 @@ static int loss_fwd_bwd_impl(const float* preds, const float* anchors, const flo
   int blocks = (int)((total + 255) / 256);
   if (blocks > 512) blocks = 512;
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(loss_kernel, dim3(blocks), dim3(256), 0, st, a);
+  if (g16) hipLaunchKernelGGL(loss_kernel<f16>, dim3(blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(loss_kernel<float>, dim3(blocks), dim3(256), 0, st, a);
   SQDET_CHECK_HIP(hipGetLastError());
-  // losses3[j] = sum over blocks of partial[b][j], fixed order; partial is [blocks][4] -> treat as 4 x strided slabs
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(1), dim3(256), 0, st, workspace, workspace + 4 * 512, (const float*)nullptr, 0.f,
-                     (size_t)4, blocks);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, workspace, losses3, blocks);
   SQDET_CHECK_HIP(hipGetLastError());
-  SQDET_CHECK_HIP(hipMemcpyAsync(losses3, workspace + 4 * 512, 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
   return SQDET_OK;
 }
 

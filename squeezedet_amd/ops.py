@@ -610,8 +610,16 @@ def relu_bwd(y, dy):
     return dy
 
 
-def scale_mask(x, mask, scale):
+def scale_mask(x, mask, scale, relu_of=None):
+    """x * mask * scale (tf.nn.dropout and its backward); relu_of: also zeroed where that ReLU output is <= 0 (the ReLU
+    backward of the layer x is the gradient of, sqdet_scale_mask_relu)."""
     y = torch.empty_like(x)
+    if relu_of is not None:
+        if tuple(relu_of.shape) != tuple(x.shape):
+            raise _lib.SqdetError("scale_mask: relu_of must be shaped like x")
+        check(lib().sqdet_scale_mask_relu(_dev(x, "x"), _dev(mask, "mask", x.dtype), _dev(relu_of, "relu_of", x.dtype), _dev(y, "y"),
+                                          float(scale), x.numel(), dtype_code(x.dtype), stream_ptr()), "sqdet_scale_mask_relu")
+        return y
     check(lib().sqdet_scale_mask(_dev(x, "x"), _dev(mask, "mask", x.dtype), _dev(y, "y"), float(scale), x.numel(),
                                  dtype_code(x.dtype), stream_ptr()), "sqdet_scale_mask")
     return y
@@ -694,6 +702,32 @@ def dropout_mask_into(mask, keep_prob, seed):
     check(lib().sqdet_dropout_mask(_dev(mask, "mask"), int(mask.numel()), float(keep_prob), int(seed) & (2 ** 64 - 1),
                                    dtype_code(mask.dtype), stream_ptr()), "sqdet_dropout_mask")
     return mask
+
+
+def loss_fwd_bwd_mixed(preds, anchors_f32, input_mask, box_delta_input, box_input, labels, mc, num_objects, loss_scale, global_batch=0):
+    """loss_fwd_bwd on FLOAT16 preds (sqdet_loss_fwd_bwd_mixed): also returns the loss-scaled float16 gradient the float16
+    backward starts from -- bitwise convert_scale(dpreds, float16, loss_scale) -- written in the same pass.
+    Returns (g16, dpreds float32, ious, losses)."""
+    n, gh, gw, ch = [int(v) for v in preds.shape]
+    A = gh * gw * mc.ANCHOR_PER_GRID
+    dev = preds.device
+    dpreds = torch.empty(preds.shape, dtype=torch.float32, device=dev)
+    g16 = torch.empty_like(preds)
+    ious = torch.empty((n, A), dtype=torch.float32, device=dev)
+    losses = torch.empty((3,), dtype=torch.float32, device=dev)
+    ws = torch.empty(int(lib().sqdet_loss_workspace_bytes()) // 4 + 16, dtype=torch.float32, device=dev)
+    on_dev = isinstance(num_objects, torch.Tensor)
+    check(lib().sqdet_loss_fwd_bwd_mixed(_dev(preds, "preds", torch.float16), _dev(anchors_f32, "anchors", torch.float32),
+                                         _dev(input_mask, "mask", torch.float32), _dev(box_delta_input, "delta", torch.float32),
+                                         _dev(box_input, "box", torch.float32), _dev(labels, "labels", torch.float32),
+                                         _dev(dpreds, "dpreds"), _dev(g16, "g16"), float(loss_scale), _dev(ious, "ious"),
+                                         _dev(losses, "losses"), _dev(ws, "ws"), n, gh, gw, int(mc.ANCHOR_PER_GRID), int(mc.CLASSES),
+                                         float(mc.IMAGE_WIDTH), float(mc.IMAGE_HEIGHT), float(mc.EXP_THRESH), float(mc.EPSILON),
+                                         float(mc.LOSS_COEF_CLASS), float(mc.LOSS_COEF_CONF_POS), float(mc.LOSS_COEF_CONF_NEG),
+                                         float(mc.LOSS_COEF_BBOX), 1.0 if on_dev else float(num_objects),
+                                         _dev(num_objects, "num_objects", torch.float32) if on_dev else None, int(global_batch),
+                                         stream_ptr()), "sqdet_loss_fwd_bwd_mixed")
+    return g16, dpreds, ious, losses
 
 
 def loss_fwd_bwd(preds, anchors_f32, input_mask, box_delta_input, box_input, labels, mc, num_objects, global_batch=0):

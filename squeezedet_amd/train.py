@@ -147,6 +147,25 @@ class _TrainerBase:
             fn()
         self._wg_keep.extend(reads)
 
+    def fork_labels(self, build):
+        """Runs build() -- the label construction of a step: a handful of small latency-bound launches nothing in the forward
+        depends on -- on the side stream, beside the forward; forward_backward joins it ahead of the loss.  Everything build()
+        returns must be produced there (pass num_objects in: _labels would sum the mask on the main stream)."""
+        if not self.overlap_wgrad:
+            return build()
+        if self._wg_stream is None:
+            self._wg_stream = torch.cuda.Stream(device=self.dev)
+        self._wg_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._wg_stream):
+            out = build()
+        self._labels_forked = True
+        return out
+
+    def _join_labels(self):
+        if getattr(self, "_labels_forked", False):
+            torch.cuda.current_stream().wait_stream(self._wg_stream)
+            self._labels_forked = False
+
     def _before_inplace(self, t):
         """The caller is about to write `t` in place on its stream: if a pending side-stream weight gradient reads it, wait for
         the side stream first (ResNet's residual gradients are shared by the branch and the shortcut and accumulated into)."""
@@ -192,13 +211,13 @@ class _TrainerBase:
     def _loss(self, preds, mask, delta, box, lab, num_objects):
         """Loss forward + backward in float32; returns (gradient w.r.t. preds in the activation dtype -- times
         loss_scale in float16 mode --, float32 dpreds, ious, losses)."""
-        p32 = ops.convert_scale(preds, torch.float32) if self.half else preds
         # global_num_objects: this replica's loss is its share of ONE graph of batch world*B -- the confidence term's
         # reduce_mean over the batch (nn_skeleton.py:304-312) divides by the global batch too; the bucket is then SUMMED
         gb, _ = step_normalisation(self.global_num_objects, int(preds.shape[0]), self.world)
-        dpreds, ious, losses = ops.loss_fwd_bwd(p32, self.model.anchors_f32(), mask, delta, box, lab, self.mc, num_objects, global_batch=gb)
-        g = ops.convert_scale(dpreds, torch.float16, self.loss_scale) if self.half else dpreds
-        return g, dpreds, ious, losses
+        if self.half:     # float16 preds in, float32 dpreds + its loss-scaled float16 copy out: one launch, no conversions around it
+            return ops.loss_fwd_bwd_mixed(preds, self.model.anchors_f32(), mask, delta, box, lab, self.mc, num_objects, self.loss_scale, global_batch=gb)
+        dpreds, ious, losses = ops.loss_fwd_bwd(preds, self.model.anchors_f32(), mask, delta, box, lab, self.mc, num_objects, global_batch=gb)
+        return dpreds, dpreds, ious, losses
 
     def _finish_step(self, apply_update):
         """Gradient all-reduce (the one collective) + clipped Momentum update on the flat buffers."""
@@ -404,6 +423,7 @@ class SqueezeDetTrainer(_TrainerBase):
                 cur = y
         preds = cur
         # ---------------- loss ----------------
+        self._join_labels()
         g, dpreds, ious, losses = self._loss(preds, mask, delta, box, lab, num_objects)
         # ---------------- backward ----------------
         self.flat_grads.zero_()
@@ -459,7 +479,8 @@ class SqueezeDetTrainer(_TrainerBase):
                 if need_dx:
                     if name == "conv12" and keep != 1.0:
                         g = ops.conv2d_bwd_data(g, bwd(name))
-                        g = ops.scale_mask(g, dm, 1.0 / keep)
+                        g = ops.scale_mask(g, dm, 1.0 / keep, relu_of=below)      # dropout backward (+ the ReLU backward below it)
+                        masked = below is not None
                     else:
                         g = ops.conv2d_bwd_data(g, bwd(name), relu_of=below)
                         masked = below is not None
@@ -604,6 +625,7 @@ class ResNet50ConvDetTrainer(_TrainerBase):
             else:
                 raise SqdetError("ResNet50ConvDetTrainer: unsupported op %s in the trainable region" % n.op)
         preds = val[m.preds]
+        self._join_labels()
         g0, dpreds, ious, losses = self._loss(preds, mask, delta, box, lab, num_objects)
         # ---------------- backward ----------------
         self.flat_grads.zero_()
@@ -710,9 +732,14 @@ class GraphedStep:
         self.eager_nobj = tr.global_num_objects and tr.world > 1
         if self.eager_nobj:
             st["nobj"] = torch.ones(1, dtype=torch.float32, device=tr.dev)
-        run = lambda: tr.forward_backward(st["x"], *ops.build_labels(self.anchors, st["gt"], st["gcls"], st["gcnt"], self.classes)[:4],
-                                          dropout_mask=st["mask"] if keep != 1.0 else None,
-                                          num_objects=st.get("nobj"), num_objects_is_global=self.eager_nobj)
+        def build():       # label build + num_objects = sum(input_mask): on the trainer's side stream, beside the forward
+            lab = ops.build_labels(self.anchors, st["gt"], st["gcls"], st["gcnt"], self.classes)[:4]
+            return lab, (st["nobj"] if self.eager_nobj else ops.sum_f32(lab[0].reshape(int(x.shape[0]), -1)))
+
+        def run():
+            lab, nobj = tr.fork_labels(build)
+            return tr.forward_backward(st["x"], *lab, dropout_mask=st["mask"] if keep != 1.0 else None,
+                                       num_objects=nobj, num_objects_is_global=self.eager_nobj)
         side = torch.cuda.Stream(device=tr.dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -239,6 +239,10 @@ def test_float16_elementwise_backward_ops():
     np.testing.assert_array_equal(got.cpu().numpy(), (dy * (y > 0)).numpy())
     m = torch.from_numpy((rs.uniform(size=(2, 9, 11, 16)) < 0.5).astype(np.float32)).half()
     np.testing.assert_array_equal(ops.scale_mask(dy.to(DEV), m.to(DEV), 2.0).cpu().numpy(), (dy.float() * m.float() * 2.0).half().numpy())
+    # dropout backward + the ReLU backward below it in one pass (sqdet_scale_mask_relu) = the two launches
+    for dt in (torch.float16, torch.float32):
+        a, b, c = dy.to(DEV, dt), m.to(DEV, dt), y.to(DEV, dt)
+        assert torch.equal(ops.scale_mask(a, b, 2.0, relu_of=c), ops.relu_bwd(c, ops.scale_mask(a, b, 2.0)))
     for (H, W, pad) in ((47, 156, "SAME"), (20, 31, "VALID")):
         # distinct float16 values per channel so the argmax is unique
         bits = np.stack([rs.permutation(H * W) for _ in range(8)], -1).reshape(1, H, W, 8) + 0x2000
@@ -316,6 +320,28 @@ def test_loss_forward_backward_vs_oracle():
     np.testing.assert_allclose(ls, [float(parts["class_loss"]), float(parts["conf_loss"]), float(parts["bbox_loss"])], rtol=2e-5)
     np.testing.assert_allclose(ious.cpu().numpy(), parts["ious"].numpy(), rtol=1e-5, atol=1e-6)
     _close(dp, dref, rel=5e-5, what="dpreds")
+
+
+def test_mixed_precision_loss_one_launch_equals_convert_loss_convert():
+    """sqdet_loss_fwd_bwd_mixed (float16 preds in; float32 dpreds and the loss-scaled float16 gradient out) against
+    convert_scale -> sqdet_loss_fwd_bwd_dev -> convert_scale: bitwise, num_objects from the host or from the device."""
+    ops = _ops()
+    mc = O.squeezeDet_config_for_input(128, 256)
+    B = 3
+    rs = np.random.RandomState(15)
+    gh, gw = O.squeezedet_grid(128, 256)
+    preds = torch.from_numpy((rs.randn(B, gh, gw, 72) * 1.2).astype(np.float32)).to(DEV, torch.float16)
+    mask, delta, box, labels = TO.synthetic_labels(mc, B, seed=16)
+    anchors = torch.from_numpy(mc.ANCHOR_BOX.astype(np.float32)).to(DEV)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    args = (anchors, t(mask.reshape(B, -1)), t(delta), t(box), t(labels), mc)
+    for nobj in (float(mask.sum()), torch.full((1,), float(mask.sum()), device=DEV)):
+        dp, ious, losses = ops.loss_fwd_bwd(ops.convert_scale(preds, torch.float32), *args, nobj, global_batch=2 * B)
+        want = ops.convert_scale(dp, torch.float16, 512.0)
+        g16, dp2, ious2, losses2 = ops.loss_fwd_bwd_mixed(preds, *args, nobj, 512.0, global_batch=2 * B)
+        torch.cuda.synchronize()
+        assert g16.dtype == torch.float16 and torch.equal(g16, want)
+        assert torch.equal(dp2, dp) and torch.equal(ious2, ious) and torch.equal(losses2, losses)
 
 
 def test_loss_two_replica_shares_sum_to_the_full_batch_graph():
