@@ -633,6 +633,39 @@ def test_training_step_from_gpu_built_labels():
     assert float(out["num_objects"]) == 6.0 and np.isfinite(float(out["bbox_loss"]))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+def test_graphed_step_equals_the_eager_step(dtype):
+    """train.GraphedStep (label build on the side stream, forward, loss, backward captured as one hipGraph; all-reduce + update
+    eager) against trainer.step on device-built labels: four steps from the same start -- dropout masks from the same
+    counter stream -- leave bit-identical variables, momentum and reported losses."""
+    from squeezedet_amd.train import GraphedStep
+    ops = _ops()
+    omc = O.squeezeDet_config_for_input(128, 256)
+    rs = np.random.RandomState(31)
+    B, M = 2, 5
+    gt = torch.from_numpy(np.stack([rs.uniform(0, 256, (B, M)), rs.uniform(0, 128, (B, M)), rs.uniform(20, 120, (B, M)),
+                                    rs.uniform(20, 90, (B, M))], 2)).to(DEV)
+    cls = torch.from_numpy(rs.randint(0, 3, (B, M)).astype(np.int32)).to(DEV)
+    cnt = torch.from_numpy(np.array([5, 3], np.int32)).to(DEV)
+    xs = [O.synthetic_images(B, 128, 256, seed=60 + i).to(DEV, dtype) for i in range(4)]
+    res = []
+    for graphed in (False, True):
+        tr, mc, params = _trainer(seed=9, dtype=dtype)
+        tr.seed = 1234
+        gs = GraphedStep(tr, torch.from_numpy(omc.ANCHOR_BOX).to(DEV), 3) if graphed else None
+        losses = []
+        for x in xs:
+            if graphed:
+                out = gs.step(x, gt, cls, cnt)
+            else:
+                out = tr.step(x, *ops.build_labels(omc.ANCHOR_BOX, gt, cls, cnt, 3, device=DEV)[:4])
+            losses.append([float(out[k]) for k in ("class_loss", "conf_loss", "bbox_loss")])
+        torch.cuda.synchronize()
+        res.append((tr.flat_params.clone(), tr.flat_accum.clone(), losses))
+    assert res[0][2] == res[1][2]
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 def test_squeezedet_plus_training_step_vs_oracle():
     """The same trainer on SqueezeDet+ (nets/squeezeDetPlus.py:30-79: 7x7/s2 VALID conv1 -- frozen --, VALID pools,
     wider fire modules; train.py --net squeezeDet+) at its full 1242x375 size, batch 1: losses and every gradient
