@@ -228,22 +228,72 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
   i32x4 xr[PF][MB][NCHX];
   bool inimgs[PF][MB];
   unsigned offs[MB];
-  auto prep_loads = [&](int tl, bool tile_ok, bool (&inimg)[MB]) {
-    int b = tl;
-    const int tx = b % a.tiles_x; b /= a.tiles_x;
-    const int ty = b % a.tiles_y;
-    const int n = b / a.tiles_y;
-    const int hy0 = ty * Geo<POOL>::RSTEP - (POOL ? a.ptp : 0) - 1, hx0 = tx * Geo<POOL>::CSTEP - (POOL ? a.plp : 0) - 1;
+  // Tile coordinates are carried, not decoded: a workgroup's tiles are `nl` apart, so (tx, ty, n) advance by the mixed-radix
+  // digits of nl with two carries (~10 scalar instructions; the two divisions of a decode were ~50, twice per tile: the
+  // tile loop's instruction stream -- SQ_INSTS per wave and tile, profiles/r03_sq_counters.txt -- was 30 % scalar).
+  struct TileXY { int tx, ty, n; };
+  auto decode = [&](int t) {
+    TileXY c;
+    c.tx = t % a.tiles_x; t /= a.tiles_x;
+    c.ty = t % a.tiles_y;
+    c.n = t / a.tiles_y;
+    return c;
+  };
+  const TileXY dstride = decode(nl);
+  auto advance = [&](TileXY& c) {
+    c.tx += dstride.tx;
+    const int cy = c.tx >= a.tiles_x ? 1 : 0;
+    c.tx -= cy ? a.tiles_x : 0;
+    c.ty += dstride.ty + cy;
+    const int cn = c.ty >= a.tiles_y ? 1 : 0;
+    c.ty -= cn ? a.tiles_y : 0;
+    c.n += dstride.n + cn;
+  };
+  TileXY cur = decode(tile), pre = cur;     // of `tile` and of the tile PF steps ahead (whose halo prep_loads fetches)
+  // Per-lane, tile-invariant parts of the halo addressing, once per workgroup: relx[mb] = byte offset of this lane's piece of
+  // halo pixel P relative to the halo origin (0x80000000 for a piece that does not exist: base + relx is then out of range,
+  // tensors being < 2 GiB), rcp[mb] = (halo row << 16 | halo column), and -- SQIN -- the LDS address phase A copies the piece to
+  // (a never-read pitch column for pieces that do not exist: the four stores of phase A are unconditional).
+  // (the forms that start from the squeeze tensor only -- the forward plan's: the whole-module forms have no registers to spare)
+  constexpr bool PRE = SQIN;
+  unsigned relx[MB], rcp[MB], ldsoff[MB];
+#pragma unroll
+  for (int mb = 0; mb < (PRE ? MB : 0); ++mb) {
+    const int P = (wave + NWAVES * mb) * 16 + j;
+    const int r = P / (SCOLS + 2), c = P - r * (SCOLS + 2);
+    const bool exists = P < SHP && (!SQIN || g * KG < a.Cin);
+    relx[mb] = exists ? (unsigned)(((r * a.W + c) * a.Cin + g * KG) * (int)sizeof(T)) : OOBL;
+    rcp[mb] = ((unsigned)r << 16) | (unsigned)c;
+    const int PL = P < SHP ? r * LW + c : SCOLS + 4;          // (column 20 of row 0: the LDS pitch is 24, columns 18.. are never read)
+    ldsoff[mb] = (unsigned)(PL * 64 + ((g ^ ((PL >> 1) & 3)) << 4));
+  }
+  auto prep_loads = [&](const TileXY& tc, bool tile_ok, bool (&inimg)[MB]) {
+    const int hy0 = tc.ty * Geo<POOL>::RSTEP - (POOL ? a.ptp : 0) - 1, hx0 = tc.tx * Geo<POOL>::CSTEP - (POOL ? a.plp : 0) - 1;
     // common case (wave-uniform): a real tile whose halo lies inside the image -- no per-pixel bounds tests
     const bool allin = tile_ok && hy0 >= 0 && hy0 + Geo<POOL>::ROWS + 2 <= a.H && hx0 >= 0 && hx0 + SCOLS + 2 <= a.W;
+    if constexpr (!PRE) {
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const int P = (wave + NWAVES * mb) * 16 + j;
-      const int r = P / (SCOLS + 2), c = P - r * (SCOLS + 2);
-      const int iy = hy0 + r, ix = hx0 + c;
-      inimg[mb] = allin || (tile_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W);
-      const unsigned base = (unsigned)((((n * a.H + iy) * a.W + ix) * a.Cin + g * KG) * (int)sizeof(T));
-      offs[mb] = (inimg[mb] && P < SHP && (!SQIN || g * KG < a.Cin)) ? base : OOBL;
+      for (int mb = 0; mb < MB; ++mb) {
+        const int P = (wave + NWAVES * mb) * 16 + j;
+        const int r = P / (SCOLS + 2), c = P - r * (SCOLS + 2);
+        const int iy = hy0 + r, ix = hx0 + c;
+        inimg[mb] = allin || (tile_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W);
+        const unsigned base = (unsigned)((((tc.n * a.H + iy) * a.W + ix) * a.Cin + g * KG) * (int)sizeof(T));
+        offs[mb] = (inimg[mb] && P < SHP && (!SQIN || g * KG < a.Cin)) ? base : OOBL;
+      }
+      return;
+    }
+    const unsigned base = (unsigned)((((tc.n * a.H + hy0) * a.W + hx0) * a.Cin) * (int)sizeof(T));   // (modular when hy0 / hx0 = -1)
+    if (allin) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) { inimg[mb] = true; offs[mb] = base + relx[mb]; }
+    } else {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int iy = hy0 + (int)(rcp[mb] >> 16), ix = hx0 + (int)(rcp[mb] & 0xffffu);
+        inimg[mb] = tile_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        offs[mb] = inimg[mb] ? base + relx[mb] : OOBL;
+      }
     }
   };
   auto issue_loads = [&](int first, int last, i32x4 (&xq)[MB][NCHX]) {   // (Cin fills whole 64-byte chunks: stream_shape)
@@ -258,10 +308,8 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
   auto step = [&](int tile, i32x4 (&xq)[MB][NCHX], bool (&inimg)[MB], unsigned char* sqb) {
     FT_MARK(7);
     // coordinates of THIS tile (all wave-uniform)
-    int b = tile;
-    const int tx = b % a.tiles_x; b /= a.tiles_x;
-    const int ty = b % a.tiles_y;
-    const int n = b / a.tiles_y;
+    if constexpr (!PRE) cur = decode(tile);
+    const int tx = cur.tx, ty = cur.ty, n = cur.n;
     const int oy0 = ty * Geo<POOL>::RSTEP - (POOL ? a.ptp : 0), ox0 = tx * Geo<POOL>::CSTEP - (POOL ? a.plp : 0);
     // the whole halo inside the image (3 tiles out of 4): no SAME-padding select on the squeeze tile
     const bool haloin = oy0 >= 1 && oy0 + Geo<POOL>::ROWS + 1 <= a.H && ox0 >= 1 && ox0 + SCOLS + 1 <= a.W;
@@ -269,14 +317,7 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
     if constexpr (SQIN) {
       // the prefetched pieces ARE the squeeze tile: lane (j, g) holds piece g of halo pixel P
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const int P = (wave + NWAVES * mb) * 16 + j;
-        if (P < SHP) {
-          const int hr = P / (SCOLS + 2);
-          const int PL = hr * LW + (P - hr * (SCOLS + 2));
-          *reinterpret_cast<i32x4*>(sqb + PL * 64 + ((g ^ ((PL >> 1) & 3)) << 4)) = xq[mb][0];
-        }
-      }
+      for (int mb = 0; mb < MB; ++mb) *reinterpret_cast<i32x4*>(sqb + ldsoff[mb]) = xq[mb][0];
       FT_MARK(0);
     } else {
       f32x4 acc[MB][NTS];
@@ -333,7 +374,9 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
     FT_MARK(1);
     // ---------------- prefetch: addresses of the halo of the tile PF steps ahead (its loads go out during phase B,
     // into the registers phase A has just consumed) ----------------
-    prep_loads(tile + PF * nl, tile + PF * nl < band_end, inimg);
+    if constexpr (PRE) { advance(cur); advance(pre); }
+    else pre = decode(tile + PF * nl);
+    prep_loads(pre, tile + PF * nl < band_end, inimg);
     if constexpr (!SPREAD) issue_loads(0, NLOADS, xq);
     FT_MARK(2);
     __syncthreads();
@@ -568,12 +611,15 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
     }
   };
 
-  prep_loads(tile, tile < band_end, inimgs[0]);
+  prep_loads(pre, tile < band_end, inimgs[0]);
   issue_loads(0, NLOADS, xr[0]);
   if constexpr (PF == 2) {
-    prep_loads(tile + nl, tile + nl < band_end, inimgs[1]);
+    if constexpr (PRE) advance(pre);
+    else pre = decode(tile + nl);
+    prep_loads(pre, tile + nl < band_end, inimgs[1]);
     issue_loads(0, NLOADS, xr[1]);
   }
+  // (from here on `pre` is PF - 1 tiles ahead of `cur` at the top of a step and PF ahead once the step has advanced both)
   __syncthreads();                                    // squeeze weights / padding / biases visible
   if constexpr (PF == 1) {
     int buf = 0;
