@@ -267,6 +267,28 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
     const int PL = P < SHP ? r * LW + c : SCOLS + 4;          // (column 20 of row 0: the LDS pitch is 24, columns 18.. are never read)
     ldsoff[mb] = (unsigned)(PL * 64 + ((g ^ ((PL >> 1) & 3)) << 4));
   }
+  // (PRE) the LDS byte offset, inside a squeeze tile, of this lane's B fragment of expand3x3 K-step `tap` at its first row
+  // (load_tap below has the derivation): 5 or 9 registers instead of ~6 VALU instructions per K-step and tile
+  constexpr int NT3P = PAIR ? 5 : 9;
+  unsigned tapoff[NT3P];
+  if constexpr (PRE) {
+    const int m0p = POOL ? (wave % RS) * 2 * (4 / RS) : (wave % RS) * (8 / RS);
+#pragma unroll
+    for (int tap = 0; tap < NT3P; ++tap) {
+      int P0, piece;
+      if constexpr (PAIR) {
+        const int ta = 2 * tap, tb = 2 * tap + 1 < 9 ? 2 * tap + 1 : 8;
+        const int ca = (ta / 3) * LW + ta % 3, cbb = (tb / 3) * LW + tb % 3;
+        P0 = j + (g >= 2 ? cbb : ca);
+        piece = (2 * tap + 1 < 9) ? (g & 1) : g;
+      } else {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        P0 = dy * LW + j + dx;
+        piece = g;
+      }
+      tapoff[tap] = (unsigned)((P0 + LW * m0p) * 64 + ((piece ^ ((P0 >> 1) & 3)) << 4));
+    }
+  }
   auto prep_loads = [&](const TileXY& tc, bool tile_ok, bool (&inimg)[MB]) {
     const int hy0 = tc.ty * Geo<POOL>::RSTEP - (POOL ? a.ptp : 0) - 1, hx0 = tc.tx * Geo<POOL>::CSTEP - (POOL ? a.plp : 0) - 1;
     // common case (wave-uniform): a real tile whose halo lies inside the image -- no per-pixel bounds tests
@@ -509,7 +531,7 @@ __global__ __launch_bounds__(NWAVES * 64, 8 / NWAVES) void fire_stream(FireSArgs
           P0 = dy * LW + jo + dx;
           piece = go;
         }
-        const unsigned char* base = sqb + (P0 + LW * m0) * 64 + ((piece ^ ((P0 >> 1) & 3)) << 4);   // LW*(m0+m)/2 = 0 mod 4
+        const unsigned char* base = PRE ? sqb + tapoff[tap] : sqb + (P0 + LW * m0) * 64 + ((piece ^ ((P0 >> 1) & 3)) << 4);   // LW*(m0+m)/2 = 0 mod 4
 #pragma unroll
         for (int m = 0; m < MT; ++m) bf[m] = *reinterpret_cast<const i32x4*>(base + m * (LW * 64));
       };
