@@ -288,21 +288,23 @@ __global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
       for (int m = 0; m < 4; ++m)
         *reinterpret_cast<i32x4*>(xch + (wave * 4 + m) * 1024 + lane * 16) = bf[m];
       sync(true);
-      i32x4 bo[4];   // the partner's chunk
+      // both K chunks of the block come back from the exchange area in canonical order (u = 0: the h = 0 wave's, u = 1: the
+      // h = 1 wave's) -- this wave's own chunk included: four more 16-byte LDS reads instead of 64 lane-uniform selects
+      // between the registers it still holds and its partner's (h is a run-time scalar)
+      i32x4 bx[2][4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) bo[m] = *reinterpret_cast<const i32x4*>(xch + ((wave ^ 4) * 4 + m) * 1024 + lane * 16);
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) bx[u][m] = *reinterpret_cast<const i32x4*>(xch + ((pg + 4 * u) * 4 + m) * 1024 + lane * 16);
 #pragma unroll
       for (int n = 0; n < 2; ++n) an[n] = lda(nbo, 2 * h + n);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
 #pragma unroll
         for (int i = 0; i < TH; ++i) {
-          if (h * TH + i < NSQ) {
+          if (NSQ % 2 == 0 || h * TH + i < NSQ) {        // (an even NSQ splits evenly over the pair: no test)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-              const i32x4 bv = (u == h) ? bf[m] : bo[m];
-              mma16<T>(accs[i][m], fr[u][i], bv);
-            }
+            for (int m = 0; m < 4; ++m) mma16<T>(accs[i][m], fr[u][i], bx[u][m]);
           }
           if (u == 0 && i == 0) refill();
         }
