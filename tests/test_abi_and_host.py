@@ -49,6 +49,52 @@ def test_argument_validation_returns_codes(lib):
     assert lib.sqdet_conv_packed_bytes(0, 3, 3, 1) == 0
 
 
+def test_many_table_builders_are_host_side(lib):
+    """The `*_prepare` halves of the one-launch-for-many entry points (weight-gradient slab reduction, packing with the batch norm
+    folded, fold backward) are host functions: table sizes, block ranges and argument validation without a device."""
+    n = 3
+    arr = lambda vals, ct: (ct * n)(*vals)
+    fake = lambda k: arr([0x10000 * (k + i + 1) for i in range(n)], C.c_void_p)      # (never dereferenced on the host)
+    nul = arr([None] * n, C.c_void_p)
+    dims = [arr(v, C.c_int) for v in ([20, 20, 8], [24, 47, 24], [78, 156, 78], [768, 32, 1024], [72, 128, 256], [3, 3, 1])]
+    # --- sqdet_slab_reduce_many_prepare
+    tb = lib.sqdet_slab_reduce_many_table_bytes(n)
+    assert tb > 0 and tb % n == 0 and lib.sqdet_slab_reduce_many_table_bytes(0) == 0
+    host, blocks = (C.c_ubyte * tb)(), C.c_int()
+    dec = arr([0.0, 1e-4, 0.0], C.c_float)
+    assert lib.sqdet_slab_reduce_many_prepare(fake(0), fake(10), fake(20), nul, dec, *dims, n, host, C.byref(blocks)) == 0
+    want = 0
+    for i in range(n):
+        cnt = dims[5][i] ** 2 * dims[3][i] * dims[4][i] + dims[4][i]
+        want += min((cnt + 63) // 64, 4096)
+        ws = lib.sqdet_conv2d_bwd_filter_workspace_bytes(*[d[i] for d in dims])
+        assert ws > 0 and ws % (4 * cnt) == 0                     # ksplit whole slabs of k*k*cin*cout + cout floats
+    assert blocks.value == want
+    bad = arr([3, 5, 1], C.c_int)                                  # k = 5 is not a trainable conv of these nets
+    assert lib.sqdet_slab_reduce_many_prepare(fake(0), fake(10), fake(20), nul, dec, *dims[:5], bad, n, host, C.byref(blocks)) == -1
+    # --- sqdet_conv_pack_many_prepare_bn: plain items and folded items in one table
+    tb = lib.sqdet_conv_pack_many_table_bytes(n)
+    host, blocks = (C.c_ubyte * tb)(), C.c_int()
+    ks, cis, cos, bw = dims[5], dims[3], dims[4], arr([0, 1, 0], C.c_int)
+    gam = arr([0x500000, None, 0x510000], C.c_void_p)
+    assert lib.sqdet_conv_pack_many_prepare_bn(fake(0), fake(10), ks, cis, cos, bw, gam, fake(30), fake(40), fake(50), nul, fake(60),
+                                               1e-5, n, _lib.F16, host, C.byref(blocks)) == 0
+    assert blocks.value > 0
+    b2 = C.c_int()
+    assert lib.sqdet_conv_pack_many_prepare(fake(0), fake(10), ks, cis, cos, bw, n, _lib.F16, host, C.byref(b2)) == 0
+    assert b2.value == blocks.value                                 # the fold changes what is written, not the grid
+    # --- sqdet_fold_batchnorm_bwd_many_prepare
+    tb = lib.sqdet_fold_batchnorm_bwd_many_table_bytes(n)
+    host, b1, bf = (C.c_ubyte * tb)(), C.c_int(), C.c_int()
+    assert lib.sqdet_fold_batchnorm_bwd_many_prepare(fake(0), fake(10), fake(20), nul, fake(30), fake(40), fake(50), fake(60), fake(70),
+                                                     fake(80), fake(90), ks, cis, cos, n, host, C.byref(b1), C.byref(bf)) == 0
+    rows = [ks[i] ** 2 * cis[i] for i in range(n)]
+    assert b1.value == sum(((cos[i] + 63) // 64) * ((rows[i] + 31) // 32) for i in range(n))
+    assert bf.value == sum((cos[i] + 255) // 256 for i in range(n))
+    for i in range(n):
+        assert lib.sqdet_fold_batchnorm_bwd_workspace_bytes(ks[i], cis[i], cos[i]) == ((rows[i] + 31) // 32) * cos[i] * 4
+
+
 def test_net_plan_tables_without_gpu(lib):
     """The plan is host-side: parameter table, workspace sizes and the layer table can be
     inspected without a device."""
