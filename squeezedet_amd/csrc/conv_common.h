@@ -88,7 +88,7 @@ __device__ __forceinline__ void store_couts(T* dst, const f32x4 (&v)[NT], int nt
 // 1 = generic only (conv_direct / conv_gather).  Set from SQDET_CONV_ALGO=generic (tests, A/B).
 int conv_algo();
 // experiment knobs set through sqdet_set_option (0 = built-in heuristic)
-// fire_fuse: 0 heuristic, 1 always, 2 never; stem_algo: 0 persistent kernel where eligible, else strip kernel (in-register pool); 2 strip kernel only
+// fire_fuse: 0 heuristic, 1 always, 2 never; stem_algo: 0 phase kernel (stem4.hip), else persistent strip-lane kernel (stem3.hip), else strip kernel (in-register pool), whichever is eligible first; 3 skips the phase kernel; 2 strip kernel only
 enum { TUNE_C1_WAVES = 0, TUNE_C1_MT = 1, TUNE_C1_MIN_TILES = 2, TUNE_FIRE_FUSE = 3, TUNE_STEM_ALGO = 4, TUNE_DBG = 5 };
 int tune(int which);
 

@@ -2,9 +2,10 @@
 // conv1 + pool1 of SqueezeDet (reference src/nets/squeezeDet.py:40-44: 3x3/s2 SAME + pool SAME), SqueezeDet+
 // (src/nets/squeezeDetPlus.py:40-44: 7x7/s2 VALID + pool VALID) and ResNet50 (src/nets/resnet50_convDet.py:41-45: 7x7/s2,
 // 64 couts, pool VALID).  Unfused, conv1 writes 188x621x64 and pool1 reads it back -- 36.4 MB of the 133 MB per image
-// (fp16); fused, the conv activations never leave the CU.  Kernels: stem3.hip (persistent; fp16 3x3), stem4.hip (the same with
-// lane-local pooling over three column phases: opt-in, "stem_algo" 4 -- faster alone, no gain inside the forward) and stem2.hip (strip
-// kernel with the pool in registers; every other shape / dtype).  (The round-1 LDS-conv-tile kernel that lived here -- conv
+// (fp16); fused, the conv activations never leave the CU.  Kernels: stem4.hip (persistent, lane-local pooling over three column
+// phases; fp16 3x3 on images >= 523 wide: the default there since the end of round 3 -- the 32-image step 0.5254 against
+// 0.5305 ms, six alternating runs on two boxes), stem3.hip (persistent, strip lanes + DPP pooling; fp16 3x3 otherwise, or
+// "stem_algo" 3) and stem2.hip (strip kernel with the pool in registers; every other shape / dtype, or "stem_algo" 2).  (The round-1 LDS-conv-tile kernel that lived here -- conv
 // tile written to LDS, pooled from LDS -- was superseded by both and is gone.)
 #include "stem.h"
 
@@ -30,7 +31,7 @@ int stem_launch(const void* x, const void* w_packed, const float* bias, void* y,
   a.y_cstride = y_cstride; a.y_coffset = y_coffset;
   a.ws2 = nullptr; a.bs2 = nullptr; a.s_out = nullptr;
   if (a.Hp <= 0 || a.Wp <= 0) return SQDET_OK;
-  if (tune(TUNE_STEM_ALGO) == 4) {  // "stem_algo" 4: the phase kernel (stem4.hip; wide images only, else the kernels below)
+  if (tune(TUNE_STEM_ALGO) == 0 || tune(TUNE_STEM_ALGO) == 4) {  // the phase kernel (stem4.hip; wide images only, else the kernels below)
     const int rc4 = stem_phase_launch(a, k, dtype, st, handled);
     if (rc4 != SQDET_OK || *handled) return rc4;
   }
@@ -64,7 +65,7 @@ int stem_squeeze_launch(const void* x, const void* w_packed, const float* bias, 
   a.y_cstride = cout; a.y_coffset = 0;
   a.ws2 = ws2_packed; a.bs2 = bs2; a.s_out = s_out;
   if (a.Hp <= 0 || a.Wp <= 0) return SQDET_OK;
-  if (tune(TUNE_STEM_ALGO) == 4) {
+  if (tune(TUNE_STEM_ALGO) == 0 || tune(TUNE_STEM_ALGO) == 4) {
     const int rc4 = stem_phase_launch(a, k, dtype, st, handled);
     if (rc4 != SQDET_OK || *handled) return rc4;
   }

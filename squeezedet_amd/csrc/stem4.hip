@@ -17,8 +17,10 @@
 //
 // Arithmetic per element is stem_pers's (same K order inside the MFMA, max before bias before the one float16 rounding):
 // results are bitwise equal to stem_pers's (tools/exp_stem4.py, tests/test_gpu_ops.py).
-// OPT-IN ("stem_algo" 4): alone it is faster than stem_pers, inside the forward it gains nothing -- the per-launch survey of
-// bench.py reads 59.1 us against 62.5, the 32-image step 0.5402 against 0.5397 ms (two runs each, same box).
+// THE DEFAULT on images >= 523 wide since the end of round 3 ("stem_algo" 3 = stem_pers).  When it was written the 32-image step
+// gained nothing from it (0.5402 against 0.5397 ms, the launch alone 59.1 us against 62.5); with the post-processing riding in
+// the chain launches and the leaner streaming launches behind it, six alternating runs on two boxes read 0.5254 against
+// 0.5305 ms (-1 %).
 // Measured (batch 32, 375x1242, squeeze form, same box, the launch alone): 56.5 us against stem_pers's 61.1; ladder: no stores 52.3, no loads
 // 46.4, neither 43.0 (stem_pers 53.0 / 49.1 / 46.7).  Two workgroups per CU: the three phases' "previous conv row"
 // accumulators (48 registers) + one set in flight + the running maximum + 32 prefetch registers need ~250; the 168-register

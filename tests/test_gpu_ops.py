@@ -778,8 +778,8 @@ PHASE_STEM_CASES = [(2, 375, 1242, "SAME", "SAME"), (1, 384, 1248, "SAME", "SAME
 @pytest.mark.parametrize("sq", [False, True], ids=["plain", "squeeze"])
 @pytest.mark.parametrize("case", PHASE_STEM_CASES, ids=lambda c: "x".join(str(v) for v in c))
 def test_phase_stem_equals_persistent_stem(case, sq):
-    """stem4.hip (opt-in, stem_algo = 4: lane = pooled column, three column phases, lane-local pooling; images >= 523 wide)
-    BITWISE against stem3.hip's persistent strip-lane kernel (the default), plain and squeeze forms: full KITTI sizes,
+    """stem4.hip (the default on images >= 523 wide: lane = pooled column, three column phases, lane-local pooling)
+    BITWISE against stem3.hip's persistent strip-lane kernel (stem_algo = 3), plain and squeeze forms: full KITTI sizes,
     several images, ragged right / bottom tiles, VALID paddings, an image wider than 32 tiles."""
     ops = _ops()
     N, H, W, cpad, ppad = case
@@ -791,10 +791,10 @@ def test_phase_stem_equals_persistent_stem(case, sq):
     bs = torch.from_numpy(rs.uniform(-0.1, 0.1, 16).astype(np.float32)).to(DEV)
     pk, pks = ops.pack_conv_weights(w, torch.float16), ops.pack_conv_weights(ws, torch.float16)
     run = lambda: ops.stem_conv_pool_squeeze(x, pk, b, pks, bs, cpad, ppad) if sq else ops.stem_conv_pool(x, pk, b, cpad, ppad)
-    want = run()
-    ops.set_option("stem_algo", 4)
+    got = run()
+    ops.set_option("stem_algo", 3)
     try:
-        got = run()
+        want = run()
     finally:
         ops.set_option("stem_algo", 0)
     torch.cuda.synchronize()
