@@ -35,6 +35,7 @@ SOURCES = [
     ("stem4.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-honor-nans"]),
     ("fire.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("fire2.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    ("fire3.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     # (-ffp-contract=off: its rider workgroups run filter_body.h's decode / IoU arithmetic, bit-exact by contract)
     ("chain.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-ffp-contract=off"]),
     ("pool.hip", []),

@@ -121,6 +121,10 @@ bool fire_expand_squeeze_next_eligible(int s, int e1, int e3, int s2, int pool, 
 int fire_expand_squeeze_next_launch(const void* sq_in, const void* w1, const float* b1, const void* w3, const float* b3,
                                     const void* ws2, const float* bs2, void* s_out, int n, int h, int w, int s, int e1, int e3,
                                     int s2, int pool, int dtype, hipStream_t st, bool* handled);
+// fire3.hip: the same launch as a DMA-fed kernel sized for four waves per SIMD (SqueezeDet's four shapes)
+int fire_dma_launch(const void* sq_in, const void* w1, const float* b1, const void* w3, const float* b3, const void* ws2,
+                    const float* bs2, void* s_out, int n, int h, int w, int s, int e1, int e3, int s2, int pool, int dtype,
+                    hipStream_t st, bool* handled);
 int conv3x3_tile_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);
 // convdet.hip: the score epilogue's shapes; conv.hip: ConvDet + scores in one launch (sqdet_convdet_fwd)
 bool convdet_score_supported(int cout, int apg, int classes, int dtype);

@@ -831,6 +831,10 @@ int fire_expand_squeeze_next_launch(const void* sq_in, const void* w1, const flo
                                     int s2, int pool, int dtype, hipStream_t st, bool* handled) {
   *handled = false;
   if (!fire_expand_squeeze_next_eligible(s, e1, e3, s2, pool, dtype)) return SQDET_OK;
+  {   // the DMA-fed four-waves-per-SIMD kernel (fire3.hip) takes SqueezeDet's four shapes ("dbg" 70: the forms below)
+    const int rc = fire_dma_launch(sq_in, w1, b1, w3, b3, ws2, bs2, s_out, n, h, w, s, e1, e3, s2, pool, dtype, st, handled);
+    if (rc != SQDET_OK || *handled) return rc;
+  }
   FireSArgs a;
   a.x = sq_in; a.y = nullptr; a.ws = nullptr; a.w1 = w1; a.w3 = w3; a.bs = nullptr; a.b1 = b1; a.b3 = b3;
   a.ws2 = ws2; a.bs2 = bs2; a.s_out = s_out; a.S2 = s2; a.sq_keep = nullptr;
