@@ -75,8 +75,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="run decode + NMS on the forward's stream (no side stream)")
     ap.add_argument("--no-graph", action="store_true", help="training configs: issue the step from Python instead of replaying a hipGraph")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=26.0)
     ap.add_argument("--layer-table", default="", help="write the per-launch table (json) here")
+    ap.add_argument("--opt", action="append", default=[], help="A/B diagnostics: tuning knob name=value (sqdet_set_option), repeatable")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / timing reduction only: gloo on CPU, no kernels")
     a = ap.parse_args(argv)
     c = CONFIGS[a.config]
@@ -222,6 +223,31 @@ def pmc_traffic(config_name, layer):
     return best
 
 
+def rocprof_launch_ms(traffic_profile, layer):
+    """Average duration of `layer`'s kernel in the rocprofv3 --kernel-trace --stats summary committed beside the fingerprinted
+    PMC profile (same collection: profiles/<tag>_kernel_stats.txt next to profiles/<tag>_hbm_traffic_pmc.json), or None.  The
+    summary must carry the same build fingerprint in its header; the layer -> kernel name map is the PMC profile's."""
+    prof = os.path.join(ROOT, "profiles")
+    try:
+        with open(os.path.join(prof, traffic_profile)) as fh:
+            d = json.load(fh)
+        kname = next(k["kernel"] for k in d["kernels"] if k["layer"] == layer)
+        shared = sum(1 for k in d["kernels"] if k["kernel"] == kname)
+        stats = traffic_profile.replace("_hbm_traffic_pmc.json", "_kernel_stats.txt")
+        fp_ok, avg = False, None
+        with open(os.path.join(prof, stats)) as fh:
+            for line in fh:
+                if line.startswith("# build_fingerprint:"):
+                    fp_ok = line.split(":", 1)[1].strip() == d.get("build_fingerprint")
+                elif not line.startswith(("#", "kernel ")) and line[:88].rstrip() == kname[:88].rstrip():
+                    avg = float(line[90:].split()[2]) * 1e-3            # columns: calls, total_us, avg_us, %
+        if not fp_ok or avg is None:
+            return None
+        return {"ms": round(avg, 5), "profile": stats, "kernel_shared_by_launches": shared}
+    except (OSError, ValueError, KeyError, StopIteration, IndexError):
+        return None
+
+
 def rotation_count(batch_bytes):
     """distinct input batches to rotate through: at least 4, and more than the Infinity Cache holds"""
     return max(4, int(np.ceil(1.3 * MALL_BYTES / float(batch_bytes))))
@@ -312,43 +338,66 @@ def cpu_baseline_infer(args, seconds):
         batches = [1, 4]
     prev_threads = torch.get_num_threads()
     O.detect(args.arch, mc, p32, x_all[:1])  # warm-up
-    sweep, best = [], None
+
+    def rate_of(th, nb, min_s):
+        torch.set_num_threads(th)
+        x = x_all[:nb]
+        O.detect(args.arch, mc, p32, x)
+        t0 = time.perf_counter()
+        n = 0
+        while n < 2 * nb or time.perf_counter() - t0 < min_s:
+            O.detect(args.arch, mc, p32, x)
+            n += nb
+        return n / (time.perf_counter() - t0), n
+
+    # 1. a short sweep RANKS the (threads x images per call) candidates (0.4 s each: noisy, used for the ranking only)
+    sweep = []
     t_sweep = time.perf_counter()
     for th in cpu_thread_candidates():
-        torch.set_num_threads(th)
         for nb in batches:
-            x = x_all[:nb]
-            O.detect(args.arch, mc, p32, x)
-            t0 = time.perf_counter()
-            n = 0
-            while n < 2 * nb or time.perf_counter() - t0 < 0.4:
-                O.detect(args.arch, mc, p32, x)
-                n += nb
-            rate = n / (time.perf_counter() - t0)
-            sweep.append({"threads": th, "images_per_call": nb, "images_per_s": round(rate, 2)})
-            if best is None or rate > best[0]:
-                best = (rate, th, nb)
-        if time.perf_counter() - t_sweep > 0.6 * seconds:
+            r, _ = rate_of(th, nb, 0.4)
+            sweep.append({"threads": th, "images_per_call": nb, "images_per_s": round(r, 2)})
+        if time.perf_counter() - t_sweep > 0.3 * seconds:
             break
-    _, th, nb = best
-    torch.set_num_threads(th)
-    x = x_all[:nb]
-    budget = max(2.0, seconds - (time.perf_counter() - t_sweep))
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        O.detect(args.arch, mc, p32, x)
-        n += nb
-        if time.perf_counter() - t0 >= budget:
-            break
-    dt = time.perf_counter() - t0
+    # 2. the two best are measured properly: three runs of >= `per_run` seconds each, the MEDIAN is the candidate's rate (round 3
+    # reported single 0.4-second samples: 20.9-74.3 images/s for one box class); the better median is the baseline
+    ranked = sorted(sweep, key=lambda e: -e["images_per_s"])[:2]
+    per_run = max(3.0, (seconds - (time.perf_counter() - t_sweep)) / (3.0 * len(ranked)))
+    finals = []
+    for e in ranked:
+        runs, imgs = [], 0
+        for _ in range(3):
+            r, n = rate_of(e["threads"], e["images_per_call"], per_run)
+            runs.append(r)
+            imgs += n
+        med = float(np.median(runs))
+        finals.append({"threads": e["threads"], "images_per_call": e["images_per_call"], "runs_images_per_s": [round(r, 2) for r in runs],
+                       "median": round(med, 3), "spread": round((max(runs) - min(runs)) / med, 3), "images": imgs})
+    best = max(finals, key=lambda f: f["median"])
+    th, nb, n = best["threads"], best["images_per_call"], best["images"]
     torch.set_num_threads(prev_threads)
-    return {"value": round(n / dt, 3), "unit": "images/s", "cores": int(th), "kind": "port", "ms_per_image": round(dt / n * 1e3, 2),
-            "sample": "%d %s %dx%d images (%d per call) on the best of a (threads x images-per-call) sweep, fp32: PyTorch-CPU convs "
-                      "with TF SAME padding + NumPy interpret_output + restated filter_prediction; host has %d logical cores, one "
-                      "process; oneDNN is faster than TF-1.0 Eigen, so this over-estimates the reference's own CPU path"
-                      % (n, "copies of sample.png at" if args.sample else "synthetic", args.width, args.height, nb, os.cpu_count()),
-            "sweep": sweep}
+    return {"value": best["median"], "unit": "images/s", "cores": int(th), "kind": "port", "ms_per_image": round(1e3 / best["median"], 2),
+            "spread": best["spread"], "runs": best["runs_images_per_s"],
+            "sample": "%d %s %dx%d images (%d per call): median of three >= %.1f-second runs of the better of the two best "
+                      "(threads x images-per-call) candidates of a ranking sweep, fp32: PyTorch-CPU convs with TF SAME padding + NumPy "
+                      "interpret_output + restated filter_prediction; host has %d logical cores, one process; oneDNN is faster than "
+                      "TF-1.0 Eigen, so this over-estimates the reference's own CPU path"
+                      % (n, "copies of sample.png at" if args.sample else "synthetic", args.width, args.height, nb, per_run, os.cpu_count()),
+            "candidates": finals, "sweep": sweep}
+
+
+def box_calibration(device):
+    """`box_mfma_tflops` / `box_copy_gbs`: a fixed ~1 ms MFMA microkernel and a 1 GiB device copy run right before the timed region
+    (ops.box_calibration -> sqdet_calib_mfma / sqdet_calib_copy).  Round 3 met boxes that ran every MFMA-heavy launch 20-27 % slower
+    while reporting the same clock and power (profiles/r03_slowbox_*): with these two numbers in the line such a box is
+    identifiable from the JSON alone.  SQDET_BENCH_NO_CALIB=1 skips it."""
+    if os.environ.get("SQDET_BENCH_NO_CALIB") == "1":
+        return None
+    from squeezedet_amd import ops
+    try:
+        return ops.box_calibration(device)
+    except Exception as e:  # noqa: BLE001 -- a calibration failure must not void the bench line
+        return {"error": repr(e)[:160]}
 
 
 def spin_up(step, ms, flush=None):
@@ -386,6 +435,13 @@ def run_infer(args, rank, local_rank, world, device):
     model, mc, xs = build_infer_model(args, local_rank)
     plan = model._native_plan(args.batch)
     layers = plan.layer_table()
+    # the benchmarked step runs ConvDet's SCORE form (interpret_output's det_probs written by its epilogue: one float32 per anchor):
+    # those bytes are part of what the launch must write
+    score_epilogue = bool(plan.scores_supported() and os.environ.get("SQDET_SCORE_EPILOGUE") != "0" and not args.no_pipeline)
+    score_bytes = args.batch * plan.gh * plan.gw * mc.ANCHOR_PER_GRID * 4 if score_epilogue else 0
+    if score_bytes:
+        n_, f_, b_ = layers[-1]
+        layers = list(layers[:-1]) + [(n_, f_, b_ + score_bytes)]
     nrot = len(xs)
 
     def step(i):
@@ -414,6 +470,8 @@ def run_infer(args, rank, local_rank, world, device):
         ms0 = [min(a, b) for a, b in zip(ms0, ms)]
     dom = int(np.argmax(ms0))
     spin_up(step, args.spinup_ms, model.flush_pipeline)
+    box = box_calibration(device)                         # ~6 ms of fixed microkernels: what THIS box sustains (untimed)
+    spin_up(step, min(args.spinup_ms, 20.0), model.flush_pipeline)
     if os.environ.get("SQDET_BENCH_NO_PROBE") != "1":     # (A/B knob: what the live event pairs cost the step)
         plan.set_probe(dom, args.steps)
     clocks = {"before": gpu_state(local_rank)}
@@ -449,6 +507,13 @@ def run_infer(args, rank, local_rank, world, device):
     roof["traffic"] = tr[0] if tr else None
     if tr:
         roof["traffic_profile"] = tr[1]
+        # the same launch as rocprofv3's kernel trace timed it in the committed collection of THIS build (the live event pair
+        # below brackets the launch on its stream and reads ~4 us more than the kernel's own duration)
+        rp = rocprof_launch_ms(tr[1], name)
+        roof["rocprof_avg_launch_ms"] = rp["ms"] if rp else None
+        if rp:
+            roof["rocprof_profile"] = rp["profile"]
+            roof["rocprof_frac"] = launch_roofline(flops, nbytes, rp["ms"], args.dtype)["frac"]
     roof["kernel"] = name
     roof["avg_launch_ms"] = round(avg_ms, 5)
     roof["algorithmic_bytes_per_launch"] = nbytes
@@ -472,6 +537,7 @@ def run_infer(args, rank, local_rank, world, device):
                      "name": args.config, "global_batch": args.batch * world,
                      "parallelism": "dp%d (independent image shards, no collective)" % world}
     res["roofline"] = roof
+    res["box"] = box
     res["host_issue_ms_per_step"] = round(t_issued / args.steps * 1e3, 4)
     res["forward_launches_ms_sum"] = round(float(sum(ms0)), 4)
     # diagnostic, outside the timed region: the same K forwards back to back WITHOUT decode / filter / D2H -- what the
@@ -483,7 +549,9 @@ def run_infer(args, rank, local_rank, world, device):
         plan.forward(xs[i % nrot], pre)
     torch.cuda.synchronize()
     res["forward_only_ms_per_step"] = round((time.perf_counter() - t1) / args.steps * 1e3, 4)
-    res["score_epilogue"] = bool(plan.scores_supported() and os.environ.get("SQDET_SCORE_EPILOGUE") != "0" and not args.no_pipeline)
+    res["score_epilogue"] = score_epilogue
+    if score_bytes:
+        res["roofline"]["score_bytes_in_conv12"] = score_bytes
     mode = os.environ.get("SQDET_POST_DEFER", "ride")
     res["post_processing"] = ("riders of the next forward's fire_chain launches (same stream, rows written to pinned host memory)"
                               if res["score_epilogue"] and mode == "ride" and plan.rider_capacity() >= args.batch else
@@ -599,6 +667,8 @@ def run_train(args, rank, local_rank, world, device):
         out = step(i)
     torch.cuda.synchronize()
     spin_up(step, args.spinup_ms)
+    box = box_calibration(device)
+    spin_up(step, min(args.spinup_ms, 20.0))
     clocks = {"before": gpu_state(local_rank)}
     barrier(world, device)
     torch.cuda.synchronize()
@@ -634,6 +704,7 @@ def run_train(args, rank, local_rank, world, device):
                      "name": args.config, "global_batch": args.batch * world,
                      "parallelism": "dp%d (one flat float32 gradient bucket all-reduced over RCCL per step)" % world}
     res["roofline"] = roof
+    res["box"] = box
     res["host_issue_ms_per_step"] = round(t_issued / args.steps * 1e3, 4)
     res["hipgraph"] = bool(use_graph)
     res["skipped_steps"] = tr.skipped_steps
@@ -756,7 +827,14 @@ def main(argv=None):
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.opt:
+            from squeezedet_amd import ops
+            for o in args.opt:
+                k, v = o.split("=")
+                ops.set_option(k, int(v))
         res = run_infer(args, rank, local_rank, world, device) if args.kind == "infer" else run_train(args, rank, local_rank, world, device)
+        if args.opt and res is not None:
+            res["options"] = list(args.opt)           # (a line measured with non-default knobs says so)
     if rank == 0:
         if res.get("ranks_seen") != args.gpus:
             res["error"] = "ranks_seen %s != --gpus %d" % (res.get("ranks_seen"), args.gpus)

@@ -552,6 +552,14 @@ int sqdet_copy_to_mapped_host(const void* src_device, void* dst_pinned_host, siz
  * (row, col) of every accumulator register to host_out (see csrc/probe.hip). */
 int sqdet_probe_mfma_layout(int32_t* host_out, int capacity);
 
+/* Box calibration (bench.py's `box_mfma_tflops` / `box_copy_gbs`; no reference counterpart -- the reference has no
+ * device code).  sqdet_calib_mfma enqueues a fixed MFMA microkernel (512 workgroups x 4 waves x iters x 8 independent
+ * 16x16x32 float16 MFMAs; scratch: >= 131072 device floats it may overwrite) and returns the flops it performs in
+ * *flops; sqdet_calib_copy enqueues a plain 16-byte-per-lane device copy of `bytes` bytes.  The caller times them with
+ * events on `stream`. */
+int sqdet_calib_mfma(float* scratch, size_t scratch_floats, int iters, double* flops, sqdet_stream_t stream);
+int sqdet_calib_copy(const void* src, void* dst, size_t bytes, sqdet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

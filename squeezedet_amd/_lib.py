@@ -113,6 +113,8 @@ SIGNATURES = {
     "sqdet_preprocess_bgr": (ci, [vp, vp] + [ci] * 5 + [cf, cf, cf, ci, vp]),
     "sqdet_copy_to_mapped_host": (ci, [vp, vp, sz, vp]),
     "sqdet_probe_mfma_layout": (ci, [C.POINTER(C.c_int32), ci]),
+    "sqdet_calib_mfma": (ci, [vp, sz, ci, C.POINTER(cd), vp]),
+    "sqdet_calib_copy": (ci, [vp, vp, sz, vp]),
 }
 
 

@@ -256,17 +256,26 @@ __global__ __launch_bounds__((4 * NG / NTW) * RS * 64, WPS) void fire_dma(FireXA
         f32x4 acc[NTW];
 #pragma unroll
         for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (IS3) {
+        if constexpr (IS3 && S16) {
           i32x4 bf[NT3];
 #pragma unroll
-          for (int k = 0; k < NT3; ++k) {
-            if constexpr (S16) bf[k] = *reinterpret_cast<const i32x4*>(sqb + boff[k] + m * ROWP);
-            else bf[k] = *reinterpret_cast<const i32x4*>(sqb + boff[k % 3] + (m + k / 3) * ROWP);
-          }
+          for (int k = 0; k < NT3; ++k) bf[k] = *reinterpret_cast<const i32x4*>(sqb + boff[k] + m * ROWP);
 #pragma unroll
           for (int k = 0; k < NT3; ++k)
 #pragma unroll
             for (int t = 0; t < NTW; ++t) mma16<f16>(acc[t], w3r[k][t], bf[k]);
+        } else if constexpr (IS3) {
+          // one kernel row (3 taps) of B fragments at a time: 12 registers in flight instead of 36
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            i32x4 bf[3];
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) bf[dx] = *reinterpret_cast<const i32x4*>(sqb + boff[dx] + (m + dy) * ROWP);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+              for (int t = 0; t < NTW; ++t) mma16<f16>(acc[t], w3r[dy * 3 + dx][t], bf[dx]);
+          }
         } else {
           i32x4 bf1;
           if constexpr (S16) bf1 = *reinterpret_cast<const i32x4*>(sqb + boff[5] + m * ROWP);
@@ -424,7 +433,7 @@ int fire_dma_launch(const void* sq_in, const void* w1, const float* b1, const vo
   a.N = n; a.H = h; a.W = w; a.S = s; a.E = e1; a.S2 = s2;
   a.Hp = out_size(h, 3, 2, SQDET_PAD_SAME); a.Wp = out_size(w, 3, 2, SQDET_PAD_SAME);
   a.ptp = pad_before(h, 3, 2, SQDET_PAD_SAME); a.plp = pad_before(w, 3, 2, SQDET_PAD_SAME);
-  const int rows_t = (f4 && d != 74) ? 4 : 8;
+  const int rows_t = (f4 && d != 74 && d != 76 && d != 77) ? 4 : 8;
   if (pool) { a.tiles_x = (a.Wp + 6) / 7; a.tiles_y = (a.Hp + 3) / 4; }
   else { a.tiles_x = (w + XCOLS - 1) / XCOLS; a.tiles_y = (h + rows_t - 1) / rows_t; }
   const long nt = (long)n * a.tiles_x * a.tiles_y;
@@ -436,8 +445,19 @@ int fire_dma_launch(const void* sq_in, const void* w1, const float* b1, const vo
   //                        S16   POOL  NG NTW RS ROWS NTS2 WPS
   if (f2) rc = d == 71 ? launch_dma<true, false, 1, 2, 2, 8, 1, 3>(a, st) : launch_dma<true, false, 1, 2, 4, 8, 1, 4>(a, st);
   else if (f3) rc = launch_dma<true, true, 1, 2, 2, 8, 2, 4>(a, st);
-  else if (f4) rc = d == 74 ? launch_dma<false, false, 2, 2, 2, 8, 2, 2>(a, st) : launch_dma<false, false, 2, 1, 1, 4, 2, 4>(a, st);
-  else rc = launch_dma<false, true, 2, 1, 1, 8, 3, 4>(a, st);
+  else if (f4) {
+    // (same box, us: fire_stream's form 28.5; 8 waves x 2 tiles x 4-row tile, two workgroups per CU 27.2 -- the default; one tile per
+    // wave 29.2; 8-row tiles: one 8-wave workgroup 30.9, one 16-wave workgroup 29.9 / 31.3)
+    if (d == 74) rc = launch_dma<false, false, 2, 2, 2, 8, 2, 2>(a, st);
+    else if (d == 75) rc = launch_dma<false, false, 2, 1, 1, 4, 2, 4>(a, st);
+    else if (d == 76) rc = launch_dma<false, false, 2, 2, 4, 8, 2, 4>(a, st);
+    else if (d == 77) rc = launch_dma<false, false, 2, 1, 2, 8, 2, 4>(a, st);
+    else rc = launch_dma<false, false, 2, 2, 2, 4, 2, 4>(a, st);
+  } else {
+    if (d == 78) rc = launch_dma<false, true, 2, 2, 2, 8, 3, 2>(a, st);
+    else if (d == 79) rc = launch_dma<false, true, 2, 1, 2, 8, 3, 4>(a, st);
+    else rc = launch_dma<false, true, 2, 1, 1, 8, 3, 4>(a, st);
+  }
   if (rc != SQDET_OK) return rc;
   *handled = true;
   return SQDET_OK;

@@ -37,7 +37,56 @@ __global__ void probe_kernel(float* out) {
   }
 }
 
+// ---- box calibration (bench.py: `box_mfma_tflops`, `box_copy_gbs`): two fixed ~1 ms microkernels whose only purpose is to tell a slow
+// box (profiles/r03_slowbox_*: every MFMA-heavy launch 20-27 % slower at the same reported clock) from a regression of the build.
+// 512 workgroups x 4 waves (two per SIMD), `iters` x 8 independent 16x16x32 float16 MFMAs per wave on non-trivial operands
+// (zero operands clock ~19 % higher: MI355X_MICROARCH.md, DVFS give-back).
+__global__ __launch_bounds__(256) void calib_mfma_kernel(float* out, int iters) {
+  const int l = threadIdx.x & 63;
+  f16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a[i] = (f16)(0.01f * (float)((l * 7 + i * 3) % 13 - 6));
+    b[i] = (f16)(0.02f * (float)((l * 5 + i) % 11 - 5));
+  }
+  f32x4 acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[k], 0, 0, 0);
+  }
+  f32x4 s = acc[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) s += acc[k];
+  out[blockIdx.x * 256 + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ __launch_bounds__(256) void calib_copy_kernel(const i32x4* __restrict__ src, i32x4* __restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+
 }  // namespace sqdet
+
+extern "C" int sqdet_calib_mfma(float* scratch, size_t scratch_floats, int iters, double* flops, sqdet_stream_t stream) {
+  using namespace sqdet;
+  constexpr int GRID = 512;
+  SQDET_REQUIRE(scratch && scratch_floats >= (size_t)GRID * 256 && iters > 0 && flops, "calib_mfma: scratch >= 131072 floats, iters > 0");
+  hipLaunchKernelGGL(calib_mfma_kernel, dim3(GRID), dim3(256), 0, as_stream(stream), scratch, iters);
+  SQDET_CHECK_HIP(hipGetLastError());
+  *flops = (double)GRID * 4.0 * (double)iters * 8.0 * (2.0 * 16 * 16 * 32);
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_calib_copy(const void* src, void* dst, size_t bytes, sqdet_stream_t stream) {
+  using namespace sqdet;
+  SQDET_REQUIRE(src && dst && bytes >= 16 && bytes % 16 == 0, "calib_copy: non-null pointers, bytes a multiple of 16");
+  hipLaunchKernelGGL(calib_copy_kernel, dim3(256 * 8), dim3(256), 0, as_stream(stream), reinterpret_cast<const i32x4*>(src),
+                     reinterpret_cast<i32x4*>(dst), bytes / 16);
+  SQDET_CHECK_HIP(hipGetLastError());
+  return SQDET_OK;
+}
 
 extern "C" int sqdet_probe_mfma_layout(int32_t* host_out, int capacity) {
   using namespace sqdet;

@@ -827,6 +827,35 @@ def preprocess_bgr(images_u8, dst_h, dst_w, bgr_means, dtype=torch.float32):
     return out
 
 
+def box_calibration(device, mfma_iters=8192, copy_mib=1024, reps=3):
+    """Two fixed microkernels timed with events on the current stream (sqdet_calib_mfma / sqdet_calib_copy): what THIS box
+    sustains on a bare MFMA loop (TFLOP/s, float16 16x16x32) and on a plain device copy far larger than the Infinity Cache
+    (GB/s, read + write).  bench.py prints both beside its result so that a slow box is identifiable from the JSON line alone.
+    Best of `reps`."""
+    scratch = torch.empty(512 * 256, dtype=torch.float32, device=device)
+    n = copy_mib << 20
+    src = torch.empty(n, dtype=torch.uint8, device=device)
+    dst = torch.empty(n, dtype=torch.uint8, device=device)
+    src.fill_(1)
+    flops = C.c_double(0.0)
+    best_m, best_c = None, None
+    for r in range(reps + 1):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        check(lib().sqdet_calib_mfma(_dev(scratch, "scratch"), scratch.numel(), int(mfma_iters), C.byref(flops), stream_ptr()), "sqdet_calib_mfma")
+        e1.record()
+        check(lib().sqdet_calib_copy(_dev(src, "src"), _dev(dst, "dst"), n, stream_ptr()), "sqdet_calib_copy")
+        e2.record()
+        torch.cuda.synchronize()
+        if r == 0:
+            continue                                   # warm-up
+        tm, tc = e0.elapsed_time(e1), e1.elapsed_time(e2)
+        best_m = tm if best_m is None else min(best_m, tm)
+        best_c = tc if best_c is None else min(best_c, tc)
+    return {"box_mfma_tflops": round(flops.value / (best_m * 1e-3) / 1e12, 1), "box_mfma_ms": round(best_m, 4),
+            "box_copy_gbs": round(2.0 * n / (best_c * 1e-3) / 1e9, 1), "box_copy_ms": round(best_c, 4)}
+
+
 def set_option(name, value):
     """Process-wide tuning knob (sqdet_set_option), e.g. set_option("conv_algo", 1) = generic kernels only."""
     check(lib().sqdet_set_option(name.encode(), int(value)), "sqdet_set_option")

@@ -19,7 +19,8 @@ python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_sqdet_in
 python $R/bench.py --no-cpu-baseline --layer-table $OUT/layer_table.json > /dev/null 2>&1
 # 2. rocprofv3 kernel stats of the headline command
 rocprofv3 --kernel-trace --stats -d $OUT/kstats -o ks --output-format csv -- python $R/bench.py --no-cpu-baseline > $OUT/kstats.log 2>&1
-python $R/profiles/summarize.py $(find $OUT/kstats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline" >> $OUT/kstats.log 2>&1
+FP=$(cd $R && python -c "import bench; print(bench.build_fingerprint())")
+python $R/profiles/summarize.py $(find $OUT/kstats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline" $FP >> $OUT/kstats.log 2>&1
 if [ "${FAST:-0}" != "1" ]; then
 # 2b. kernel stats of the other configs (which kernels carry SqueezeDet+, ResNet50 inference and the two training steps)
 for c in sqdetplus_infer sqdet_train_fp32 res50_train_fp16 sqdet_train_fp16; do

@@ -16,7 +16,9 @@ args = bench.parse_args(["--config", "sqdet_infer"])
 model, mc, xs = bench.build_infer_model(args, 0)
 plan = model._native_plan(args.batch)
 preds = None
+# the step bench.py times runs ConvDet's SCORE form (det_probs from its epilogue): profile THAT kernel variant
+scores = torch.empty((args.batch, mc.ANCHORS), dtype=torch.float32, device=xs[0].device) if plan.scores_supported() else None
 for i in range(5):
-    preds = plan.forward(xs[i % len(xs)], preds)
+    preds = plan.forward(xs[i % len(xs)], preds, scores=scores)
 torch.cuda.synchronize()
 print("layers:", [n for n, _, _ in plan.layer_table()])
