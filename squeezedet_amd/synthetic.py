@@ -45,65 +45,189 @@ def synthetic_params(model, seed=0):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# "Planted-object" detection head: random backbone weights give 16 848 anchor scores that form a near-continuum (the
-# 64th and 65th differ by ~1e-4), so no float16 run can be compared pick-for-pick with another implementation.  This head
-# makes the DISCRETE outputs of the path (which anchors enter the top-N, their order, classes, the NMS survivors)
-# decidable, the way a trained detector's are: a handful of cells per image fire, everything else sits at one exact
-# background level.
-#   * three "detector" channels -- channels 0..2 of fire11's concat output -- get a bias shift so that only the top
-#     ~0.135 % of cells stay positive after the ReLU (exact zeros elsewhere), and a x16 gain (a power of two: exact in
-#     float16) so that the confidence gain below stays inside float16's range;
-#   * conv12 is zero except: confidence logit of anchor shape k (channel K*C + k) = -6 + G * detector[k % C] at the
-#     centre tap, G a power of two large enough that a firing cell saturates the sigmoid to exactly 1.0f; class logits
-#     and box deltas are bias-only (class k % C wins, with a different margin per shape, so the nine shapes score at nine
-#     separated levels; deltas are small float16-exact constants).
-# A firing (cell, class c) plants the three anchor shapes c, c+3, c+6 of that cell (~20 anchors per image at z = 3);
-# the background anchors tie exactly within a shape and are ranked by the repo's tie rule (higher anchor index first).
-PLANT_TAIL = 1.35e-3          # fraction of (cell, detector channel) pairs that fire: z = 3 of a Gaussian
-PLANT_CONF_BIAS = -6.0
-PLANT_DET_SCALE = 16.0
+# "Planted objects": a detection problem whose DISCRETE outputs (which anchors enter the top-N, their order, their classes,
+# the NMS survivors) have real margins, the way a trained detector's have -- random weights give 16 848 anchor scores that
+# form a near-continuum (the 64th and 65th differ by ~1e-4), so no float16 run can be compared pick-for-pick with another
+# implementation.  (Round 3 thresholded three random feature channels of fire11: a threshold on a continuum always has
+# cells within float16 noise of it, and 4 of 16 images flipped one.  Now the objects are in the IMAGE and the channels that
+# carry them are exact.)
+#   * images (planted_images): a low-amplitude integer background with a few 3x3 "objects" -- colour channel c at +144, the
+#     others at -100 -- placed on conv1 windows chosen so that, through conv1's stride and the three 3x3/s2 max-pools, each
+#     object reaches EXACTLY ONE cell of the final grid;
+#   * three detector channels (planted_params): conv1 filter c sums colour c over its window with weight 2^-10 (every
+#     product and partial sum is a multiple of 2^-10 below 2^14: exact in float32 in ANY summation order, so device and
+#     oracle round the same value to float16); channel c of every squeeze1x1 / expand1x1 from fire2 to fire10 passes it on
+#     with a single weight 1.0 and zero bias (exact), the max-pools are exact, and fire11/expand1x1 channel c is
+#     relu(16 * (x - 0.875)): an object reads 1.265625 -> 6.25, the background (<= 0.14) and every partial window overlap
+#     (<= 0.52) are exact zeros.  Every other channel of the backbone keeps its random weights (and also reads the detector
+#     channels): the forward is the benchmark's, the decisions ride on three channels of it through EVERY launch;
+#   * head: conv12 is zero except the confidence logit of anchor shape k = -6 + 4 * detector[k % 3] at the centre tap
+#     (19 -> sigmoid == 1.0f exactly); class logits and box deltas are bias-only (class k % 3 wins with a different margin
+#     per shape: nine separated score levels).  An object of colour c plants the anchor shapes c, c+3, c+6 of its cell; all
+#     other anchors tie EXACTLY at their shape's background level and are ranked by the tie rule (higher index first);
+#   * the object layout of an image is rejection-sampled so that no two planted boxes of a class have an IoU within
+#     PLANT_IOU_MARGIN of NMS_THRESH (the boxes are a closed form of cell, shape and the constant deltas).
+PLANT_W = 2.0 ** -10
+PLANT_OBJ, PLANT_OFF, PLANT_BG = 144.0, -100.0, 16          # object colour / other colours / background amplitude (integers)
+PLANT_Q, PLANT_DET_SCALE = 0.875, 16.0
+PLANT_CONF_BIAS, PLANT_CONF_GAIN = -6.0, 4.0
+PLANT_IOU_MARGIN = 0.04
+FIRES = ["fire%d" % i for i in range(2, 12)]
 
 
-def planted_stats(det_activations):
-    """det_activations: [N,h,w,>=3] array of fire11's (post-ReLU) output under the ORIGINAL biases on a few calibration
-    images.  Returns [(q_c, e_c)] per detector channel: q_c = the (1 - PLANT_TAIL) quantile (the bias shift), e_c = the
-    distance to the (1 - PLANT_TAIL / 3) quantile (the scale of the exceedances, which sizes the confidence gain)."""
-    a = np.asarray(det_activations, dtype=np.float64)
-    stats = []
-    for c in range(3):
-        v = np.sort(a[..., c].ravel())
-        n = len(v)
-        q = v[min(n - 1, int(n * (1.0 - PLANT_TAIL)))]
-        q2 = v[min(n - 1, int(n * (1.0 - PLANT_TAIL / 3.0)))]
-        if not (q > 0 and q2 > q):
-            raise ValueError("planted_stats: detector channel %d has no positive tail to calibrate on" % c)
-        stats.append((float(np.float32(q)), float(np.float32(q2 - q))))
-    return stats
+def _same_geom(n, k=3, s=2):
+    """TF SAME: (output size, pad before)."""
+    o = -(-n // s)
+    return o, max((o - 1) * s + k - n, 0) // 2
 
 
-def planted_head(params, stats, anchors_per_grid=9, classes=3):
-    """params with the planted head installed (a new dict; untouched tensors are shared)."""
+def _single_cell_positions(n_img):
+    """Per final-grid index c (one image dimension of n_img pixels): the conv1 output positions whose value reaches final cell c
+    and NO other through the three SAME 3x3/s2 max-pools, and whose conv1 window lies inside the image.  Returns
+    ({c: [positions]}, conv1 pad before, final size)."""
+    n1, p0 = _same_geom(n_img)
+    sizes, pads = [n1], []
+    for _ in range(3):
+        o, p = _same_geom(sizes[-1])
+        sizes.append(o)
+        pads.append(p)
+    out = {}
+    for pos in range(n1):
+        if not (2 * pos - p0 >= 0 and 2 * pos - p0 + 2 < n_img):
+            continue
+        reach = {pos}
+        for lvl in range(3):
+            nxt = set()
+            for q in reach:
+                for i in range(sizes[lvl + 1]):
+                    if 2 * i - pads[lvl] <= q <= 2 * i - pads[lvl] + 2:
+                        nxt.add(i)
+            reach = nxt
+        if len(reach) == 1:
+            out.setdefault(next(iter(reach)), []).append(pos)
+    return out, p0, sizes[-1]
+
+
+def _planted_boxes(mc, cell_y, cell_x, c, shapes=None):
+    """[3, 4] (cx, cy, w, h) of the anchors an object of colour c plants at a cell (or of the given shapes), as
+    interpret_output decodes them (nn_skeleton.py:175-215: delta decode, clip to the image, back to centre form)."""
+    K = mc.ANCHOR_PER_GRID
+    gw = int(round(len(mc.ANCHOR_BOX) / K / _same_geom(_same_geom(_same_geom(_same_geom(mc.IMAGE_HEIGHT)[0])[0])[0])[0]))
+    out = []
+    for k in (shapes if shapes is not None else range(c, K, 3)):
+        ax, ay, aw, ah = [float(v) for v in mc.ANCHOR_BOX[(cell_y * gw + cell_x) * K + k]]
+        dx, dy, dw, dh = planted_deltas(k)
+        cx, cy, w, h = ax + dx * aw, ay + dy * ah, aw * math.exp(dw), ah * math.exp(dh)
+        xmin = min(max(0.0, cx - w / 2), mc.IMAGE_WIDTH - 1.0)
+        ymin = min(max(0.0, cy - h / 2), mc.IMAGE_HEIGHT - 1.0)
+        xmax = max(min(mc.IMAGE_WIDTH - 1.0, cx + w / 2), 0.0)
+        ymax = max(min(mc.IMAGE_HEIGHT - 1.0, cy + h / 2), 0.0)
+        ww, hh = xmax - xmin + 1.0, ymax - ymin + 1.0
+        out.append([xmin + 0.5 * ww, ymin + 0.5 * hh, ww, hh])
+    return np.asarray(out, np.float64)
+
+
+def _iou(a, b):
+    lr = min(a[0] + a[2] / 2, b[0] + b[2] / 2) - max(a[0] - a[2] / 2, b[0] - b[2] / 2)
+    tb = min(a[1] + a[3] / 2, b[1] + b[3] / 2) - max(a[1] - a[3] / 2, b[1] - b[3] / 2)
+    if lr <= 0 or tb <= 0:
+        return 0.0
+    inter = lr * tb
+    return inter / (a[2] * a[3] + b[2] * b[3] - inter)
+
+
+def planted_deltas(k):
+    """The constant (float16-exact) box deltas of anchor shape k.  Shape 8 has the highest background score level: its
+    highest-index anchors fill the top-N behind the planted ones, and ITS deltas are chosen so that those neighbouring boxes keep
+    every mutual IoU (and the IoU with the other two shapes of an object of colour 2) >= 0.07 away from NMS_THRESH at both benchmark sizes."""
+    if k == 8:
+        return (-0.125, -0.125, -0.25, -0.375)
+    return (0.125 * ((k % 3) - 1), 0.0625 * ((k % 2) * 2 - 1), 0.25 * (k % 2), -0.125 * (k % 3))
+
+
+def planted_images(mc, batch, seed=0, objects_per_colour=4):
+    """float32 [B,H,W,3] integer-valued images (exact in float16) with `objects_per_colour` objects of each of the three
+    colours per image, and the list of planted (image, cell_y, cell_x, colour)."""
+    rng = np.random.RandomState(seed)
+    H, W = int(mc.IMAGE_HEIGHT), int(mc.IMAGE_WIDTH)
+    rows, py0, gh = _single_cell_positions(H)
+    cols, px0, gw = _single_cell_positions(W)
+    x = rng.randint(-PLANT_BG, PLANT_BG + 1, size=(batch, H, W, 3)).astype(np.float32)
+    planted = []
+    # the top-N is filled, behind the 9 * objects_per_colour planted anchors, with the highest-index anchors of shape 8 (the
+    # highest background level; class 2): their boxes take part in class 2's NMS and in its IoU margins
+    K = mc.ANCHOR_PER_GRID
+    nfill = max(0, mc.TOP_N_DETECTION - 3 * 3 * objects_per_colour)
+    fill = [_planted_boxes(mc, cell // gw, cell % gw, 2, shapes=[K - 1])[0] for cell in range(gh * gw - 1, gh * gw - 1 - nfill, -1)]
+    for b in range(batch):
+        for attempt in range(400):
+            cells, boxes, ok = [], {0: [], 1: [], 2: list(fill)}, True
+            for c in range(3):
+                for _ in range(objects_per_colour):
+                    cy, cx = sorted(rows)[rng.randint(len(rows))], sorted(cols)[rng.randint(len(cols))]
+                    if any(abs(cy - oy) < 2 and abs(cx - ox) < 2 for oy, ox, _ in cells):
+                        ok = False              # (two objects never share or touch a cell: no window sees two of them)
+                    cells.append((cy, cx, c))
+                    boxes[c].extend(_planted_boxes(mc, cy, cx, c))
+            for c in range(3):
+                bl = boxes[c]
+                for i in range(len(bl)):
+                    for j in range(i + 1, len(bl)):
+                        if abs(_iou(bl[i], bl[j]) - mc.NMS_THRESH) < PLANT_IOU_MARGIN:
+                            ok = False
+            if ok:
+                break
+        else:
+            raise RuntimeError("planted_images: no object layout with IoU margins found for image %d" % b)
+        for cy, cx, c in cells:
+            y1, x1 = rows[cy][rng.randint(len(rows[cy]))], cols[cx][rng.randint(len(cols[cx]))]
+            iy, ix = 2 * y1 - py0, 2 * x1 - px0
+            x[b, iy:iy + 3, ix:ix + 3, :] = PLANT_OFF
+            x[b, iy:iy + 3, ix:ix + 3, c] = PLANT_OBJ
+            planted.append((b, cy, cx, c))
+    return torch.from_numpy(x), planted
+
+
+def planted_params(params, anchors_per_grid=9, classes=3):
+    """params with the three detector channels and the planted head installed (a new dict; untouched tensors are shared)."""
     K, C = int(anchors_per_grid), int(classes)
+    assert C == 3, "three colours <-> three classes"
     p = dict(params)
-    b11 = p["fire11/expand1x1/biases"].clone().float()
-    w11 = p["fire11/expand1x1/kernels"].clone().float()
+
+    def upd(name, fn):
+        t = p[name].clone().float()
+        fn(t)
+        p[name] = t
+    def conv1_k(t):
+        t[:, :, :, :3] = 0.0
+        for c in range(3):
+            t[:, :, c, c] = PLANT_W
+    upd("conv1/kernels", conv1_k)
+    upd("conv1/biases", lambda t: t[:3].zero_())
+    def passthrough(t):                       # [1,1,cin,cout]: out channel c reads in channel c only
+        t[:, :, :, :3] = 0.0
+        for c in range(3):
+            t[0, 0, c, c] = 1.0
+    for f in FIRES:
+        upd(f + "/squeeze1x1/kernels", passthrough)
+        upd(f + "/squeeze1x1/biases", lambda t: t[:3].zero_())
+        if f != "fire11":
+            upd(f + "/expand1x1/kernels", passthrough)
+            upd(f + "/expand1x1/biases", lambda t: t[:3].zero_())
+    def det_k(t):
+        t[:, :, :, :3] = 0.0
+        for c in range(3):
+            t[0, 0, c, c] = PLANT_DET_SCALE
+    upd("fire11/expand1x1/kernels", det_k)
+    upd("fire11/expand1x1/biases", lambda t: t[:3].fill_(-PLANT_Q * PLANT_DET_SCALE))
     w12 = torch.zeros_like(p["conv12/kernels"], dtype=torch.float32)
     b12 = torch.zeros(K * (C + 5), dtype=torch.float32)
-    for c, (q, e) in enumerate(stats):
-        b11[c] = (b11[c] - q) * PLANT_DET_SCALE
-        w11[..., c] *= PLANT_DET_SCALE
-        gain = 2.0 ** int(round(math.log2(23.0 / (0.02 * e * PLANT_DET_SCALE))))     # sigmoid(-6 + gain * y) == 1.0f once y > 2 % of e
-        if not gain <= 32768.0:
-            raise ValueError("planted_head: gain %g does not fit float16 (detector activations too small)" % gain)
-        for k in range(c, K, C):
-            w12[1, 1, c, K * C + k] = gain
     for k in range(K):
+        w12[1, 1, k % C, K * C + k] = PLANT_CONF_GAIN
         b12[k * C + (k % C)] = 1.0 + 0.25 * k                          # softmax level of shape k: 0.58 .. 0.91
         b12[K * C + k] = PLANT_CONF_BIAS
         d = K * (C + 1) + 4 * k
-        b12[d:d + 4] = torch.tensor([0.125 * ((k % 3) - 1), 0.0625 * ((k % 2) * 2 - 1), 0.25 * (k % 2), -0.125 * (k % 3)])
-    p["fire11/expand1x1/biases"] = b11
-    p["fire11/expand1x1/kernels"] = w11
+        b12[d:d + 4] = torch.tensor(planted_deltas(k))
     p["conv12/kernels"] = w12
     p["conv12/biases"] = b12
     return p

@@ -54,7 +54,7 @@ def image_margins(mc, ref, got):
 
 def run(size, dtype_name, nimg=16, seed=40, device="cuda:0", planted=False, batch=None, pipelined=False):
     """Runs seeded images through the device path and the oracle; returns (rows, summary) for the first nimg.
-    planted: install the planted-object head (calibrated on two other images) on both sides.  batch: device batch
+    planted: planted-object images + detector channels + head (squeezedet_amd/synthetic.py) on both sides.  batch: device batch
     (>= nimg; default nimg).  pipelined: the device picks come from detect_filter_pipelined (bench.py's step) instead of
     detect -> filter_prediction_batch."""
     import torch
@@ -68,11 +68,16 @@ def run(size, dtype_name, nimg=16, seed=40, device="cuda:0", planted=False, batc
     mc.BATCH_SIZE = batch
     m = nets.SqueezeDet(mc, gpu_id="0", dtype=tdt)
     params = O.init_params("squeezeDet", seed=seed, storage=dtype_name)
-    if planted:
-        params, _ = O.planted_head("squeezeDet", params, O.synthetic_images(2, size[0], size[1], seed=seed + 999, storage=dtype_name))
-    m.load_params(params)
     omc = O.squeezeDet_config_for_input(*size)
-    x = O.synthetic_images(batch, size[0], size[1], seed=seed + 1, storage=dtype_name)
+    if planted:
+        # planted objects (squeezedet_amd/synthetic.py: a data generator, not arithmetic under test): objects in the image, three
+        # exact detector channels through every launch, a saturating head -- every decision has a margin by construction
+        from squeezedet_amd import synthetic as SY
+        params = SY.planted_params(params, omc.ANCHOR_PER_GRID, omc.CLASSES)
+        x, _ = SY.planted_images(omc, batch, seed=seed + 1)
+    else:
+        x = O.synthetic_images(batch, size[0], size[1], seed=seed + 1, storage=dtype_name)
+    m.load_params(params)
     xd = x.to(device, tdt)
     outs = m.run([m.det_boxes, m.det_probs, m.det_class, m.pred_class_probs, m.pred_conf], {m.image_input: xd})
     if pipelined:

@@ -355,21 +355,22 @@ def test_end_to_end_decision_margins(size, dtype, capsys):
 def test_fp16_headline_path_picks_identical_planted_objects(size, capsys):
     """The benchmarked path pinned end to end (north_star: bit-exact anchor indices / NMS picks): float16, batch 32,
     through detect_filter_pipelined (bench.py's step: forward + decode + top-N + NMS + rows to pinned host memory), against
-    the float16-storage oracle, image -> picks.  Weights: random backbone + the planted-object head
-    (squeezedet_amd/synthetic.py: ~10-50 anchors per image score 0.58-0.91, the rest tie exactly at a background level),
-    so every decision has a margin unless a detector cell sits within float16 noise of its threshold -- those images are
-    reported undecidable by the margins and skipped.  Asserted on the decidable ones (>= 8 of the 16 compared): identical
-    anchor indices in output order, identical classes, boxes equal to 2e-6 relative (device expf against glibc's)."""
+    the float16-storage oracle, image -> picks, on planted objects (squeezedet_amd/synthetic.py: 12 objects per image in the
+    IMAGE, carried by three exact detector channels through every launch of the forward, a head that saturates on them -- 36
+    anchors per image score 0.58-0.91, all others tie exactly at their shape's background level; object layouts keep every
+    same-class IoU >= 0.04 away from NMS_THRESH).  EVERY one of the 16 compared images must be decidable (all margins above
+    twice the measured noise) and give identical anchor indices in output order, identical classes, and boxes equal to 2e-6
+    relative (device expf against glibc's)."""
     from tests import decision_margins as DM
     rows, summary = DM.run(size, "fp16", nimg=16, seed=40, planted=True, batch=32, pipelined=True)
     with capsys.disabled():
-        print("\n[planted head] " + DM.format_report(rows, summary))
-    dec = [r for r in rows if r["decidable"]]
-    assert len(dec) >= 8, summary
-    for r in dec:
-        assert r["same_picks"] and r["same_boxes"], "image %d: margins above the noise but the picks differ: %r" % (r["image"], r)
-        assert r["n_strong"] >= 3, r                       # the comparison is not vacuous: planted objects were found
-    assert summary["all_same"] >= len(dec)
+        print("\n[planted objects] " + DM.format_report(rows, summary))
+    for r in rows:
+        assert r["decidable"], "image %d: a decision margin is within the measured noise: %r" % (r["image"], r)
+        assert r["same_picks"] and r["same_boxes"], "image %d: the picks differ: %r" % (r["image"], r)
+        assert r["n_strong"] >= 8, r                       # the comparison is not vacuous: the planted objects were found
+        assert r["m_iou"] >= 0.03, r                       # (layout margin 0.04 minus the +1 of bbox_transform_inv's width)
+    assert summary["all_same"] == 16 and summary["decidable"] == 16, summary
 
 
 def test_zz_report_observed_errors(capsys):
