@@ -36,6 +36,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SHARE_DEVICE = os.environ.get("SQDET_SHARE_DEVICE") == "1"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
 MFMA_F32_PEAK_TFLOPS = 157.3   # f32-input MFMA (= the f32 vector rate)
@@ -113,7 +114,7 @@ def max_over_ranks(value, world, device):
 def barrier(world, device):
     if _dist_on():
         import torch.distributed as dist
-        if device.type == "cuda":
+        if device.type == "cuda" and dist.get_backend() == "nccl":
             dist.barrier(device_ids=[device.index])
         else:
             dist.barrier()
@@ -759,7 +760,7 @@ def self_launch(args, argv):
     import subprocess
     if not args.dry_run:
         n = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if n < args.gpus:
+        if n < args.gpus and not (SHARE_DEVICE and n >= 1):
             fail("--gpus %d but only %d HIP device(s) are visible" % (args.gpus, n), n_gpus=args.gpus, devices_visible=n)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
@@ -818,15 +819,23 @@ def main(argv=None):
     else:
         if not torch.cuda.is_available():
             fail("bench.py needs a HIP device (there is no CPU fallback); --dry-run exercises the launcher without one", n_gpus=args.gpus)
-        if local_rank >= torch.cuda.device_count():
-            fail("rank %d: local rank %d but only %d HIP device(s) are visible" % (rank, local_rank, torch.cuda.device_count()), n_gpus=args.gpus)
+        ndev = torch.cuda.device_count()
+        if local_rank >= ndev and not SHARE_DEVICE:
+            fail("rank %d: local rank %d but only %d HIP device(s) are visible" % (rank, local_rank, ndev), n_gpus=args.gpus)
+        # SQDET_SHARE_DEVICE=1 (tests on a one-GPU box): ranks beyond the visible devices share them, and the process group is
+        # gloo (RCCL refuses two ranks on one device) -- the launcher / rendezvous / timing path with real kernels, NOT a
+        # multi-GPU measurement: the line carries `shared_device`
+        local_rank = local_rank % ndev
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
         # (SQDET_FORCE_DIST=1 under torch.distributed.run with one process: exercises the RCCL path on a single-GPU box)
         if world > 1 or (os.environ.get("SQDET_FORCE_DIST") == "1" and in_torchrun):
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            if SHARE_DEVICE and world > ndev:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         if args.opt:
             from squeezedet_amd import ops
             for o in args.opt:
@@ -836,6 +845,8 @@ def main(argv=None):
         if args.opt and res is not None:
             res["options"] = list(args.opt)           # (a line measured with non-default knobs says so)
     if rank == 0:
+        if SHARE_DEVICE and not args.dry_run and world > torch.cuda.device_count():
+            res["shared_device"] = True
         if res.get("ranks_seen") != args.gpus:
             res["error"] = "ranks_seen %s != --gpus %d" % (res.get("ranks_seen"), args.gpus)
         print(json.dumps(res), flush=True)

@@ -131,6 +131,16 @@ class _TrainerBase:
         if self.world > 1:      # replicas start from rank 0's variables and momentum: they stay bit-identical from here on
             torch.distributed.broadcast(self.flat_params, src=torch.distributed.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
             torch.distributed.broadcast(self.flat_accum, src=torch.distributed.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+            # ... and from rank 0's FROZEN variables (conv1 of SqueezeDet, conv1 .. res3d and the batch-norm statistics of ResNet50):
+            # they are not in the flat buffers, and a replica that loaded other values would compute other gradients for good
+            src0 = torch.distributed.get_global_rank(self.pg, 0) if self.pg is not None else 0
+            for n in model.params:
+                if not model.trainable[n]:
+                    t = model.params[n].contiguous()
+                    torch.distributed.broadcast(t, src=src0, group=self.pg)
+                    model.params[n].copy_(t)
+            model._packed.clear()
+            model._plan_stale = True
 
     def _wgrad(self, fn, *reads):
         """Runs fn() -- weight-gradient launches writing into the flat gradient bucket -- behind everything issued so far,
