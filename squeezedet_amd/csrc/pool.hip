@@ -124,11 +124,13 @@ __global__ __launch_bounds__(256) void maxpool3_idx_kernel(const T* __restrict__
   unsigned char pos[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) { m[e] = (T)(-__builtin_huge_valf()); pos[e] = 255; }
+  // the first VALID cell initialises (maximum, position), later cells replace it on a strict '>': a window whose valid cells are
+  // all -inf / NaN still names a cell -- the first one, the x-searching backward's (and tf.nn.max_pool's) choice
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int e = 0; e < V; ++e)
-      if (ok[t] && v[t][e] > m[e]) { m[e] = v[t][e]; pos[e] = (unsigned char)t; }
+      if (ok[t] && (pos[e] == 255 || v[t][e] > m[e])) { m[e] = v[t][e]; pos[e] = (unsigned char)t; }
   *reinterpret_cast<vec*>(y + idx * V) = m;
   if constexpr (V == 8) {
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));

@@ -29,6 +29,11 @@
 // (-fno-honor-nans: 148 -> 84 max instructions per pooled row) changed nothing -- at 8 waves per CU the kernel is bound by the
 // latency of its gather -> MFMA -> max chains, not by instruction count.  Next step if this launch is revisited: the patch
 // prefetch as LDS-DMA into a second LDS buffer (no prefetch registers) with 2-row tiles, which fits three workgroups per CU.
+// INPUT CONTRACT: finite pixels.  This file is compiled with -fno-honor-nans (build.py: without it every two-operand max on an MFMA
+// result is preceded by a canonicalising v_max x, x, x -- 148 instead of 84 max instructions per pooled row), so the pooling chain is
+// undefined for NaN inputs and may return a finite value where conv -> pool (and stem_pers / stem_strip, stem_algo = 3 / 2) would
+// propagate the NaN.  Images are uint8 - mean in every caller (sqdet_preprocess_bgr, demo.py:186-190); a caller that can produce NaN /
+// Inf pixels selects stem_algo = 3.
 #include <type_traits>
 #include "stem.h"
 

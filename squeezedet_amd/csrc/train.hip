@@ -232,7 +232,7 @@ __global__ void maxpool3s2_bwd_kernel(const T* __restrict__ x, const T* __restri
             const V v = *reinterpret_cast<const V*>(x + ((((size_t)n * H + yy) * W + xx) * C + cv * EV));
 #pragma unroll
             for (int e = 0; e < EV; ++e)
-              if ((float)v[e] > best[e]) { best[e] = (float)v[e]; bpos[e] = 3 * r + c; }
+              if (bpos[e] < 0 || (float)v[e] > best[e]) { best[e] = (float)v[e]; bpos[e] = 3 * r + c; }   // (the first valid cell initialises: a window of -inf / NaN cells still routes its gradient, to that cell -- as maxpool3_idx_kernel's index does)
           }
         }
         const V d = *reinterpret_cast<const V*>(dy + ((((size_t)n * Ho + oy) * Wo + ox) * C + cv * EV));

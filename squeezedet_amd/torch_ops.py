@@ -85,6 +85,10 @@ def _register():
     def _conv_setup(ctx, inputs, output):
         x, w, b, stride, same, relu = inputs
         if stride != 1 or not same:
+            if any(isinstance(t, torch.Tensor) and t.requires_grad for t in (x, w, b)):
+                # fail where the graph is BUILT, not at backward time
+                raise SqdetError("sqdet::conv2d: only stride-1 SAME convs have a backward kernel (the reference's conv1 is frozen): "
+                                 "detach the inputs of a stride-%d %s conv" % (stride, "SAME" if same else "VALID"))
             ctx.unsupported = True
             return
         ctx.unsupported = False
@@ -170,6 +174,9 @@ def _register():
     def _fire_setup(ctx, inputs, output):
         x, ws, bs, w1, b1, w3, b3 = inputs
         y, sq = output
+        # the squeeze tensor is an auxiliary output (what the backward kernels need in memory): a graph that consumes it must not
+        # silently lose that gradient -- it is marked non-differentiable
+        ctx.mark_non_differentiable(sq)
         ctx.save_for_backward(x, sq, y, ws, w1, w3)
 
     def _fire_backward(ctx, gy, gsq):

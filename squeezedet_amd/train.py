@@ -97,6 +97,8 @@ class _TrainerBase:
         # become graph edges.  Same kernels, same order per buffer: bitwise the sequential results.
         self.overlap_wgrad = bool(overlap_wgrad) and os.environ.get("SQDET_WGRAD_OVERLAP", "1") != "0"
         self._wg_stream, self._wg_keep = None, []
+        # (one WgradPlan per input shape, each pinning its conv's split-K slab workspaces: bounded like GraphedStep's cache,
+        # least recently used first out)
         self._wplans, self.plan_wgrads = {}, os.environ.get("SQDET_WGRAD_PLAN", "1") != "0"
         # dropout masks are independent across the global batch (one tf.nn.dropout over all samples in the reference,
         # nets/squeezeDet.py:74): every replica draws from its own counter stream -- only parameters and momentum must
@@ -141,6 +143,19 @@ class _TrainerBase:
                     model.params[n].copy_(t)
             model._packed.clear()
             model._plan_stale = True
+
+    MAX_WPLANS = 4
+
+    def _wplan_get(self, key):
+        plan = self._wplans.get(key)
+        if plan is not None:
+            self._wplans[key] = self._wplans.pop(key)            # most recently used last
+        return plan
+
+    def _wplan_put(self, key, plan):
+        self._wplans[key] = plan
+        while len(self._wplans) > self.MAX_WPLANS:
+            del self._wplans[next(iter(self._wplans))]
 
     def _wgrad(self, fn, *reads):
         """Runs fn() -- weight-gradient launches writing into the flat gradient bucket -- behind everything issued so far,
@@ -235,6 +250,10 @@ class _TrainerBase:
         # (global mode: every replica's loss is its share of the global-batch graph: the bucket is a sum, factor 1)
         _, grad_scale = step_normalisation(self.global_num_objects, 0, self.world)
         if apply_update:
+            if self.lazy_overflow_check:
+                # settle the PREVIOUS step's flag (its event completed long ago) BEFORE this step's update is enqueued: a
+                # float32 overflow raises here with global_step / skipped_steps describing exactly the updates applied
+                self.flush()
             # (the kernel skips the whole update when any gradient norm is inf / NaN, in either precision: found_inf tells)
             self.opt.step(self.flat_params, self.flat_grads, self.flat_accum, self.learning_rate(), self.mc.MOMENTUM,
                           self.mc.MAX_GRAD_NORM, grad_scale, found_inf=self.found_inf)
@@ -247,7 +266,6 @@ class _TrainerBase:
             if not self.lazy_overflow_check:
                 self._account(bool(int(self.found_inf.item())))
             else:
-                self.flush()                                  # the PREVIOUS step's flag (its event completed long ago)
                 if getattr(self, "_flag_host", None) is None:
                     self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
                     self._flag_event = torch.cuda.Event()
@@ -258,7 +276,9 @@ class _TrainerBase:
                     self.global_step += 1                     # float32: counted now, the late flag can only raise
 
     def flush(self):
-        """lazy_overflow_check: settle the bookkeeping of the last step (loss scale, skipped / global step counters)."""
+        """lazy_overflow_check: settle the bookkeeping of the last step (loss scale, skipped / global step counters).  MANDATORY
+        after the last step of a run in lazy mode (the float32 default): a divergence in the final step is reported here and
+        nowhere else -- the reference asserts on the loss every step (train.py:302-310); bench.py and the tests call it."""
         if self._pending_flag:
             self._flag_event.synchronize()
             self._pending_flag = None
@@ -443,7 +463,7 @@ class SqueezeDetTrainer(_TrainerBase):
         # at the end sums them all (ops.WgradPlan); the first step of an input shape runs the per-conv two-launch form and
         # records what the plan needs
         wkey = tuple(int(v) for v in x.shape)
-        wplan = self._wplans.get(wkey)
+        wplan = self._wplan_get(wkey)
         witems = []
 
         def wg(name, xt, gt, k, cin, cout, dy_coffset=0):
@@ -521,7 +541,7 @@ class SqueezeDetTrainer(_TrainerBase):
         if wplan is not None:
             wplan.reduce(gs)
         elif self.plan_wgrads:
-            self._wplans[wkey] = ops.WgradPlan(witems)
+            self._wplan_put(wkey, ops.WgradPlan(witems))
         out = collections.OrderedDict(class_loss=losses[0], conf_loss=losses[1], bbox_loss=losses[2], ious=ious, preds=preds,
                                       dpreds=dpreds, num_objects=num_objects)
         if keep_activations:
@@ -645,7 +665,7 @@ class ResNet50ConvDetTrainer(_TrainerBase):
         # land in self.dwf / self.dbf), then ONE fold backward; the first step of an input shape runs the per-conv
         # two-launch gradient and records what the plan needs
         wkey = tuple(int(v) for v in xb.shape)
-        wplan = self._wplans.get(wkey)
+        wplan = self._wplan_get(wkey)
         witems = []
 
         def wg(n, xt, gt, k, cin, cout):
@@ -703,7 +723,7 @@ class ResNet50ConvDetTrainer(_TrainerBase):
         if wplan is not None:
             wplan.reduce(gs)
         elif self.plan_wgrads:
-            self._wplans[wkey] = ops.WgradPlan(witems)
+            self._wplan_put(wkey, ops.WgradPlan(witems))
         self.foldplan.run()      # d(kernels), d(gamma), d(beta) of every conv_bn conv from its folded gradients: two launches
         out = collections.OrderedDict(class_loss=losses[0], conf_loss=losses[1], bbox_loss=losses[2], ious=ious, preds=preds,
                                       dpreds=dpreds, num_objects=num_objects)

@@ -141,6 +141,18 @@ def test_maxpool_window_index_forward_and_backward(dtype):
             got = ops.maxpool_bwd_idx(idx, y, dy, (H, W), 3, 2, pad, relu=relu)
             torch.cuda.synchronize()
             assert torch.equal(got, want), (N, H, W, C, pad, relu)
+    # a window whose valid cells are ALL -inf still names a cell (the first valid one), and its gradient lands there as in the
+    # x-searching kernel (round-3 ADVICE: the index used to stay 255 and the gradient went nowhere)
+    x = torch.from_numpy(rs.randn(1, 9, 11, ev).astype(np.float32)).to(DEV, dtype)
+    x[0, 0:4, 0:5, :] = float("-inf")
+    y, idx = ops.maxpool_nhwc_idx(x, 3, 2, "SAME")
+    assert torch.equal(y, ops.maxpool_nhwc(x, 3, 2, "SAME")) and bool(torch.isinf(y[0, 0, 0]).all())
+    assert int(idx.max()) < 9, "a window index was left unset"
+    pt, pl = max((y.shape[1] - 1) * 2 + 3 - 9, 0) // 2, max((y.shape[2] - 1) * 2 + 3 - 11, 0) // 2
+    first = next(t for t in range(9) if 0 <= 0 - pt + t // 3 and 0 <= 0 - pl + t % 3)
+    assert bool((idx[0, 0, 0] == first).all())
+    dy = torch.from_numpy(rs.randn(*y.shape).astype(np.float32)).to(DEV, dtype)
+    assert torch.equal(ops.maxpool_bwd_idx(idx, y, dy, (9, 11), 3, 2, "SAME", relu=False), ops.maxpool_bwd(x, dy, 3, 2, "SAME", relu=False))
 
 
 def test_fire_backward_channel_slices_and_accumulate():
