@@ -31,11 +31,11 @@ int stem_launch(const void* x, const void* w_packed, const float* bias, void* y,
   a.y_cstride = y_cstride; a.y_coffset = y_coffset;
   a.ws2 = nullptr; a.bs2 = nullptr; a.s_out = nullptr;
   if (a.Hp <= 0 || a.Wp <= 0) return SQDET_OK;
-  if (tune(TUNE_STEM_ALGO) == 0 || tune(TUNE_STEM_ALGO) == 4) {  // the phase kernel (stem4.hip; wide images only, else the kernels below)
+  if (tune(TUNE_STEM_ALGO) == 0 || tune(TUNE_STEM_ALGO) >= 4) {  // the phase kernel (stem4.hip; wide images only, else the kernels below)
     const int rc4 = stem_phase_launch(a, k, dtype, st, handled);
     if (rc4 != SQDET_OK || *handled) return rc4;
   }
-  if (tune(TUNE_STEM_ALGO) == 0 || tune(TUNE_STEM_ALGO) == 3 || tune(TUNE_STEM_ALGO) == 4) {  // default for the fp16 3x3 stem: the persistent kernel (stem3.hip)
+  if (tune(TUNE_STEM_ALGO) == 0 || tune(TUNE_STEM_ALGO) >= 3) {  // default for the fp16 3x3 stem: the persistent kernel (stem3.hip)
     const int rc3 = stem_pers_launch(a, k, dtype, st, handled);
     if (rc3 != SQDET_OK || *handled) return rc3;
   }
@@ -65,7 +65,7 @@ int stem_squeeze_launch(const void* x, const void* w_packed, const float* bias, 
   a.y_cstride = cout; a.y_coffset = 0;
   a.ws2 = ws2_packed; a.bs2 = bs2; a.s_out = s_out;
   if (a.Hp <= 0 || a.Wp <= 0) return SQDET_OK;
-  if (tune(TUNE_STEM_ALGO) == 0 || tune(TUNE_STEM_ALGO) == 4) {
+  if (tune(TUNE_STEM_ALGO) == 0 || tune(TUNE_STEM_ALGO) >= 4) {
     const int rc4 = stem_phase_launch(a, k, dtype, st, handled);
     if (rc4 != SQDET_OK || *handled) return rc4;
   }
