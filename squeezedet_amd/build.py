@@ -27,6 +27,7 @@ SOURCES = [
     ("convdet.hip", ["-ffp-contract=off"]),
     ("conv1x1.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("gemm1x1.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+    ("conv1x1k.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("stem.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("stem2.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("stem3.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),

@@ -352,6 +352,10 @@ int conv2d_launch_masked(const void* x, const void* w_packed, const float* bias,
     rc = conv1x1_stream_launch(a, g, dtype, st, &handled);
     if (rc != SQDET_OK || handled) return rc;
   }
+  if (plain) {       // deep-K 1x1 on large maps: weights resident in LDS, activations streamed once (conv1x1k.hip)
+    rc = conv1x1_deepk_launch(a, g, dtype, st, &handled);
+    if (rc != SQDET_OK || handled) return rc;
+  }
   if (!g.gather) {   // deep-K 1x1 (incl. the accumulating / sliced forms): workgroup GEMM tile, gemm1x1.hip
     rc = conv1x1_tile_launch(a, g, dtype, st, &handled);
     if (rc != SQDET_OK || handled) return rc;

@@ -1,0 +1,190 @@
+// Deep-K 1x1 convolution (+bias +ReLU) as a persistent STREAMING kernel for gfx950: the squeeze1x1 layers of fire5..fire11
+// (K = 256..768 channels -> 32..96 couts) and the other deep 1x1s of SqueezeDet+ / ResNet50 (reference src/nets/squeezeDet.py:95-100,
+// src/nn_skeleton.py:471-563).  These layers are purely HBM-bound -- 10-30 FLOP per byte, the matrix pipe has an hour to spare -- and
+// conv1x1_tile (gemm1x1.hip), which stages the ACTIVATIONS through LDS in 4-chunk stages behind barriers, ran them at about half of what a
+// plain copy of the same bytes reaches (profiles/r03_fire_1x1_standalone.txt).  Here the roles are swapped:
+//   * the WEIGHTS of the workgroup's cout group live in LDS for the kernel's life ([K chunk][tile][64 lanes][16 B]: <= 64 KiB), read as
+//     A fragments per MFMA (1 KiB per MFMA: the LDS has bandwidth to burn at this arithmetic intensity);
+//   * the activations are read EXACTLY ONCE, straight into B-fragment registers: a wave owns one 16-pixel block at a time and issues
+//     its loads in groups of KB = 8 chunks -- eight 16-byte loads in flight per lane, 8 KiB per wave, no LDS staging, no barrier in the
+//     loop; the next group's loads are issued before the current group's MFMAs (two register sets), the first group's before the
+//     weight copy; with 4 waves per SIMD the other waves' MFMAs and stores hide the rest of the latency;
+//   * persistent grid: ONE 16-wave workgroup per CU (the weight image is copied once per CU), waves grid-stride over the 16-pixel blocks,
+//     one cout group per workgroup.
+// Accumulation order per output = chunk ascending, as conv1x1_tile and the generic kernel: bitwise the same results.
+#include "conv_common.h"
+
+namespace sqdet {
+namespace {
+
+struct K1Args {
+  ConvArgs c;
+  int nblocks;     // 16-pixel blocks
+  int nchunk;      // 64-byte K chunks
+  int wgs_per_group;
+};
+
+constexpr int KB = 8;    // chunks per load group
+
+template <typename T, int NT, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void conv1x1_deepk(K1Args a) {
+  constexpr int KG = Tr<T>::KG;
+  constexpr int KC = 4 * KG;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int j = lane & 15, g = lane >> 4;
+  const int group = blockIdx.x / a.wgs_per_group, wg = blockIdx.x - group * a.wgs_per_group;
+  const int nchunk = a.nchunk;
+  const T* x = reinterpret_cast<const T*>(a.c.x);
+  T* y = reinterpret_cast<T*>(a.c.y);
+  const i32x4 zero = {0, 0, 0, 0};
+  const int stride = a.wgs_per_group * NWAVES;
+
+  // a load group = KB consecutive K chunks of one 16-pixel block; groups are walked block-major, the NEXT group's loads are issued
+  // before the current group's MFMAs (two register sets)
+  auto issue = [&](int blk, int c0, i32x4 (&bf)[KB]) {
+    const int p = blk * 16 + j;
+    const bool ok = p < a.c.P;
+    const T* src = x + (size_t)(ok ? p : 0) * a.c.Cin + g * KG;
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      const int c = c0 + u;
+      // (chunks past the last one and the channel padding of the last chunk read as zeros; the packed weights are zero there too)
+      bf[u] = (ok && c < nchunk && c * KC + g * KG < a.c.Cin) ? *reinterpret_cast<const i32x4*>(src + c * KC) : zero;
+    }
+  };
+  // two pointers walk the same sequence of groups: (ib, ic) = the next group to REQUEST, (cb_, cc_) = the next group to COMPUTE; two
+  // groups (16 loads per lane) are in flight ahead of the compute pointer, the first two ahead of the weight copy
+  int ib = wg * NWAVES + wave, ic = 0;
+  int cb_ = ib, cc_ = 0;
+  auto advance_issue = [&]() {
+    const bool last = ic + KB >= nchunk;
+    ib = last ? ib + stride : ib;
+    ic = last ? 0 : ic + KB;
+  };
+  i32x4 bfa[KB], bfb[KB];
+  if (ib < a.nblocks) { issue(ib, ic, bfa); advance_issue(); }
+  if (ib < a.nblocks) { issue(ib, ic, bfb); advance_issue(); }
+
+  // ---- the group's weights -> LDS (once) ----
+  {
+    const i32x4* src = reinterpret_cast<const i32x4*>(a.c.wp) + (size_t)group * nchunk * NT * 64;
+    for (int i = threadIdx.x; i < nchunk * NT * 64; i += NWAVES * 64) reinterpret_cast<i32x4*>(lds)[i] = src[i];
+  }
+  const int cb = group * 16 * NT + g * 4 * NT;          // this lane's 4*NT consecutive couts
+  f32x4 bias[NT];
+  int nt_valid = 0;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const bool ok = cb + t * 4 < a.c.Cout;
+    bias[t] = ok ? *reinterpret_cast<const f32x4*>(a.c.bias + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    nt_valid += ok ? 1 : 0;
+  }
+  __syncthreads();
+
+  const unsigned char* wl = lds + lane * 16;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto step = [&](i32x4 (&cur)[KB]) {
+    const bool last = cc_ + KB >= nchunk;
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      if (cc_ + u < nchunk) {                           // wave-uniform
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mma16<T>(acc[t], *reinterpret_cast<const i32x4*>(wl + ((cc_ + u) * NT + t) * 1024), cur[u]);
+      }
+    }
+    // the registers just consumed take the group two ahead
+    if (ib < a.nblocks) { issue(ib, ic, cur); advance_issue(); }
+    if (last) {
+      const int p = cb_ * 16 + j;
+      if (p < a.c.P) {
+        f32x4 v[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          v[t] = acc[t] + bias[t];
+          if (a.c.relu) {
+            v[t][0] = fmaxf(v[t][0], 0.f); v[t][1] = fmaxf(v[t][1], 0.f);
+            v[t][2] = fmaxf(v[t][2], 0.f); v[t][3] = fmaxf(v[t][3], 0.f);
+          }
+        }
+        store_couts<T, NT>(y + (size_t)p * a.c.y_cstride + a.c.y_coffset + cb, v, nt_valid);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    cb_ = last ? cb_ + stride : cb_;
+    cc_ = last ? 0 : cc_ + KB;
+  };
+  while (cb_ < a.nblocks) {
+    step(bfa);
+    if (cb_ >= a.nblocks) break;
+    step(bfb);
+  }
+}
+
+template <typename T, int NT>
+bool launch_k1(K1Args& a, int ngroups, hipStream_t st) {
+  // ONE 16-wave workgroup per CU: the weight image is copied once per CU, four waves per SIMD keep >= 16 KiB of loads per SIMD in flight
+  constexpr int NWAVES = 16;
+  const size_t lds = (size_t)a.nchunk * NT * 1024;
+  auto kern = &conv1x1_deepk<T, NT, NWAVES>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  // persistent grid: as many workgroups per CU as are RESIDENT together (registers, the LDS weight image, 32 waves), split over the
+  // cout groups
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NWAVES * 64, lds) != hipSuccess || per_cu < 1) {
+    (void)hipGetLastError();
+    return false;
+  }
+  int wgs = 256 * per_cu / ngroups;
+  const int need = (a.nblocks + NWAVES - 1) / NWAVES;
+  if (wgs > need) wgs = need;
+  if (wgs < 1) wgs = 1;
+  a.wgs_per_group = wgs;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(wgs * ngroups)), dim3(NWAVES * 64), lds, st, a);
+  return true;
+}
+
+template <typename T>
+bool dispatch_k1(K1Args& a, int nt, int ngroups, hipStream_t st) {
+  switch (nt) {
+    case 1: return launch_k1<T, 1>(a, ngroups, st);
+    case 2: return launch_k1<T, 2>(a, ngroups, st);
+    case 3: return launch_k1<T, 3>(a, ngroups, st);
+    case 4: return launch_k1<T, 4>(a, ngroups, st);
+    case 5: return launch_k1<T, 5>(a, ngroups, st);
+    case 6: return launch_k1<T, 6>(a, ngroups, st);
+    default: return false;
+  }
+}
+
+}  // namespace
+
+// Plain (no channel slice, no accumulate) 1x1 / stride-1 convs with 5..48 K chunks whose cout group's weights fit 152 KiB of LDS and
+// that have enough pixels to stream (>= 8192).  *handled = false: conv1x1_tile / the generic kernel take it.  ("dbg" 51: never)
+int conv1x1_deepk_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (conv_algo() != 0 || tune(TUNE_DBG) == 51) return SQDET_OK;
+  if (c.k != 1 || c.stride != 1 || c.pt != 0 || c.pl != 0 || g.gather || c.accum || c.relu_of) return SQDET_OK;
+  const int esz = dtype == SQDET_F16 ? 2 : 4;
+  if (c.x_coffset != 0 || c.x_cstride != c.Cin || (c.Cin * esz) % 16 != 0) return SQDET_OK;
+  if (g.nchunk < 5 || g.nchunk > 48 || (size_t)g.nchunk * g.nt * 1024 > 152 * 1024 || c.P < 8192) return SQDET_OK;
+  K1Args a;
+  a.c = c;
+  a.nblocks = (c.P + 15) / 16;
+  a.nchunk = g.nchunk;
+  const bool ok = dtype == SQDET_F16 ? dispatch_k1<f16>(a, g.nt, g.ngroups, st) : dispatch_k1<float>(a, g.nt, g.ngroups, st);
+  if (!ok) return SQDET_OK;
+  SQDET_CHECK_HIP(hipGetLastError());
+  *handled = true;
+  return SQDET_OK;
+}
+
+}  // namespace sqdet

@@ -132,5 +132,6 @@ int convdet_scored_launch(const void* x, const void* w_packed, const float* bias
                           int cin, int apg, int classes, int dtype, hipStream_t st);
 int conv1x1_stream_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);
 int conv1x1_tile_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);   // gemm1x1.hip
+int conv1x1_deepk_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);  // conv1x1k.hip
 
 }  // namespace sqdet

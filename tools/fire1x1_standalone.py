@@ -144,7 +144,13 @@ if __name__ == "__main__":
     ap.add_argument("--width", type=int, default=1242)
     ap.add_argument("--plan", default="")
     ap.add_argument("--summarize", nargs="+", default=None)
+    ap.add_argument("--opt", action="append", default=[], help="tuning knob name=value (sqdet_set_option), repeatable -- A/B")
     a = ap.parse_args()
+    if a.opt:
+        from squeezedet_amd import ops as _ops
+        for o in a.opt:
+            k, v = o.split("=")
+            _ops.set_option(k, int(v))
     if a.summarize:
         summarize(*a.summarize)
     else:
