@@ -109,8 +109,8 @@ def summarize(plan_path, trace_csv, fetch_csv=None, write_csv=None):
         f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
         assert len(f) == need and len(w) == need, (len(f), len(w), need)
         pmc = (f, w)
-    print("# The fire modules' 1x1 convs as STAND-ALONE launches (sqdet_conv2d_nhwc_fwd: conv1x1_stream for K <= 4 chunks, conv1x1_tile")
-    print("# beyond), batch 32, 375x1242, float16, one MI355X.  us = rocprofv3 --kernel-trace mean over the %d launches behind %d warm-up" % (ITERS, WARM))
+    print("# The fire modules' 1x1 convs as STAND-ALONE launches (sqdet_conv2d_nhwc_fwd: conv1x1_stream for K <= 4 chunks, the LDS-resident-weights")
+    print("# streaming kernel conv1x1_deepk beyond), batch 32, 375x1242, float16, one MI355X.  us = rocprofv3 --kernel-trace mean over the %d launches behind %d warm-up" % (ITERS, WARM))
     print("# ones, every launch on a different input copy (rotation > 333 MB: nothing survives in the 256 MiB Infinity Cache);")
     print("# alg = input + output + weights, each touched once; traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes) from separate")
     print("# rocprofv3 --pmc passes of the same command (gfx950 correction, MI355X_MICROARCH.md); frac = alg GB/s / 8000.")
