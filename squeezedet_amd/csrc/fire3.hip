@@ -359,7 +359,12 @@ __global__ __launch_bounds__((4 * NG / NTW) * RS * 64, WPS) void fire_dma(FireXA
         f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
         const int PLc = blk * 16 + j;
         const unsigned char* cb0 = ctile + PLc * 64 + ((g ^ ((PLc >> 1) & 3)) << 4);
-        const unsigned char* wb0 = ws2l + (t * 64 + lane) * 16;
+        // item t computes the 16 CONSECUTIVE couts [16t, 16t + 16): MFMA row i <-> cout 16t + i, so a pixel's four lane groups store 32
+        // contiguous bytes (whole 32-byte sectors; with the packing's own order -- a lane owning couts 4*NTS2*g + 4t.. -- the items of a
+        // pixel interleave 8-byte pieces written by different waves at different times, and the fabric saw the 96-byte rows of
+        // fire6's squeeze tensor twice).  The packed kernel keeps cout c in tile (c % (4 NTS2)) / 4, row 4 (c / (4 NTS2)) + c % 4.
+        const int cw = 16 * t + j;
+        const unsigned char* wb0 = ws2l + ((((cw % (4 * NTS2)) >> 2) * 64 + 4 * (cw / (4 * NTS2)) + (cw & 3) + 16 * g) * 16);
 #pragma unroll
         for (int q = 0; q < NQC; ++q)
           mma16<f16>(acc2, *reinterpret_cast<const i32x4*>(wb0 + q * NTS2 * 1024), *reinterpret_cast<const i32x4*>(cb0 + q * (CPIX * 64)));
@@ -373,7 +378,7 @@ __global__ __launch_bounds__((4 * NG / NTW) * RS * 64, WPS) void fire_dma(FireXA
           orow = oy0 + blk; ocol = ox; OH = a.H; OW = a.W;
           ok = orow < OH && ocol < OW;
         }
-        const int ch = g * 4 * NTS2 + t * 4;
+        const int ch = 16 * t + 4 * g;
         f32x4 v = acc2 + *reinterpret_cast<const f32x4*>(bl + 2 * a.E + ch);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
