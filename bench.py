@@ -494,6 +494,28 @@ def run_infer(args, rank, local_rank, world, device):
 
     probe_ms = plan.read_probe(args.steps)
     plan.set_probe(-1, 0)
+    lanes = 1 if args.no_pipeline else max(1, int(os.environ.get("SQDET_SERVE_LANES", "2")))
+    single = None
+    if lanes >= 2 and os.environ.get("SQDET_BENCH_NO_PROBE") != "1":
+        # the SAME dominant launch with ONE forward in flight (untimed second pass of the same K steps): under two lanes a launch
+        # shares the chip with the other lane's launches, so its wall-clock duration above is not the time the kernel needs
+        model.serve_lanes = 1
+        for i in range(4):
+            step(i)
+        model.flush_pipeline()
+        torch.cuda.synchronize()
+        plan.set_probe(dom, args.steps)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        model.flush_pipeline()
+        torch.cuda.synchronize()
+        single_step_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        sp = plan.read_probe(args.steps)
+        plan.set_probe(-1, 0)
+        model.serve_lanes = None
+        if sp:
+            single = (float(np.mean(sp)), single_step_ms)
     counts = np.asarray(out[4].cpu() if isinstance(out[4], torch.Tensor) else out[4])
     assert (counts >= 0).all() and (counts <= 64).all()
     if rank != 0:
@@ -519,6 +541,15 @@ def run_infer(args, rank, local_rank, world, device):
     roof["avg_launch_ms"] = round(avg_ms, 5)
     roof["algorithmic_bytes_per_launch"] = nbytes
     roof["algorithmic_flops_per_launch"] = flops
+    roof["concurrent_forwards"] = lanes
+    if lanes >= 2:
+        roof["note"] = ("measured live in the timed region, where TWO forwards are in flight on two HIP streams: the launch shares the "
+                        "chip with the other lane's launches, its duration is wall time -- `single_lane` is the same launch with one forward "
+                        "in flight (second, untimed pass of the same steps), `pipeline` the chip-level rate of the timed steps")
+        if single:
+            sl = launch_roofline(flops, nbytes, single[0], args.dtype)
+            sl.update(avg_launch_ms=round(single[0], 5), ms_per_step=round(single[1], 4))
+            roof["single_lane"] = sl
     # the next largest launches (several are within a microsecond of each other, so which one is "dominant" can change from
     # run to run): durations from the untimed survey = one forward at a time, nothing else on the chip
     order = [int(k) for k in np.argsort(ms0)[::-1] if int(k) != dom][:3]
@@ -534,10 +565,19 @@ def run_infer(args, rank, local_rank, world, device):
     res = result_head(args, value, world, elapsed, ranks_seen, devices, clocks)
     res["config"] = {"workload": "%s %s inference, batch=%d per GPU, synthetic %dx%d images (%d distinct batches in rotation), full hot "
                                  "path (forward + interpret_output + filter_prediction + filtered rows to pinned host memory), inputs "
-                                 "resident in HBM" % (args.arch, args.dtype, args.batch, args.width, args.height, nrot),
+                                 "resident in HBM%s" % (args.arch, args.dtype, args.batch, args.width, args.height, nrot,
+                                                     "; %d batches in flight (consecutive steps alternate between %d HIP streams)" % (lanes, lanes) if lanes >= 2 else ""),
                      "name": args.config, "global_batch": args.batch * world,
                      "parallelism": "dp%d (independent image shards, no collective)" % world}
     res["roofline"] = roof
+    # chip-level view of the timed steps: the forward's algorithmic flops over the step time, and the composite roofline -- the sum over
+    # the launches of max(bytes / 8 TB/s, flops / 2.5 PF/s) -- over the step time
+    fl_sum = float(sum(f for _, f, _ in layers))
+    comp = sum(max(b / (HBM_PEAK_GBS * 1e9), (f / (MFMA_F16_PEAK_TFLOPS * 1e12)) if args.dtype == "fp16" else 0.0) for _, f, b in layers)
+    step_s = elapsed / args.steps
+    res["pipeline"] = {"forwards_in_flight": lanes, "forward_gflop": round(fl_sum / 1e9, 2), "achieved_tflops": round(fl_sum / step_s / 1e12, 1),
+                       "frac_of_mfma_peak": round(fl_sum / step_s / 1e12 / MFMA_F16_PEAK_TFLOPS, 4) if args.dtype == "fp16" else None,
+                       "composite_roofline_ms": round(comp * 1e3, 4), "composite_roofline_frac": round(comp / step_s, 4)}
     res["box"] = box
     res["host_issue_ms_per_step"] = round(t_issued / args.steps * 1e3, 4)
     res["forward_launches_ms_sum"] = round(float(sum(ms0)), 4)
@@ -549,7 +589,21 @@ def run_infer(args, rank, local_rank, world, device):
     for i in range(args.steps):
         plan.forward(xs[i % nrot], pre)
     torch.cuda.synchronize()
-    res["forward_only_ms_per_step"] = round((time.perf_counter() - t1) / args.steps * 1e3, 4)
+    res["forward_only_ms_per_step"] = round((time.perf_counter() - t1) / args.steps * 1e3, 4)   # ONE forward in flight
+    if lanes == 2:
+        plans2 = [plan, model._native_plan(args.batch, 1)]
+        pres = [pre, torch.empty_like(pre)]
+        strs = [ln["stream"] for ln in model._lanes]          # (the serving lanes' own streams: idle here)
+        for i in range(2):
+            with torch.cuda.stream(strs[i]):
+                plans2[i].forward(xs[i], pres[i])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            with torch.cuda.stream(strs[i & 1]):
+                plans2[i & 1].forward(xs[i % nrot], pres[i & 1])
+        torch.cuda.synchronize()
+        res["forward_only_ms_per_step_two_lanes"] = round((time.perf_counter() - t1) / args.steps * 1e3, 4)
     res["score_epilogue"] = score_epilogue
     if score_bytes:
         res["roofline"]["score_bytes_in_conv12"] = score_bytes

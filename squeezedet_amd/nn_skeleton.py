@@ -94,7 +94,9 @@ class ModelSkeleton:
         self.activation_counter = [("input", mc.IMAGE_WIDTH * mc.IMAGE_HEIGHT * 3)]
         self._packed = {}
         self._scope = []                          # tf.variable_scope stack
-        self._plan = None
+        # native plans: [0] = the model's plan; [1] = the second serving lane's (detect_filter_pipelined, two batches in flight).
+        # A plan is stale when its parameter version is behind the model's (`_plan_stale = True` bumps the model's)
+        self._plans, self._plan_ver, self._param_version = {}, {}, 0
         self._plan_stale = True
         self._anchors_f32 = None
         self.caffemodel_weight = None
@@ -282,21 +284,38 @@ class ModelSkeleton:
         return self._packed[name]
 
     # ------------------------------------------------------------------ execution
-    def _native_plan(self, batch):
-        if self._plan is None or self._plan.batch != batch:
+    @property
+    def _plan_stale(self):
+        return self._plan_ver.get(0) != self._param_version
+
+    @_plan_stale.setter
+    def _plan_stale(self, stale):
+        if stale:
+            self._param_version += 1            # every plan (both serving lanes) re-reads the variables at its next use
+        else:
+            self._plan_ver[0] = self._param_version
+
+    @property
+    def _plan(self):
+        return self._plans.get(0)
+
+    def _native_plan(self, batch, which=0):
+        plan = self._plans.get(which)
+        if plan is None or plan.batch != batch:
             mc = self.mc
-            self._plan = ops.NetPlan(self.NATIVE_ARCH, self.dtype, batch, mc.IMAGE_HEIGHT, mc.IMAGE_WIDTH, mc.CLASSES,
-                                     mc.ANCHOR_PER_GRID, self.device)
-            self._plan.set_bn_epsilon(mc.BATCH_NORM_EPSILON)
-            self._plan_stale = True
-        if self._plan_stale:
-            specs = dict(self._plan.param_specs())
+            plan = ops.NetPlan(self.NATIVE_ARCH, self.dtype, batch, mc.IMAGE_HEIGHT, mc.IMAGE_WIDTH, mc.CLASSES,
+                               mc.ANCHOR_PER_GRID, self.device)
+            plan.set_bn_epsilon(mc.BATCH_NORM_EPSILON)
+            self._plans[which] = plan
+            self._plan_ver[which] = None
+        if self._plan_ver.get(which) != self._param_version:
+            specs = dict(plan.param_specs())
             if set(specs) != set(self.params):
                 raise SqdetError("native plan parameters do not match the python graph")
             for name, t in self.params.items():
-                self._plan.set_param(name, t)
-            self._plan_stale = False
-        return self._plan
+                plan.set_param(name, t)
+            self._plan_ver[which] = self._param_version
+        return plan
 
     def _to_input(self, value):
         x = value if isinstance(value, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(value, dtype=np.float32)))
@@ -439,21 +458,77 @@ class ModelSkeleton:
         tensors are this call's, complete after the NEXT call (or flush_pipeline()) and a synchronisation of the caller's
         stream.  (SQDET_POST_DEFER=signal: the previous form -- the side stream's launch gated on a mid-forward event.)"""
         with torch.cuda.device(self.device):
-            return self._detect_filter_pipelined(images, to_host, defer)
+            lanes = self._serving_lanes(defer)
+            if lanes is None:
+                return self._detect_filter_pipelined(images, to_host, defer)
+            # TWO batches in flight (round 4): consecutive calls alternate between two LANES -- each with its own plan (workspace),
+            # HIP stream and pipeline slots -- and nothing orders the lanes against each other.  Every launch of the forward is one
+            # wave of persistent workgroups: its ramp and its tail leave CUs idle that the other lane's launch fills (forward only,
+            # same box: 0.389 against 0.475 ms per 32-image batch).  A lane starts behind the caller's stream (the input may have
+            # been produced there); the results of a call are complete after the second-next call or flush_pipeline().
+            lane = lanes[self._lane_next % len(lanes)]
+            self._lane_next = (self._lane_next + 1) % len(lanes)
+            cur = torch.cuda.current_stream()
+            lane["in_ev"].record(cur)
+            with torch.cuda.stream(lane["stream"]), self._lane_state(lane):
+                lane["stream"].wait_event(lane["in_ev"])
+                out = self._detect_filter_pipelined(images, to_host, defer)
+                if isinstance(images, torch.Tensor) and images.is_cuda:
+                    images.record_stream(lane["stream"])
+            return out
+
+    @contextlib.contextmanager
+    def _lane_state(self, lane):
+        """The pipeline state (_pipe, post_stream, _post_event, which plan) of `lane` installed for the duration of a call."""
+        saved = (getattr(self, "_pipe", None), getattr(self, "post_stream", None), getattr(self, "_post_event", None))
+        self._pipe, self.post_stream, self._post_event = lane["pipe"], lane["post_stream"], lane["post_event"]
+        self._lane_plan = lane["which"]
+        try:
+            yield
+        finally:
+            lane["pipe"], lane["post_stream"], lane["post_event"] = self._pipe, self.post_stream, self._post_event
+            self._lane_plan = 0
+            self._pipe, self.post_stream, self._post_event = saved
+
+    def _serving_lanes(self, defer):
+        """The serving lanes of detect_filter_pipelined (None: single-lane operation).  Used for deferred (rider) steps on native
+        plans; SQDET_SERVE_LANES=n (default 2; 1 = off, 3 measured no better: bench.py's A/B)."""
+        n = getattr(self, "serve_lanes", None)          # (attribute: set by a caller that measures both forms in one process)
+        if n is None:
+            n = int(os.environ.get("SQDET_SERVE_LANES", "2"))
+        if not defer or self.NATIVE_ARCH is None or n < 2:
+            return None
+        if getattr(self, "_lanes", None) is None or len(self._lanes) != n:
+            if getattr(self, "_lanes", None) is not None:
+                self.flush_pipeline()
+            self._lanes = [dict(which=k, stream=torch.cuda.Stream(device=self.device), in_ev=torch.cuda.Event(), pipe=None, post_stream=None,
+                                post_event=None) for k in range(n)]
+            self._lane_next = 0
+        return self._lanes
 
     def flush_pipeline(self):
-        """defer=True: enqueue the side work of the last call now (nothing to overlap it with)."""
+        """defer=True: enqueue the side work of the last call(s) now (nothing to overlap it with); the caller's stream then waits
+        for the serving lanes."""
         with torch.cuda.device(self.device):
-            pipe = getattr(self, "_pipe", None)
-            if pipe is not None and pipe.get("pending") is not None:
-                s = pipe["pending"]
-                if s.get("ride"):       # same stream as the forward: stream order is all the synchronisation there is
-                    cur = torch.cuda.current_stream()
-                    s["fwd_done"].record(cur)
-                    self._enqueue_post(s, None, stream=cur)
-                else:
-                    self._enqueue_post(s, None)
-                pipe["pending"] = None
+            lanes = getattr(self, "_lanes", None)
+            if lanes is not None:
+                cur = torch.cuda.current_stream()
+                for lane in lanes:
+                    with torch.cuda.stream(lane["stream"]), self._lane_state(lane):
+                        self._flush_pipe(self._pipe)
+                    cur.wait_stream(lane["stream"])
+            self._flush_pipe(getattr(self, "_pipe", None))
+
+    def _flush_pipe(self, pipe):
+        if pipe is not None and pipe.get("pending") is not None:
+            s = pipe["pending"]
+            if s.get("ride"):       # same stream as the forward: stream order is all the synchronisation there is
+                cur = torch.cuda.current_stream()
+                s["fwd_done"].record(cur)
+                self._enqueue_post(s, None, stream=cur)
+            else:
+                self._enqueue_post(s, None)
+            pipe["pending"] = None
 
     def _enqueue_post(self, s, gate, stream=None):
         """Decode + filter + row copy of slot s on the side stream, behind its forward (and `gate`, an event of a later forward)."""
@@ -492,7 +567,7 @@ class ModelSkeleton:
         if self.NATIVE_ARCH is not None:
             x = self._to_input(images)
             B = int(x.shape[0])
-            plan = self._native_plan(B)
+            plan = self._native_plan(B, getattr(self, "_lane_plan", 0))
             if self._pipe is None or self._pipe["batch"] != B:
                 self.flush_pipeline()
                 A = mc.ANCHORS

@@ -252,15 +252,19 @@ def test_pipelined_step_equals_sequential():
                 assert torch.equal(got[t][i, :n[i]], want[t][i, :n[i]])
 
 
+@pytest.mark.parametrize("lanes", [2, 1])
 @pytest.mark.parametrize("mode", ["ride", "signal"])
 @pytest.mark.parametrize("batch", [32, 5])
-def test_deferred_pipelined_step_equals_sequential(mode, batch, monkeypatch):
+def test_deferred_pipelined_step_equals_sequential(mode, batch, lanes, monkeypatch):
     """defer=True (bench.py's step): the decode + filter of call k is carried out by call k+1 -- "ride": as rider workgroups
     of that forward's fire_chain launches (sqdet_net_set_post_job: same stream, rows written straight to pinned host
     memory; 512-thread form of the filter body); "signal": on the side stream behind that forward's mid-point event, the
     images walked by 16 workgroups -- and flush_pipeline() carries out the last one.  Every step's rows, read after the
-    NEXT call (or the flush), equal detect -> filter_prediction_batch exactly."""
+    NEXT call (or the flush), equal detect -> filter_prediction_batch exactly.  lanes = 2 (the default since round 4): consecutive
+    calls alternate between two serving lanes (two plans, two HIP streams, nothing ordering them), so a call's rows are carried out
+    by the SECOND-next call (the next one of its lane) -- read there, they must be the same."""
     monkeypatch.setenv("SQDET_POST_DEFER", mode)
+    monkeypatch.setenv("SQDET_SERVE_LANES", str(lanes))
     m, mc, params, storage = _model("squeezeDet", torch.float16, batch, (375, 1242))
     xs = [O.synthetic_images(batch, 375, 1242, seed=s, storage=storage).to(DEV, torch.float16) for s in (3, 4, 5)]
     seq = []
@@ -270,16 +274,16 @@ def test_deferred_pipelined_step_equals_sequential(mode, batch, monkeypatch):
     torch.cuda.synchronize()
     plan = m._native_plan(batch)
     assert plan.overlap_layer() >= 0 and plan.scores_supported() and plan.rider_capacity() >= batch
-    outs, prev = [], None
+    outs, hist = [], []
     for x in xs + xs:
-        out = m.detect_filter_pipelined(x, to_host=True, defer=True)
-        if prev is not None:                                    # the previous call's rows: enqueued by THIS call
+        hist.append(m.detect_filter_pipelined(x, to_host=True, defer=True))
+        if len(hist) > lanes:                                   # the rows of the call `lanes` back: enqueued by THIS call
             torch.cuda.synchronize()
-            outs.append([t.clone() for t in prev])
-        prev = out
+            outs.append([t.clone() for t in hist[-1 - lanes]])
     m.flush_pipeline()
     torch.cuda.synchronize()
-    outs.append([t.clone() for t in prev])
+    for out in hist[-lanes:]:
+        outs.append([t.clone() for t in out])
     seq = seq + seq
     assert len(outs) == 6
     for got, want in zip(outs, seq):

@@ -21,6 +21,12 @@ python $R/bench.py --no-cpu-baseline --layer-table $OUT/layer_table.json > /dev/
 rocprofv3 --kernel-trace --stats -d $OUT/kstats -o ks --output-format csv -- python $R/bench.py --no-cpu-baseline > $OUT/kstats.log 2>&1
 FP=$(cd $R && python -c "import bench; print(bench.build_fingerprint())")
 python $R/profiles/summarize.py $(find $OUT/kstats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline" $FP >> $OUT/kstats.log 2>&1
+# 2a. the same command with ONE forward in flight (SQDET_SERVE_LANES=1): per-launch durations without the other lane's launches
+# sharing the chip -- what the per-launch roofline table is computed from
+SQDET_SERVE_LANES=1 rocprofv3 --kernel-trace --stats -d $OUT/kstats1 -o ks --output-format csv -- python $R/bench.py --no-cpu-baseline > $OUT/kstats1.log 2>&1
+python $R/profiles/summarize.py $(find $OUT/kstats1 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_1lane.txt "SQDET_SERVE_LANES=1 rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline" $FP >> $OUT/kstats1.log 2>&1
+SQDET_SERVE_LANES=1 python $R/bench.py --no-cpu-baseline > $OUT/bench_sqdet_infer_1lane.json 2>> $OUT/bench_sqdet_infer.err
+rm -rf $OUT/kstats1
 if [ "${FAST:-0}" != "1" ]; then
 # 2b. kernel stats of the other configs (which kernels carry SqueezeDet+, ResNet50 inference and the two training steps)
 for c in sqdetplus_infer sqdet_train_fp32 res50_train_fp16 sqdet_train_fp16; do

@@ -13,17 +13,24 @@ HBM, MFMA = 8000.0, 2500.0
 lt = json.load(open(P("layer_table.json")))
 pm = json.load(open(P("hbm_traffic_pmc.json")))
 kname = {k["layer"]: k["kernel"] for k in pm["kernels"]}
-stats = {}
-for line in open(P("kernel_stats.txt")):
-    if line.startswith(("#", "kernel ")) or len(line) < 100:
-        continue
-    stats[line[:88].rstrip()] = float(line[90:].split()[2])
+def load_stats(path):
+    out = {}
+    for line in open(path):
+        if line.startswith(("#", "kernel ")) or len(line) < 100:
+            continue
+        out[line[:88].rstrip()] = float(line[90:].split()[2])
+    return out
+
+
+stats2 = load_stats(P("kernel_stats.txt"))                       # the benchmarked step: two forwards in flight
+stats = load_stats(P("kernel_stats_1lane.txt")) if os.path.exists(P("kernel_stats_1lane.txt")) else stats2
 b = json.loads(open(P("bench_sqdet_infer.json")).read().strip().splitlines()[-1])
+b1 = json.loads(open(P("bench_sqdet_infer_1lane.json")).read().strip().splitlines()[-1]) if os.path.exists(P("bench_sqdet_infer_1lane.json")) else None
 print("(`profiles/%s_*`, one collection of build `%s` on a %s MHz box, `box_mfma_tflops` %s; in-step = rocprofv3 kernel trace of"
       % (tag, lt["build_fingerprint"], b["clocks"]["before"].get("gfxclk_mhz"), (b.get("box") or {}).get("box_mfma_tflops")))
 print("`bench.py`, alone = HIP events around single launches; frac = of 8 TB/s or of the 2.5 PF/s dense fp16 peak, whichever bounds the launch by intensity)\n")
-print("| launch | µs in-step | µs alone | alg MB | traffic MB | GFLOP | bound | frac (in-step) |")
-print("|---|---|---|---|---|---|---|---|")
+print("| launch | µs in-step, one forward in flight | µs in the two-lane step (wall) | µs alone | alg MB | traffic MB | GFLOP | bound | frac (one in flight) |")
+print("|---|---|---|---|---|---|---|---|---|")
 tot = 0.0
 for l in lt["layers"]:
     k = kname[l["layer"]][:88].rstrip()
@@ -34,11 +41,14 @@ for l in lt["layers"]:
     t = us if us else l["ms"] * 1e3
     frac = (l["flops"] / (t * 1e-6) / 1e12 / MFMA) if bound == "MFMA" else (l["bytes"] / (t * 1e-6) / 1e9 / HBM)
     tot += t
-    print("| %s | %s%s | %.1f | %.0f | %.0f | %.1f | %s | %.3f |" % (l["layer"], "%.1f" % us if us else "—", " (mean of %d launches)" % shared if shared > 1 else "",
-                                                                  l["ms"] * 1e3, l["bytes"] / 1e6, pm["by_layer"][l["layer"]] / 1e6, l["flops"] / 1e9, bound, frac))
-print("| **sum** | **%.0f** | %.0f | %.0f | %.0f | %.0f | | step %.4f ms = %.1f k img/s |" % (
-    tot, lt["forward_ms_sum"] * 1e3, sum(l["bytes"] for l in lt["layers"]) / 1e6, sum(pm["by_layer"].values()) / 1e6,
-    sum(l["flops"] for l in lt["layers"]) / 1e9, b["ms_per_step"], b["value"] / 1e3))
+    print("| %s | %s%s | %s | %.1f | %.0f | %.0f | %.1f | %s | %.3f |" % (l["layer"], "%.1f" % us if us else "—", " (mean of %d launches)" % shared if shared > 1 else "",
+                                                                       "%.1f" % stats2[k] if k in stats2 else "—", l["ms"] * 1e3, l["bytes"] / 1e6,
+                                                                       pm["by_layer"][l["layer"]] / 1e6, l["flops"] / 1e9, bound, frac))
+print("| **sum** | **%.0f**%s | step %.4f ms = %.1f k img/s | %.0f | %.0f | %.0f | %.0f | | |" % (
+    tot, " (step %.4f ms = %.1f k img/s)" % (b1["ms_per_step"], b1["value"] / 1e3) if b1 else "", b["ms_per_step"], b["value"] / 1e3,
+    lt["forward_ms_sum"] * 1e3, sum(l["bytes"] for l in lt["layers"]) / 1e6, sum(pm["by_layer"].values()) / 1e6, sum(l["flops"] for l in lt["layers"]) / 1e9))
+if b.get("pipeline"):
+    print("\nchip-level (`pipeline` of the bench line): %s" % json.dumps(b["pipeline"]))
 print()
 print("| config | value | ms/step | box (MFMA TF/s, clock) | note |")
 print("|---|---|---|---|---|")
