@@ -21,6 +21,8 @@ Inference shards by image (weak scaling, no data-path collective); training all-
 --gpus N > 1 without a torchrun environment re-launches this script under torch.distributed.run with N local ranks.
 --dry-run: no kernels, no GPU: the launcher, rendezvous (gloo), barrier and max-over-ranks timing only (CI on a CPU box).
 Every step reads a DIFFERENT input batch from a rotation larger than the 256 MiB Infinity Cache.
+Inference steps keep TWO batches in flight (consecutive steps alternate between two HIP streams / plans; SQDET_SERVE_LANES=1: one):
+all K batches' work is inside the timed region, which ends with flush_pipeline() + a device-wide synchronize.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -224,7 +226,7 @@ def pmc_traffic(config_name, layer):
     return best
 
 
-def rocprof_launch_ms(traffic_profile, layer):
+def rocprof_launch_ms(traffic_profile, layer, stats_suffix="_kernel_stats.txt"):
     """Average duration of `layer`'s kernel in the rocprofv3 --kernel-trace --stats summary committed beside the fingerprinted
     PMC profile (same collection: profiles/<tag>_kernel_stats.txt next to profiles/<tag>_hbm_traffic_pmc.json), or None.  The
     summary must carry the same build fingerprint in its header; the layer -> kernel name map is the PMC profile's."""
@@ -234,7 +236,7 @@ def rocprof_launch_ms(traffic_profile, layer):
             d = json.load(fh)
         kname = next(k["kernel"] for k in d["kernels"] if k["layer"] == layer)
         shared = sum(1 for k in d["kernels"] if k["kernel"] == kname)
-        stats = traffic_profile.replace("_hbm_traffic_pmc.json", "_kernel_stats.txt")
+        stats = traffic_profile.replace("_hbm_traffic_pmc.json", stats_suffix)
         fp_ok, avg = False, None
         with open(os.path.join(prof, stats)) as fh:
             for line in fh:
@@ -549,6 +551,10 @@ def run_infer(args, rank, local_rank, world, device):
         if single:
             sl = launch_roofline(flops, nbytes, single[0], args.dtype)
             sl.update(avg_launch_ms=round(single[0], 5), ms_per_step=round(single[1], 4))
+            rp1 = rocprof_launch_ms(tr[1], name, "_kernel_stats_1lane.txt") if tr else None
+            if rp1:      # the committed SQDET_SERVE_LANES=1 kernel trace of this build
+                sl.update(rocprof_avg_launch_ms=rp1["ms"], rocprof_profile=rp1["profile"],
+                          rocprof_frac=launch_roofline(flops, nbytes, rp1["ms"], args.dtype)["frac"])
             roof["single_lane"] = sl
     # the next largest launches (several are within a microsecond of each other, so which one is "dominant" can change from
     # run to run): durations from the untimed survey = one forward at a time, nothing else on the chip
