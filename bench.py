@@ -585,6 +585,8 @@ def run_infer(args, rank, local_rank, world, device):
                        "frac_of_mfma_peak": round(fl_sum / step_s / 1e12 / MFMA_F16_PEAK_TFLOPS, 4) if args.dtype == "fp16" else None,
                        "composite_roofline_ms": round(comp * 1e3, 4), "composite_roofline_frac": round(comp / step_s, 4)}
     res["box"] = box
+    if getattr(model, "_lane_check", None):
+        res["pipeline"]["lane_stream_check"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in model._lane_check.items()}
     res["host_issue_ms_per_step"] = round(t_issued / args.steps * 1e3, 4)
     res["forward_launches_ms_sum"] = round(float(sum(ms0)), 4)
     # diagnostic, outside the timed region: the same K forwards back to back WITHOUT decode / filter / D2H -- what the

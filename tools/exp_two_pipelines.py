@@ -52,3 +52,16 @@ for _ in range(2):
     run(1); run(2)
 for rep in range(3):
     print("one stream: %.4f ms per forward   two streams: %.4f ms per forward" % (run(1), run(2)), flush=True)
+# does the PAIR of streams matter (hardware-queue assignment)?  Later streams of torch's pool, and explicitly prioritised ones
+pool = [torch.cuda.Stream() for _ in range(10)]
+for a, b in ((0, 1), (2, 3), (4, 5), (6, 7), (8, 9), (0, 5), (1, 8)):
+    streams[0], streams[1] = pool[a], pool[b]
+    run(2)
+    print("pool streams (%d, %d): %.4f ms per forward" % (a, b, run(2)), flush=True)
+hp = [torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1)]
+streams[0], streams[1] = hp
+run(2)
+print("two high-priority streams: %.4f ms per forward" % run(2))
+streams[0], streams[1] = torch.cuda.current_stream(), pool[0]
+run(2)
+print("default stream + one pool stream: %.4f ms per forward" % run(2))
