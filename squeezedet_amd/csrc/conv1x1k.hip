@@ -138,10 +138,19 @@ bool launch_k1(K1Args& a, int ngroups, hipStream_t st) {
   }
   // persistent grid: as many workgroups per CU as are RESIDENT together (registers, the LDS weight image, 32 waves), split over the
   // cout groups
+  // (asked once per LDS size and instantiation: the query costs tens of microseconds of host time)
+  static size_t cached_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static int cached_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NWAVES * 64, lds) != hipSuccess || per_cu < 1) {
-    (void)hipGetLastError();
-    return false;
+  for (int i = 0; i < 8; ++i)
+    if (cached_n[i] > 0 && cached_lds[i] == lds) per_cu = cached_n[i];
+  if (per_cu == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NWAVES * 64, lds) != hipSuccess || per_cu < 1) {
+      (void)hipGetLastError();
+      return false;
+    }
+    for (int i = 0; i < 8; ++i)
+      if (cached_n[i] == 0) { cached_lds[i] = lds; cached_n[i] = per_cu; break; }
   }
   int wgs = 256 * per_cu / ngroups;
   const int need = (a.nblocks + NWAVES - 1) / NWAVES;
