@@ -457,7 +457,12 @@ class ModelSkeleton:
         launch was placed (side stream, same stream, with or without the score kernel, beside the stem or beside the
         fire_chain launches) -- whereas the six fire_chain launches occupy 240 of the 256 CUs at batch 32.  The returned
         tensors are this call's, complete after the NEXT call (or flush_pipeline()) and a synchronisation of the caller's
-        stream.  (SQDET_POST_DEFER=signal: the previous form -- the side stream's launch gated on a mid-forward event.)"""
+        stream.  (SQDET_POST_DEFER=signal: the previous form -- the side stream's launch gated on a mid-forward event.)
+
+        Since round 4 deferred calls on native plans keep TWO batches in flight: consecutive calls alternate between two serving
+        LANES (each its own plan = workspace, HIP stream and pipeline slots; SQDET_SERVE_LANES=1: one lane, the round-3 behaviour),
+        so a call's rows are complete after the SECOND-next call -- the next one of its lane -- or after flush_pipeline(), which
+        also makes the caller's stream wait for the lanes."""
         with torch.cuda.device(self.device):
             lanes = self._serving_lanes(defer)
             if lanes is None:
