@@ -303,3 +303,49 @@ def test_one_hip_runtime_whatever_the_import_order():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.strip().splitlines()[-1] == "1", r.stdout
+
+
+def test_bench_rocprof_launch_ms_reads_only_a_fingerprinted_profile(tmp_path, monkeypatch):
+    """bench.rocprof_launch_ms: a kernel's average duration is quoted from profiles/<tag>_kernel_stats(_1lane).txt only when that
+    summary carries the SAME build fingerprint as the PMC profile next to it; the layer -> kernel map is the PMC profile's."""
+    import json
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    kname = "void sqdet::convdet_dma_kernel<true>(sqdet::TileArgs, int, int)"
+    (prof / "rX_hbm_traffic_pmc.json").write_text(json.dumps({
+        "build_fingerprint": "abc", "config": "sqdet_infer", "by_layer": {"conv12": 1},
+        "kernels": [{"layer": "conv12", "kernel": kname}, {"layer": "fire7", "kernel": "k2"}, {"layer": "fire8", "kernel": "k2"}]}))
+    row = "%-90s %7d %12.1f %10.2f %7.2f\n"
+    (prof / "rX_kernel_stats.txt").write_text("# x\n# build_fingerprint: abc\n" + row % ("kernel", 0, 0, 0, 0) + row % (kname[:90], 100, 8800.0, 88.0, 10.0)
+                                              + row % ("k2", 200, 5000.0, 25.0, 5.0))
+    (prof / "rX_kernel_stats_1lane.txt").write_text("# x\n# build_fingerprint: OTHER\n" + row % (kname[:90], 100, 6000.0, 60.0, 10.0))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    got = bench.rocprof_launch_ms("rX_hbm_traffic_pmc.json", "conv12")
+    assert got == {"ms": 0.088, "profile": "rX_kernel_stats.txt", "kernel_shared_by_launches": 1}
+    assert bench.rocprof_launch_ms("rX_hbm_traffic_pmc.json", "fire7")["kernel_shared_by_launches"] == 2
+    assert bench.rocprof_launch_ms("rX_hbm_traffic_pmc.json", "conv12", "_kernel_stats_1lane.txt") is None     # another build's trace
+    assert bench.rocprof_launch_ms("rX_hbm_traffic_pmc.json", "nope") is None
+    assert bench.rocprof_launch_ms("missing.json", "conv12") is None
+
+
+def test_serving_lane_state_is_swapped_and_restored():
+    """ModelSkeleton._lane_state (the two-batches-in-flight serving loop): the pipeline state of a lane is installed for the duration
+    of a call and written back, the single-lane state is restored afterwards -- also when the call raises."""
+    from squeezedet_amd.nn_skeleton import ModelSkeleton
+
+    class M(ModelSkeleton):
+        def __init__(self):          # (no device, no graph: only the attributes _lane_state touches)
+            self._pipe, self.post_stream, self._post_event = "P0", "S0", "E0"
+    m = M()
+    lane = dict(which=1, pipe=None, post_stream=None, post_event=None)
+    with m._lane_state(lane):
+        assert (m._pipe, m.post_stream, m._post_event, m._lane_plan) == (None, None, None, 1)
+        m._pipe, m.post_stream, m._post_event = "P1", "S1", "E1"           # what the first call of a lane creates
+    assert (lane["pipe"], lane["post_stream"], lane["post_event"]) == ("P1", "S1", "E1")
+    assert (m._pipe, m.post_stream, m._post_event, m._lane_plan) == ("P0", "S0", "E0", 0)
+    with pytest.raises(RuntimeError):
+        with m._lane_state(lane):
+            m._pipe = "P2"
+            raise RuntimeError("boom")
+    assert lane["pipe"] == "P2" and m._pipe == "P0" and m._lane_plan == 0
