@@ -552,8 +552,9 @@ class ModelSkeleton:
         if getattr(self, "_lanes", None) is None or len(self._lanes) != n:
             if getattr(self, "_lanes", None) is not None:
                 self.flush_pipeline()
-            self._lanes = [dict(which=k, stream=torch.cuda.Stream(device=self.device), in_ev=torch.cuda.Event(), pipe=None, post_stream=None,
-                                post_event=None) for k in range(n)]
+            prio = [int(v) for v in os.environ.get("SQDET_LANE_PRIORITIES", "").split(",") if v] + [0] * n      # (experiments)
+            self._lanes = [dict(which=k, stream=torch.cuda.Stream(device=self.device, priority=prio[k]), in_ev=torch.cuda.Event(), pipe=None,
+                                post_stream=None, post_event=None) for k in range(n)]
             self._lane_next = 0
         return self._lanes
 
