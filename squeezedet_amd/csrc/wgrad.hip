@@ -239,8 +239,49 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile(WgArgs a) {
 // trips: 15 us per launch, 31 launches = 0.48 ms of a 3.8 ms mixed-precision SqueezeDet step.)
 __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ dbias,
                                                  const float* __restrict__ w, float decay, float scale, size_t count, int cout,
-                                                 size_t stride, int nslabs, unsigned block, unsigned nblocks) {
+                                                 size_t stride, int nslabs, unsigned block, unsigned nblocks, int wide_ok) {
   const size_t total = count + (dbias ? (size_t)cout : 0);
+  // Large gradients with few slabs (ResNet50's res4: 0.26 - 0.59 M elements, 8 - 16 slabs; the 4-lane form above reads 64-byte
+  // pieces of four slabs per wave instruction and ran this reduction at 1.7 TB/s): one thread per FOUR consecutive elements, all
+  // slabs as independent 16-byte loads, combined in exactly the order of the 4-lane form (lane q's slabs q, q + 4, ..; then
+  // (q0 + q1) + (q2 + q3)) -- the same bits.
+  if (wide_ok && nslabs <= 16 && total >= 65536 && ((count | stride | (size_t)cout) & 3) == 0 && (reinterpret_cast<uintptr_t>(partial) & 15) == 0) {
+    const size_t n4 = total >> 2, nthr4 = (size_t)nblocks * blockDim.x;
+    for (size_t e4 = (size_t)block * blockDim.x + threadIdx.x; e4 < n4; e4 += nthr4) {
+      const size_t e = e4 << 2;
+      f32x4 p[16];
+#pragma unroll
+      for (int z = 0; z < 16; ++z)
+        p[z] = z < nslabs ? *reinterpret_cast<const f32x4*>(partial + (size_t)z * stride + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool is_w = e < count;
+      float* dst = is_w ? dw + e : dbias + (e - count);
+      float out[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float sq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // (absent slabs leave the 4-lane form's accumulators at +0: `0.f + x` and `+ 0.f` are kept, they turn -0 into +0)
+          const float a0 = 0.f + p[q][c];
+          const float a1 = q + 4 < nslabs ? 0.f + p[q + 4][c] : 0.f;
+          const float a2 = q + 8 < nslabs ? 0.f + p[q + 8][c] : 0.f;
+          const float a3 = q + 12 < nslabs ? 0.f + p[q + 12][c] : 0.f;
+          sq[q] = ((a0 + a1) + (a2 + a3)) + 0.f;
+          if (q >= nslabs) sq[q] = 0.f;
+        }
+        float s = (sq[0] + sq[1]) + (sq[2] + sq[3]);
+        s *= scale;
+        if (is_w && w) s += decay * w[e + c];
+        out[c] = s;
+      }
+      if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{out[0], out[1], out[2], out[3]};
+      } else {
+        dst[0] = out[0]; dst[1] = out[1]; dst[2] = out[2]; dst[3] = out[3];
+      }
+    }
+    return;
+  }
   const int q = threadIdx.x & 3;
   const size_t nthr = (size_t)nblocks * (blockDim.x >> 2);
   // every lane of a 4-lane group runs the same trip count (the shuffles below are wave-wide): elements rounded up per group
@@ -273,8 +314,8 @@ __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ parti
 
 __global__ void slab_reduce2_kernel(const float* __restrict__ partial, float* __restrict__ dw, float* __restrict__ dbias,
                                     const float* __restrict__ w, float decay, float scale, size_t count, int cout,
-                                    size_t stride, int nslabs) {
-  slab_reduce_body(partial, dw, dbias, w, decay, scale, count, cout, stride, nslabs, blockIdx.x, gridDim.x);
+                                    size_t stride, int nslabs, int wide_ok) {
+  slab_reduce_body(partial, dw, dbias, w, decay, scale, count, cout, stride, nslabs, blockIdx.x, gridDim.x, wide_ok);
 }
 
 // The slab reductions of MANY backward-filter launches in one launch (a training step's 31: each was a launch of its own
@@ -289,6 +330,7 @@ struct ReduceItem {
   float decay;
   int cout, nslabs;
   unsigned first_block, nblocks;
+  int wide_ok;      // the four-elements-per-thread form may be used ("dbg" 52: never -- the A/B of the two forms' bits)
 };
 
 __global__ void slab_reduce_many_kernel(const ReduceItem* __restrict__ items, int n, float scale) {
@@ -299,7 +341,7 @@ __global__ void slab_reduce_many_kernel(const ReduceItem* __restrict__ items, in
   }
   const ReduceItem it = items[lo];
   slab_reduce_body(it.partial, it.dw, it.dbias, it.w, it.decay, scale, it.count, it.cout, it.stride, it.nslabs,
-                   blockIdx.x - it.first_block, it.nblocks);
+                   blockIdx.x - it.first_block, it.nblocks, it.wide_ok);
 }
 
 namespace {
@@ -413,7 +455,8 @@ static int bwd_filter_impl(const void* x, const void* dy, float* dw_hwio, float*
   SQDET_CHECK_HIP(hipGetLastError());
   if (!dw_hwio) return SQDET_OK;
   hipLaunchKernelGGL(slab_reduce2_kernel, dim3(reduce_blocks(p.count + (dbias ? (size_t)cout : 0))), dim3(256), 0, st, workspace,
-                     dw_hwio, dbias, w_hwio_for_decay, weight_decay, grad_scale, p.count, cout, p.slab_stride, p.ksplit);
+                     dw_hwio, dbias, w_hwio_for_decay, weight_decay, grad_scale, p.count, cout, p.slab_stride, p.ksplit,
+                     tune(TUNE_DBG) == 52 ? 0 : 1);
   SQDET_CHECK_HIP(hipGetLastError());
   return SQDET_OK;
 }
@@ -454,6 +497,7 @@ extern "C" int sqdet_slab_reduce_many_prepare(const float* const* workspaces, fl
     it.partial = workspaces[i]; it.dw = dws[i]; it.dbias = dbiases[i]; it.w = w_for_decay[i];
     it.count = p.count; it.stride = p.slab_stride; it.decay = decays[i]; it.cout = cout[i]; it.nslabs = p.ksplit;
     it.first_block = next;
+    it.wide_ok = tune(TUNE_DBG) == 52 ? 0 : 1;
     it.nblocks = (unsigned)reduce_blocks(p.count + (dbiases[i] ? (size_t)cout[i] : 0));
     next += it.nblocks;
   }

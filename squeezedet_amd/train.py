@@ -582,6 +582,9 @@ class ResNet50ConvDetTrainer(_TrainerBase):
         for n in self.region:
             if n.op in ("conv", "conv_bn") and not has_tr(n):
                 raise SqdetError("frozen conv %s above the first trainable one is not supported" % n.name)
+        # gradient contributions each node of the region receives in the backward (one per reader)
+        self._grad_fanin = collections.Counter(i for n in self.region for i in n.inputs if i is not self.boundary)
+        self.fuse_relu_bwd = os.environ.get("SQDET_FUSE_RELU_BWD", "1") != "0"
         self._plans_for = None
         self._build_plans()
 
@@ -676,38 +679,58 @@ class ResNet50ConvDetTrainer(_TrainerBase):
             witems.append((n.name, (int(xt.shape[0]), int(xt.shape[1]), int(xt.shape[2]), cin, cout, k), dw, db, None, 0.0))
             ops.conv2d_bwd_filter(xt, gt, k, cin, cout, dw=dw, db=db, grad_scale=gs)
 
+        # ReLU backward without a pass of its own: the launch that delivers the LAST contribution to a ReLU output's gradient
+        # also zeroes it where that output is <= 0 (conv2d_bwd_data / scale_mask relu_of) -- the bits of a relu_bwd launch
+        # behind it.  left[node] = contributions still to come; a node whose last contribution is a plain alias (add_relu
+        # handing its gradient to both summands) keeps its relu_bwd launch.
+        left = dict(self._grad_fanin)
+        relu_done = set()
+        has_relu = lambda node: node.op == "add_relu" or (node.op in ("conv", "conv_bn") and node.attrs["relu"])
+
+        def last_relu(node):
+            """Counts one contribution to g[node]; the ReLU output to mask with if it is the last one."""
+            left[node] -= 1
+            if self.fuse_relu_bwd and left[node] == 0 and has_relu(node):
+                relu_done.add(node)
+                return val[node]
+            return None
+
         def give(node, dy, packed_bwd):
             """d(input) of a stride-1 conv into g[node] (accumulating when the node already has a gradient)."""
             if node is self.boundary:
                 return
+            r = last_relu(node)
             if node in g:
                 self._before_inplace(g[node])
-                ops.conv2d_bwd_data(dy, packed_bwd, dx=g[node], accumulate=True)
+                ops.conv2d_bwd_data(dy, packed_bwd, dx=g[node], accumulate=True, relu_of=r)
             else:
-                g[node] = ops.conv2d_bwd_data(dy, packed_bwd)
+                g[node] = ops.conv2d_bwd_data(dy, packed_bwd, relu_of=r)
 
         for n in reversed(self.region):
             gy = g.pop(n)
             if n.op == "conv":
                 x = val[n.inputs[0]]
-                if n.attrs["relu"]:
+                if n.attrs["relu"] and n not in relu_done:
                     self._before_inplace(gy)
                     ops.relu_bwd(val[n], gy)
                 k, cin, cout = n.attrs["size"], int(x.shape[3]), int(n.shape[3])
                 self._wgrad(lambda x=x, gy=gy, k=k, cin=cin, cout=cout, n=n: wg(n, x, gy, k, cin, cout), gy, x)
                 give(n.inputs[0], gy, self.packplan.bwd.get(n.name))
             elif n.op == "dropout":
-                g[n.inputs[0]] = ops.scale_mask(gy, aux[n], 1.0 / n.attrs["keep_prob"])
+                g[n.inputs[0]] = ops.scale_mask(gy, aux[n], 1.0 / n.attrs["keep_prob"], relu_of=last_relu(n.inputs[0]))
             elif n.op == "add_relu":
-                self._before_inplace(gy)
-                ops.relu_bwd(val[n], gy)
+                if n not in relu_done:
+                    self._before_inplace(gy)
+                    ops.relu_bwd(val[n], gy)
                 sc, br = n.inputs
                 g[br] = gy                              # both summands receive the same gradient;
+                left[br] -= 1
                 if sc is not self.boundary:             # the branch's last d(input) is accumulated into it
                     g[sc] = gy
+                    left[sc] -= 1
             elif n.op == "conv_bn":
                 x = val[n.inputs[0]]
-                if n.attrs["relu"]:
+                if n.attrs["relu"] and n not in relu_done:
                     self._before_inplace(gy)
                     ops.relu_bwd(val[n], gy)
                 k, stride = n.attrs["size"], n.attrs["stride"]

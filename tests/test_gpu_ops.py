@@ -95,6 +95,15 @@ CONV_CASES = [
     ("e3_k288_n192", 1, 17, 30, 288, 192, 3, 1, "SAME", True),
     ("e3_k384_n256", 2, 9, 19, 384, 256, 3, 1, "SAME", True),
     ("e3_k512_n512", 1, 8, 16, 512, 512, 3, 1, "SAME", True),
+    # deep-K 1x1 on large maps: the streaming kernel with the cout group's weights resident in LDS (conv1x1k.hip: >= 8192 pixels,
+    # 5..48 K chunks) -- ragged last pixel block, K not a multiple of the 8-chunk load group, channel padding in the last chunk,
+    # ragged couts, 1..6 cout tiles per wave, several cout groups
+    ("k1_k256_n32", 1, 94, 311, 256, 32, 1, 1, "SAME", True),
+    ("k1_k768_n96", 1, 47, 175, 768, 96, 1, 1, "SAME", True),
+    ("k1_k264_n40", 2, 70, 67, 264, 40, 1, 1, "SAME", True),
+    ("k1_k160_n72", 1, 100, 90, 160, 72, 1, 1, "SAME", False),
+    ("k1_k1024_n256", 1, 64, 130, 1024, 256, 1, 1, "SAME", True),
+    ("k1_k384_n16", 1, 91, 93, 384, 16, 1, 1, "SAME", True),
 ]
 
 

@@ -337,3 +337,39 @@ def test_resnet50_side_stream_weight_gradients_equal_the_serial_order():
         torch.cuda.synchronize()
         res.append((tr.flat_grads.clone(), tr.flat_params.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+def test_resnet50_relu_backward_rides_in_the_last_contribution(dtype):
+    """fuse_relu_bwd (default): the launch that delivers the last contribution to a ReLU output's gradient -- the backward-data
+    conv of its reader, accumulating at the residual junctions, or the dropout backward under conv5 -- also applies the ReLU
+    mask; 18 relu_bwd launches per step fewer.  Same bits as the separate launches, and no relu_bwd launch is left."""
+    from oracle import train_oracle as TO
+    from squeezedet_amd import ops
+    size, B = (96, 160), 2
+    res, calls = [], []
+    real = ops.relu_bwd
+    for fuse in (False, True):
+        tr, mc, params = _trainer(size, B, seed=3, dtype=dtype, **({"loss_scale": 1.0} if dtype == torch.float16 else {}))
+        tr.fuse_relu_bwd = fuse
+        tr.seed = 7
+        x = O.synthetic_images(B, size[0], size[1], seed=61)
+        mask, delta, box, labels = TO.synthetic_labels(mc, B, seed=62)
+        n = [0]
+
+        def counted(*a, **k):
+            n[0] += 1
+            return real(*a, **k)
+        ops.relu_bwd = counted
+        try:
+            for _ in range(2):
+                tr.step(x, mask, delta, box, labels)
+        finally:
+            ops.relu_bwd = real
+        torch.cuda.synchronize()
+        calls.append(n[0])
+        res.append((tr.flat_grads.clone(), tr.flat_params.clone()))
+    assert calls[0] == 2 * 18 and calls[1] == 0, calls
+    assert dtype == torch.float16 or torch.isfinite(res[0][0]).all()
+    bits = lambda t_: t_.view(torch.int32)       # (bit patterns: an overflowed float16 step must overflow the same way)
+    assert torch.equal(bits(res[0][0]), bits(res[1][0])) and torch.equal(bits(res[0][1]), bits(res[1][1]))

@@ -51,7 +51,11 @@ BWD_CASES = [("e1_16_64", 2, 23, 31, 16, 64, 1), ("e3_16_64", 2, 23, 31, 16, 64,
              # SqueezeDet+ late modules (22x76 map, squeeze 384, expand 256) and its 96 / 192 / 288-channel squeezes
              ("plus_e1_384_256", 1, 22, 76, 384, 256, 1), ("plus_e3_384_256", 1, 22, 76, 384, 256, 3),
              ("plus_sq_512_384", 1, 22, 76, 512, 384, 1), ("plus_e3_192_128", 1, 23, 39, 192, 128, 3),
-             ("plus_sq_256_288", 1, 23, 39, 256, 288, 1)]
+             ("plus_sq_256_288", 1, 23, 39, 256, 288, 1),
+             # ResNet50 res4 at the training batch (8 x 24 x 78): 8 - 16 slabs of 0.13 - 0.59 M elements, the slab reduction's
+             # four-elements-per-thread form (wgrad.hip slab_reduce_body)
+             ("res4_2a_1024_256", 8, 24, 78, 1024, 256, 1), ("res4_2b_256_256", 8, 24, 78, 256, 256, 3),
+             ("res4_512_256_16slabs", 8, 24, 78, 512, 256, 1)]
 
 
 @pytest.mark.parametrize("case", BWD_CASES, ids=[c[0] for c in BWD_CASES])
@@ -107,6 +111,42 @@ def test_wgrad_plan_one_reduction_for_many_convs(dtype):
         for name, _, dw, db, _, _ in items:
             assert torch.equal(dw, want[name][0]), name
             assert db is None or torch.equal(db, want[name][1]), name
+
+
+@pytest.mark.parametrize("case", ["res4_2a_1024_256", "res4_2b_256_256", "res4_512_256_16slabs", "plus_e3_384_256", "convdet_768_72"])
+def test_slab_reduction_wide_form_has_the_four_lane_forms_bits(case):
+    """The slab reduction's four-elements-per-thread form (large gradients, <= 16 slabs) against the four-lanes-per-element
+    form ("dbg" 52) on the same partial sums: bitwise, with weight decay, a bias gradient, a gradient scale, and a dW that is
+    only 4-byte aligned (a trainer's flat gradient view); the same through WgradPlan's one-launch reduction."""
+    ops = _ops()
+    name, N, H, W, cin, cout, k = next(c for c in BWD_CASES if c[0] == case)
+    rs = np.random.RandomState(11)
+    x = torch.from_numpy(rs.randn(N, H, W, cin).astype(np.float32)).to(DEV, torch.float16)
+    dy = torch.from_numpy(rs.randn(N, H, W, cout).astype(np.float32)).to(DEV, torch.float16)
+    w = torch.from_numpy(rs.randn(k, k, cin, cout).astype(np.float32)).to(DEV)
+    cnt = k * k * cin * cout
+
+    def run():
+        flat = torch.full((cnt + 8,), float("nan"), dtype=torch.float32, device=DEV)
+        dw_odd = flat[1:1 + cnt].view(k, k, cin, cout)             # 4-byte aligned only
+        a = ops.conv2d_bwd_filter(x, dy, k, cin, cout, w_for_decay=w, weight_decay=1e-3, grad_scale=0.125)
+        b = ops.conv2d_bwd_filter(x, dy, k, cin, cout, w_for_decay=w, weight_decay=1e-3, grad_scale=0.125, dw=dw_odd)
+        dwp, dbp = torch.empty_like(a[0]), torch.empty_like(a[1])
+        plan = ops.WgradPlan([(name, (N, H, W, cin, cout, k), dwp, dbp, w, 1e-3)])
+        plan.partial(name, x, dy)
+        plan.reduce(0.125)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(flat[0])) and bool(torch.isnan(flat[1 + cnt:]).all())
+        return a[0], a[1], b[0].clone(), b[1], dwp, dbp
+    new = run()
+    ops.set_option("dbg", 52)
+    try:
+        old = run()
+    finally:
+        ops.set_option("dbg", 0)
+    for got, ref in zip(new, old):
+        assert torch.isfinite(ref).all() and torch.equal(got, ref)
+    assert torch.equal(new[0], new[2]) and torch.equal(new[0], new[4]) and torch.equal(new[1], new[5])
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
