@@ -11,7 +11,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench lines (driver-style short run of the headline too)
 CONFIGS="sqdet_infer sqdet_infer_384 sqdet_sample_b1 sqdetplus_infer sqdet_train_fp32 res50_train_fp16 sqdet_train_fp16"
-[ "${FAST:-0}" = "1" ] && CONFIGS="sqdet_infer"
+[ "${FAST:-0}" = "1" ] && CONFIGS="sqdet_infer ${EXTRA:-}"      # EXTRA="res50_train_fp16 ..": those configs' bench lines + kernel stats too
 for c in $CONFIGS; do
   python $R/bench.py --config $c > $OUT/bench_$c.json 2> $OUT/bench_$c.err
 done
@@ -27,13 +27,15 @@ SQDET_SERVE_LANES=1 rocprofv3 --kernel-trace --stats -d $OUT/kstats1 -o ks --out
 python $R/profiles/summarize.py $(find $OUT/kstats1 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_1lane.txt "SQDET_SERVE_LANES=1 rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline" $FP >> $OUT/kstats1.log 2>&1
 SQDET_SERVE_LANES=1 python $R/bench.py --no-cpu-baseline > $OUT/bench_sqdet_infer_1lane.json 2>> $OUT/bench_sqdet_infer.err
 rm -rf $OUT/kstats1
-if [ "${FAST:-0}" != "1" ]; then
+KS_CONFIGS="sqdetplus_infer sqdet_train_fp32 res50_train_fp16 sqdet_train_fp16"
+[ "${FAST:-0}" = "1" ] && KS_CONFIGS="${EXTRA:-}"
 # 2b. kernel stats of the other configs (which kernels carry SqueezeDet+, ResNet50 inference and the two training steps)
-for c in sqdetplus_infer sqdet_train_fp32 res50_train_fp16 sqdet_train_fp16; do
+for c in $KS_CONFIGS; do
   rocprofv3 --kernel-trace --stats -d $OUT/ks_$c -o ks --output-format csv -- python $R/bench.py --config $c --no-cpu-baseline --no-graph > $OUT/kstats_$c.log 2>&1
   python $R/profiles/summarize.py $(find $OUT/ks_$c -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$c.txt "rocprofv3 --kernel-trace --stats -- python bench.py --config $c --no-cpu-baseline --no-graph" >> $OUT/kstats_$c.log 2>&1
   rm -rf $OUT/ks_$c
 done
+if [ "${FAST:-0}" != "1" ]; then
 rocprofv3 --kernel-trace --stats -d $OUT/ks_res50_infer -o ks --output-format csv -- python $R/tools/netbench.py --arch resnet50 --batch 8 > $OUT/netbench_resnet50_b8.txt 2>&1
 python $R/profiles/summarize.py $(find $OUT/ks_res50_infer -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_res50_infer.txt "rocprofv3 --kernel-trace --stats -- python tools/netbench.py --arch resnet50 --batch 8" >> $OUT/kstats.log 2>&1
 rm -rf $OUT/ks_res50_infer
