@@ -474,10 +474,12 @@ def run_infer(args, rank, local_rank, world, device):
     dom = int(np.argmax(ms0))
     spin_up(step, args.spinup_ms, model.flush_pipeline)
     box = box_calibration(device)                         # ~6 ms of fixed microkernels: what THIS box sustains (untimed)
+    # (the clock read-out sits AHEAD of the last spin-up: its first call loads and initialises amdsmi, tens of milliseconds with
+    # the GPU idle, and a 20-step timed region that starts behind such a gap reads up to 10 % below a 200-step one)
+    clocks = {"before": gpu_state(local_rank)}
     spin_up(step, min(args.spinup_ms, 20.0), model.flush_pipeline)
     if os.environ.get("SQDET_BENCH_NO_PROBE") != "1":     # (A/B knob: what the live event pairs cost the step)
         plan.set_probe(dom, args.steps)
-    clocks = {"before": gpu_state(local_rank)}
 
     # ---- timed region: EXACTLY `steps` steps between barrier+synchronize pairs ----
     barrier(world, device)
@@ -731,8 +733,8 @@ def run_train(args, rank, local_rank, world, device):
     torch.cuda.synchronize()
     spin_up(step, args.spinup_ms)
     box = box_calibration(device)
+    clocks = {"before": gpu_state(local_rank)}            # (ahead of the last spin-up: see run_infer)
     spin_up(step, min(args.spinup_ms, 20.0))
-    clocks = {"before": gpu_state(local_rank)}
     barrier(world, device)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
