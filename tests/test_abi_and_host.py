@@ -349,3 +349,19 @@ def test_serving_lane_state_is_swapped_and_restored():
             m._pipe = "P2"
             raise RuntimeError("boom")
     assert lane["pipe"] == "P2" and m._pipe == "P0" and m._lane_plan == 0
+
+
+def test_tools_and_scripts_parse():
+    """Every tools/*.py compiles and every tools/*.sh passes `bash -n` (they run on the GPU box only; a syntax error there costs a
+    gpurun call)."""
+    import glob
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pys = sorted(glob.glob(os.path.join(root, "tools", "*.py")) + glob.glob(os.path.join(root, "profiles", "*.py")) +
+                 [os.path.join(root, n) for n in ("bench.py", "demo.py", "__graft_entry__.py")])
+    assert len(pys) > 10
+    for p in pys:
+        compile(open(p).read(), p, "exec")
+    for p in sorted(glob.glob(os.path.join(root, "tools", "*.sh"))):
+        r = subprocess.run(["bash", "-n", p], capture_output=True, text=True)
+        assert r.returncode == 0, (p, r.stderr)
