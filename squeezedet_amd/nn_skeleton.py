@@ -480,10 +480,35 @@ class ModelSkeleton:
             lane["in_ev"].record(cur)
             with torch.cuda.stream(lane["stream"]), self._lane_state(lane):
                 lane["stream"].wait_event(lane["in_ev"])
-                out = self._detect_filter_pipelined(images, to_host, defer)
+                self._lane_signal = self._lane_phase(lanes, lane)
+                try:
+                    out = self._detect_filter_pipelined(images, to_host, defer)
+                finally:
+                    self._lane_signal = None
                 if isinstance(images, torch.Tensor) and images.is_cuda:
                     images.record_stream(lane["stream"])
             return out
+
+    def _lane_phase(self, lanes, lane):
+        """Experiment knob SQDET_LANE_PHASE=m[b] (default: off -- nothing orders the lanes): lane 1's forward starts when lane 0's
+        current forward reaches layer m (an event recorded ahead of that launch, sqdet_net_set_signal), so that one lane's early,
+        bandwidth-leaning launches run beside the other's late, matrix-bound ones; `b`: lane 0's next forward also waits for lane
+        1's.  Returns the (layer, event) this forward signals, or None."""
+        spec = os.environ.get("SQDET_LANE_PHASE", "")
+        if not spec or len(lanes) != 2:
+            return None
+        both, m = spec.endswith("b"), int(spec.rstrip("b"))
+        k = 0 if lane is lanes[0] else 1
+        other = lanes[1 - k]
+        for ln in lanes:
+            if "phase_ev" not in ln:
+                ln["phase_ev"] = torch.cuda.Event()
+                ln["phase_ev"].record(ln["stream"])          # (creates the handle)
+                ln["phase_armed"] = False
+        if (k == 1 or both) and other["phase_armed"]:
+            lane["stream"].wait_event(other["phase_ev"])
+        lane["phase_armed"] = True
+        return (m, lane["phase_ev"])
 
     def _check_lane_streams(self, images):
         """One-time, at the first two-lane call: make sure the lanes' HIP streams really run CONCURRENTLY.  Which hardware queue a HIP
@@ -678,7 +703,8 @@ class ModelSkeleton:
                                           mc.TOP_N_DETECTION, mc.NMS_THRESH)
                     else:
                         self._enqueue_post(prev, None)
-                plan.set_signal(-1, None)
+                sig = getattr(self, "_lane_signal", None)
+                plan.set_signal(*(sig if sig else (-1, None)))
                 plan.forward(x, s["preds"], scores=s["det"][1])
                 pipe["pending"] = s
                 s["used"] = False                       # (no side-stream reader to wait for)
