@@ -50,6 +50,9 @@ CONFIGS = {
     "sqdet_infer_384": dict(kind="infer", arch="squeezeDet", batch=32, height=384, width=1248, dtype="fp16",
                             metric="images/sec SqueezeDet 1248x384 inference", steps=200, warmup=20),
     "sqdet_sample_b1": dict(kind="infer", arch="squeezeDet", batch=1, height=384, width=1248, dtype="fp16", sample=True,
+                            # (a batch-1 forward leaves most of the chip idle: THREE images in flight -- 11.1-11.8 k img/s against 8.3 k
+                            # with two on the same box, host-bound from there; four read 8.4 k)
+                            lanes=3,
                             metric="images/sec SqueezeDet single sample.png (1242x375 -> 1248x384) inference, batch 1", steps=500, warmup=20),
     "sqdetplus_infer": dict(kind="infer", arch="squeezeDet+", batch=8, height=375, width=1242, dtype="fp16",
                             metric="images/sec SqueezeDet+ 1242x375 inference", steps=100, warmup=10),
@@ -436,6 +439,10 @@ def launch_roofline(flops, nbytes, ms, dtype):
 
 def run_infer(args, rank, local_rank, world, device):
     model, mc, xs = build_infer_model(args, local_rank)
+    # forwards in flight (serving lanes of detect_filter_pipelined): the library's default is 2; a config may name its own
+    cfg_lanes = CONFIGS[args.config].get("lanes")
+    lanes = 1 if args.no_pipeline else max(1, int(os.environ.get("SQDET_SERVE_LANES", cfg_lanes or 2)))
+    model.serve_lanes = lanes if (cfg_lanes and not args.no_pipeline) else None
     plan = model._native_plan(args.batch)
     layers = plan.layer_table()
     # the benchmarked step runs ConvDet's SCORE form (interpret_output's det_probs written by its epilogue: one float32 per anchor):
@@ -498,7 +505,6 @@ def run_infer(args, rank, local_rank, world, device):
 
     probe_ms = plan.read_probe(args.steps)
     plan.set_probe(-1, 0)
-    lanes = 1 if args.no_pipeline else max(1, int(os.environ.get("SQDET_SERVE_LANES", "2")))
     single = None
     if lanes >= 2 and os.environ.get("SQDET_BENCH_NO_PROBE") != "1":
         # the SAME dominant launch with ONE forward in flight (untimed second pass of the same K steps): under two lanes a launch
@@ -517,7 +523,7 @@ def run_infer(args, rank, local_rank, world, device):
         single_step_ms = (time.perf_counter() - t1) / args.steps * 1e3
         sp = plan.read_probe(args.steps)
         plan.set_probe(-1, 0)
-        model.serve_lanes = None
+        model.serve_lanes = lanes if cfg_lanes else None
         if sp:
             single = (float(np.mean(sp)), single_step_ms)
     counts = np.asarray(out[4].cpu() if isinstance(out[4], torch.Tensor) else out[4])
@@ -547,9 +553,10 @@ def run_infer(args, rank, local_rank, world, device):
     roof["algorithmic_flops_per_launch"] = flops
     roof["concurrent_forwards"] = lanes
     if lanes >= 2:
-        roof["note"] = ("measured live in the timed region, where TWO forwards are in flight on two HIP streams: the launch shares the "
-                        "chip with the other lane's launches, its duration is wall time -- `single_lane` is the same launch with one forward "
-                        "in flight (second, untimed pass of the same steps), `pipeline` the chip-level rate of the timed steps")
+        roof["note"] = ("measured live in the timed region, where %s forwards are in flight on as many HIP streams: the launch shares the "
+                        "chip with the other lanes' launches, its duration is wall time -- `single_lane` is the same launch with one forward "
+                        "in flight (second, untimed pass of the same steps), `pipeline` the chip-level rate of the timed steps"
+                        % {2: "TWO", 3: "THREE"}.get(lanes, str(lanes)))
         if single:
             sl = launch_roofline(flops, nbytes, single[0], args.dtype)
             sl.update(avg_launch_ms=round(single[0], 5), ms_per_step=round(single[1], 4))
