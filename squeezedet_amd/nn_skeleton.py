@@ -570,7 +570,8 @@ class ModelSkeleton:
         """The serving lanes of detect_filter_pipelined (None: single-lane operation).  Used for deferred (rider) steps on native
         plans; SQDET_SERVE_LANES=n or the attribute serve_lanes (default 2; 1 = off).  At batch 32 three lanes are no better than two
         (0.396 against 0.390 ms per step); at batch 1, where a forward leaves most of the chip idle, three give 11.1-11.8 k img/s
-        against 8.3 k with two and four fall back to 8.4 k (bench.py's sqdet_sample_b1 config asks for three)."""
+        against 8.3 k with two and four fall back to 8.4 k (bench.py's sqdet_sample_b1 config asks for three); SqueezeDet+ at batch 8
+        loses 11 % with three (1.147 against 1.018 ms)."""
         n = getattr(self, "serve_lanes", None)          # (attribute: set by a caller that measures both forms in one process)
         if n is None:
             n = int(os.environ.get("SQDET_SERVE_LANES", "2"))
