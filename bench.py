@@ -317,6 +317,41 @@ def sync_latency_ms(model, x, iters=60):
     return float(np.median(ts[5:]))
 
 
+def batch_latency(model, step, lanes, x, n=24):
+    """Result latency of a batch beside the throughput (untimed pass).  `steady_state`: in the free-running serving loop with
+    `lanes` batches in flight, from the start of a batch's device work (event on its lane's stream ahead of its forward) to the end
+    of the call that carries its decode + filter (the next call of its lane; an upper bound: the riders finish inside that
+    forward's fire_chain launches) -- median over the loop.  `synchronous`: one batch issued on an idle device, flush_pipeline(),
+    synchronize: forward + decode + filter + rows in pinned host memory, host-timed."""
+    model.flush_pipeline()
+    torch.cuda.synchronize()
+    model._latency_probe = probe = []
+    try:
+        for i in range(n):
+            step(i)
+        model.flush_pipeline()
+        torch.cuda.synchronize()
+    finally:
+        model._latency_probe = None
+    lat = []
+    for i, (which, evs) in enumerate(probe):
+        nxt = [e for (w, e) in probe[i + 1:] if w == which]
+        if nxt and i >= lanes:
+            lat.append(evs[0].elapsed_time(nxt[0][1]))
+    ts = []
+    for i in range(12):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.detect_filter_pipelined(x, to_host=True, defer=True)
+        model.flush_pipeline()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return {"steady_state": round(float(np.median(lat)), 4) if lat else None, "batches_in_flight": lanes,
+            "synchronous": round(float(np.median(ts[2:])), 4),
+            "note": "steady_state: start of a batch's forward -> end of the next call of its lane (which carries its decode + filter), "
+                    "device events, median; synchronous: one batch on an idle device incl. flush, host-timed"}
+
+
 def cpu_thread_candidates():
     n = os.cpu_count() or 8
     c = sorted({t for t in (4, 8, 16, 32, 64, 128, n) if t <= n})
@@ -442,7 +477,7 @@ def run_infer(args, rank, local_rank, world, device):
     # forwards in flight (serving lanes of detect_filter_pipelined): the library's default is 2; a config may name its own
     cfg_lanes = CONFIGS[args.config].get("lanes")
     lanes = 1 if args.no_pipeline else max(1, int(os.environ.get("SQDET_SERVE_LANES", cfg_lanes or 2)))
-    model.serve_lanes = lanes if (cfg_lanes and not args.no_pipeline) else None
+    model.serve_lanes = lanes                 # (explicit: the completion contract of a deferred call depends on it)
     plan = model._native_plan(args.batch)
     layers = plan.layer_table()
     # the benchmarked step runs ConvDet's SCORE form (interpret_output's det_probs written by its epilogue: one float32 per anchor):
@@ -523,9 +558,10 @@ def run_infer(args, rank, local_rank, world, device):
         single_step_ms = (time.perf_counter() - t1) / args.steps * 1e3
         sp = plan.read_probe(args.steps)
         plan.set_probe(-1, 0)
-        model.serve_lanes = lanes if cfg_lanes else None
+        model.serve_lanes = lanes
         if sp:
             single = (float(np.mean(sp)), single_step_ms)
+    latency = batch_latency(model, step, lanes, xs[0])
     counts = np.asarray(out[4].cpu() if isinstance(out[4], torch.Tensor) else out[4])
     assert (counts >= 0).all() and (counts <= 64).all()
     if rank != 0:
@@ -595,7 +631,8 @@ def run_infer(args, rank, local_rank, world, device):
                        "composite_roofline_ms": round(comp * 1e3, 4), "composite_roofline_frac": round(comp / step_s, 4)}
     res["box"] = box
     if getattr(model, "_lane_check", None):
-        res["pipeline"]["lane_stream_check"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in model._lane_check.items()}
+        res["pipeline"]["lane_stream_check"] = json.loads(json.dumps(model._lane_check), parse_float=lambda v: round(float(v), 4))
+    res["latency_ms_per_batch"] = latency
     res["host_issue_ms_per_step"] = round(t_issued / args.steps * 1e3, 4)
     res["forward_launches_ms_sum"] = round(float(sum(ms0)), 4)
     # diagnostic, outside the timed region: the same K forwards back to back WITHOUT decode / filter / D2H -- what the
@@ -610,7 +647,7 @@ def run_infer(args, rank, local_rank, world, device):
     if lanes == 2:
         plans2 = [plan, model._native_plan(args.batch, 1)]
         pres = [pre, torch.empty_like(pre)]
-        strs = [ln["stream"] for ln in model._lanes]          # (the serving lanes' own streams: idle here)
+        strs = [ln["stream"] for ln in model._serving_lanes(True, 2)]          # (the serving lanes' own streams: idle here)
         for i in range(2):
             with torch.cuda.stream(strs[i]):
                 plans2[i].forward(xs[i], pres[i])

@@ -115,6 +115,7 @@ SIGNATURES = {
     "sqdet_probe_mfma_layout": (ci, [C.POINTER(C.c_int32), ci]),
     "sqdet_calib_mfma": (ci, [vp, sz, ci, C.POINTER(cd), vp]),
     "sqdet_calib_copy": (ci, [vp, vp, sz, vp]),
+    "sqdet_calib_mfma2": (ci, [vp, sz, vp, sz, ci, ci, ci, ci, C.POINTER(cd), C.POINTER(ci), vp]),
 }
 
 

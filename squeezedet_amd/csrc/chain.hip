@@ -78,7 +78,7 @@ struct ChainArgs {
 // its completion is counted by hand (vm_wait below).  (hipcc has no other use for M0 in this kernel: gfx9 LDS
 // instructions do not read it.)
 __device__ __forceinline__ void glds16(unsigned voff, const unsigned char* sbase, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 
 template <int N>
@@ -756,13 +756,10 @@ bool fire_chain_stream_shape(int s, int e1, int e3, int s2) {
 template <int NSQ>
 int launch_chain_stream(const ChainSArgs& a, hipStream_t st) {
   const size_t lds = (size_t)(a.nb1 * (4 + 2 * NSQ) + a.nb3 * (36 + 2 * NSQ)) * 1024 + CS_TILES * CS_TILE_B + (size_t)(a.E1 + a.E3 + a.S2) * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    SQDET_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_chain_stream<NSQ>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
-  int grid = 256;                                           // one persistent workgroup per CU
+  static PerDevice once;
+  SQDET_CHECK_HIP(once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_chain_stream<NSQ>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }));
+  int grid = cu_count();                                    // one persistent workgroup per CU
   if (grid > (a.nquads + 7) / 8 * 8) grid = (a.nquads + 7) / 8 * 8;
   hipLaunchKernelGGL((fire_chain_stream<NSQ>), dim3((unsigned)grid), dim3(512), lds, st, a);
   SQDET_CHECK_HIP(hipGetLastError());
@@ -779,12 +776,9 @@ template <int NCH, int NSQ, bool WY>
 int launch_chain(const ChainArgs& a, hipStream_t st) {
   constexpr int RG = chain_ring(NCH, NSQ);
   const size_t lds = chain_lds_bytes(NCH, NSQ, RG, a.E1 + a.E3 + a.S2);
-  static bool attr_done = false;
-  if (!attr_done) {
-    SQDET_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_chain<NCH, NSQ, WY, RG>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  static PerDevice once;
+  SQDET_CHECK_HIP(once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_chain<NCH, NSQ, WY, RG>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }));
   const int wgs = ((a.N + 1) / 2) * a.tiles_x * a.tiles_y;
   ChainArgs& am = const_cast<ChainArgs&>(a);
   am.per_xcd = (wgs + 7) / 8;

@@ -19,6 +19,28 @@ int hip_fail(hipError_t e, const char* what) {
   return SQDET_EHIP;
 }
 
+int current_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return d;
+}
+
+int cu_count() {
+  static std::atomic<int> cached[64];
+  const int d = current_device() & 63;
+  int n = cached[d].load(std::memory_order_relaxed);
+  if (n == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, current_device()) != hipSuccess || v < 8) {
+      (void)hipGetLastError();
+      v = 256;
+    }
+    n = v / 8 * 8;
+    cached[d].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 ConvGeom conv_geom(int k, int cin, int cout, int dtype) {
   ConvGeom g;
   g.kg = dtype == SQDET_F16 ? 8 : 4;

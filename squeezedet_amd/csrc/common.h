@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "sqdet.h"
 
 namespace sqdet {
@@ -42,6 +43,28 @@ inline int pad_before(int n, int k, int s, int pad_mode) {
   if (tot < 0) tot = 0;
   return tot / 2;
 }
+// One-time, PER-DEVICE launcher setup (hipFuncSetAttribute of the dynamic-LDS ceiling, occupancy queries): function attributes belong to
+// the device's copy of the code object, so a process that drives several GPUs must set them on each.  `static PerDevice once;` in a
+// launcher; `once.run(f)` calls f (returns hipError_t) the first time the CURRENT device is seen (up to 64 devices) and records
+// success; racing first calls may both run f -- it is idempotent.
+struct PerDevice {
+  std::atomic<uint64_t> done{0};
+  template <class F>
+  hipError_t run(F&& f) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const uint64_t bit = 1ull << (d & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    const hipError_t e = f();
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+  }
+};
+// Compute units of the current device, rounded down to a multiple of 8 (the persistent kernels deal tiles XCD-major: blockIdx & 7),
+// at least 8; 256 on an MI355X in SPX mode.  Cached per device.
+int cu_count();
+int current_device();
+
 inline size_t dtype_size(int dtype) { return dtype == SQDET_F16 ? 2 : 4; }
 inline hipStream_t as_stream(sqdet_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -156,7 +156,7 @@ template <typename T, int NCH, int NT, int MT>
 static void launch_c1(C1Args& a, hipStream_t st) {
   a.ntiles = (a.c.P + 16 * MT - 1) / (16 * MT);
   // persistent: ~8 waves per SIMD-slot budget -> 256 CUs x 16 waves, split over the cout groups
-  const int budget = tune(TUNE_C1_WAVES) > 0 ? tune(TUNE_C1_WAVES) : 256 * 16;
+  const int budget = tune(TUNE_C1_WAVES) > 0 ? tune(TUNE_C1_WAVES) : cu_count() * 16;
   int streams = budget / a.c.ngroups;
   if (streams < 1) streams = 1;
   // a wave re-loads its weight fragments once: give it at least `min_tiles` pixel tiles to amortise them

@@ -131,28 +131,27 @@ bool launch_k1(K1Args& a, int ngroups, hipStream_t st) {
   constexpr int NWAVES = 16;
   const size_t lds = (size_t)a.nchunk * NT * 1024;
   auto kern = &conv1x1_deepk<T, NT, NWAVES>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  static PerDevice once;
+  (void)once.run([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
   // persistent grid: as many workgroups per CU as are RESIDENT together (registers, the LDS weight image, 32 waves), split over the
   // cout groups
   // (asked once per LDS size and instantiation: the query costs tens of microseconds of host time)
+  // (keyed by LDS size and device: slot key = lds * 64 + device + 1)
   static size_t cached_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   static int cached_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const size_t lds_key = lds * 64 + (size_t)(current_device() & 63) + 1;
   int per_cu = 0;
   for (int i = 0; i < 8; ++i)
-    if (cached_n[i] > 0 && cached_lds[i] == lds) per_cu = cached_n[i];
+    if (cached_n[i] > 0 && cached_lds[i] == lds_key) per_cu = cached_n[i];
   if (per_cu == 0) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NWAVES * 64, lds) != hipSuccess || per_cu < 1) {
       (void)hipGetLastError();
       return false;
     }
     for (int i = 0; i < 8; ++i)
-      if (cached_n[i] == 0) { cached_lds[i] = lds; cached_n[i] = per_cu; break; }
+      if (cached_n[i] == 0) { cached_lds[i] = lds_key; cached_n[i] = per_cu; break; }
   }
-  int wgs = 256 * per_cu / ngroups;
+  int wgs = cu_count() * per_cu / ngroups;
   const int need = (a.nblocks + NWAVES - 1) / NWAVES;
   if (wgs > need) wgs = need;
   if (wgs < 1) wgs = 1;

@@ -224,12 +224,10 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
 
 template <typename T, int MT, int NTW>
 static void launch_tile(const TileArgs& a, int grid_y, size_t lds, hipStream_t st) {
-  static bool big_lds_ok = false;   // > 64 KiB of dynamic LDS has to be allowed once per kernel
-  if (lds > 65536 && !big_lds_ok) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_tile<T, MT, NTW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    big_lds_ok = true;
-  }
+  static PerDevice once;   // > 64 KiB of dynamic LDS has to be allowed once per kernel and device
+  if (lds > 65536)
+    (void)once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_tile<T, MT, NTW>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
   const dim3 grid((unsigned)((a.c.N * a.tiles_x * a.tiles_y + 7) / 8 * 8), (unsigned)grid_y);
   hipLaunchKernelGGL((conv3x3_tile<T, MT, NTW>), grid, dim3(256), lds, st, a);
 }

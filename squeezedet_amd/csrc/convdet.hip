@@ -378,7 +378,7 @@ constexpr int CDD_SC = CDD_RED + 12 * CDD_SLOT;        // score exchange area be
 constexpr int CDD_LDS = CDD_SC;                        // (+ CD_SC_LDS in the SCORE form)
 
 __device__ __forceinline__ void cd_dma16(unsigned voff, const i32x4& rsrc, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_dst) : "memory", "m0");
 }
 
 template <bool SCORE>
@@ -629,27 +629,23 @@ __global__ __launch_bounds__(256) void convdet_dma_kernel(TileArgs a, int ntiles
 
 template <bool SCORE>
 static void convdet_dma_launch(const TileArgs& a, hipStream_t st) {
-  static bool lds_ok = false;
-  if (!lds_ok) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convdet_dma_kernel<SCORE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    lds_ok = true;
-  }
+  static PerDevice once;
+  (void)once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&convdet_dma_kernel<SCORE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
   const int ntiles = a.c.N * a.tiles_x * a.tiles_y;
   const int per_xcd = (ntiles + 7) / 8;
-  const int slots = per_xcd < 32 ? per_xcd : 32;
+  const int cus8 = cu_count() / 8;                            // persistent: one workgroup per CU
+  const int slots = per_xcd < cus8 ? per_xcd : cus8;
   hipLaunchKernelGGL((convdet_dma_kernel<SCORE>), dim3((unsigned)(slots * 8)), dim3(256), CDD_LDS + (SCORE ? CD_SC_LDS : 0), st, a, ntiles, per_xcd);
 }
 
 template <typename T, bool PERS, bool SCORE = false>
 static void convdet_launch(const TileArgs& a, hipStream_t st) {
-  static bool lds_ok = false;   // > 64 KiB of dynamic LDS has to be allowed once per kernel
-  if (!lds_ok) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convdet_kernel<T, PERS, SCORE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    lds_ok = true;
-  }
+  static PerDevice once;        // > 64 KiB of dynamic LDS has to be allowed once per kernel and device
+  (void)once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&convdet_kernel<T, PERS, SCORE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
   const int ntiles = a.c.N * a.tiles_x * a.tiles_y;
   const int per_xcd = (ntiles + 7) / 8;
-  const int slots = (!PERS || per_xcd < 32) ? per_xcd : 32;   // persistent: one workgroup per CU, 32 CUs per XCD
+  const int cus8 = cu_count() / 8;
+  const int slots = (!PERS || per_xcd < cus8) ? per_xcd : cus8;   // persistent: one workgroup per CU (32 CUs per XCD)
   hipLaunchKernelGGL((convdet_kernel<T, PERS, SCORE>), dim3((unsigned)(slots * 8)), dim3(256), CD_LDS + (SCORE ? CD_SC_LDS : 0), st, a, ntiles, per_xcd);
 }
 

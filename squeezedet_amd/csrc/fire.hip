@@ -342,12 +342,10 @@ __global__ __launch_bounds__(256, (MT == 4 && NTW <= 4 ? 4 : 2)) void fire_fused
 
 template <typename T, int NTS, int NTW, int MT>
 static void launch_ff(const FireArgs& a, size_t lds, hipStream_t st) {
-  static bool big_lds_ok = false;   // > 64 KiB of dynamic LDS has to be allowed once per kernel
-  if (lds > 65536 && !big_lds_ok) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_fused<T, NTS, NTW, MT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    big_lds_ok = true;
-  }
+  static PerDevice once;   // > 64 KiB of dynamic LDS has to be allowed once per kernel and device
+  if (lds > 65536)
+    (void)once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_fused<T, NTS, NTW, MT>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
   // few tiles (small batches): split the expand items of a tile over up to items/4 workgroups (one item per wave)
   const int tiles = a.N * a.tiles_x * a.tiles_y;
   const int items = (a.e3_tiles / NTW + a.e1_tiles / NTW) * (FROWS / MT);

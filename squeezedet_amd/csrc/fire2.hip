@@ -685,7 +685,7 @@ template <typename T, int NCHX, int NTS, int NWAVES, bool POOL, int RS, bool SQI
 static void launch_stream(const FireSArgs& a, hipStream_t st) {
   const size_t lds = 2 * (size_t)Geo<POOL>::TILE + (size_t)NCHX * NTS * 1024 + (size_t)(NWAVES / RS / 2) * 4 * 1024 + (size_t)(2 * a.E + a.S) * 4;
   // persistent: 8 waves per CU (the register-resident weights + prefetched input allow 2 per SIMD)
-  int grid = 256 * (8 / NWAVES);
+  int grid = cu_count() * (8 / NWAVES);
   if (grid > (a.ntiles + 7) / 8 * 8) grid = (a.ntiles + 7) / 8 * 8;
   // two tiles of input in flight when their fragments fit the register budget next to the resident weights
   constexpr int MBH = (Geo<POOL>::BLK + NWAVES - 1) / NWAVES;
@@ -804,13 +804,10 @@ static int launch_stream_sq(const FireSArgs& a, hipStream_t st) {
   constexpr int NQ = (NWAVES / 2 / 2) * 4;
   const size_t lds = 2 * (size_t)Geo<POOL>::TILE + (size_t)NCHX * NTS * 1024 + (size_t)(NWAVES / 2 / 2) * 4 * 1024 +
                      (size_t)NQ * (POOL ? 32 : 128) * 64 + (size_t)NQ * NTS2 * 1024 + (size_t)(2 * a.E + a.S + a.S2) * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    SQDET_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_stream<f16, NCHX, NTS, NWAVES, 2, POOL, 2, PAIR, SQIN, NTS2>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
-  int grid = 256 * (8 / NWAVES);
+  static PerDevice once;
+  SQDET_CHECK_HIP(once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&fire_stream<f16, NCHX, NTS, NWAVES, 2, POOL, 2, PAIR, SQIN, NTS2>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }));
+  int grid = cu_count() * (8 / NWAVES);
   if (grid > (a.ntiles + 7) / 8 * 8) grid = (a.ntiles + 7) / 8 * 8;
   hipLaunchKernelGGL((fire_stream<f16, NCHX, NTS, NWAVES, 2, POOL, 2, PAIR, SQIN, NTS2>), dim3(grid), dim3(NWAVES * 64), lds, st, a);
   SQDET_CHECK_HIP(hipGetLastError());

@@ -52,7 +52,7 @@ template <bool S16, bool POOL, int ROWS_T> struct GeoX {
 // One 1-KiB block straight into LDS: global address = buffer resource + per-lane byte offset (out of range -> zeros), LDS address =
 // M0 + lane * 16.  Hidden from hipcc's wait-count pass on purpose (it would wait vmcnt(0) at the next LDS read).
 __device__ __forceinline__ void dma16(unsigned voff, const i32x4& rsrc, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_dst) : "memory", "m0");
 }
 template <int N> __device__ __forceinline__ void vm_wait_x() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -407,13 +407,10 @@ int launch_dma(const FireXArgs& a, hipStream_t st) {
   constexpr int NQC = NG * 4, CPIX = POOL ? 32 : G::ROWS * 16;
   const size_t lds = 2 * (size_t)G::STILE + (size_t)NQC * CPIX * 64 + (size_t)NQC * NTS2 * 1024 + (size_t)(2 * a.E + a.S2) * 4;
   auto kern = &fire_dma<S16, POOL, NG, NTW, RS, ROWS_T, NTS2, WPS>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    SQDET_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  static PerDevice once;
+  SQDET_CHECK_HIP(once.run([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }));
   constexpr int WGPC = WPS * 4 / NWAVES;              // workgroups per CU
-  int grid = 256 * WGPC;
+  int grid = cu_count() * WGPC;
   if (grid > (a.ntiles + 7) / 8 * 8) grid = (a.ntiles + 7) / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, st, a);
   SQDET_CHECK_HIP(hipGetLastError());

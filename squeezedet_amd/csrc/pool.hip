@@ -124,13 +124,18 @@ __global__ __launch_bounds__(256) void maxpool3_idx_kernel(const T* __restrict__
   unsigned char pos[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) { m[e] = (T)(-__builtin_huge_valf()); pos[e] = 255; }
-  // the first VALID cell initialises (maximum, position), later cells replace it on a strict '>': a window whose valid cells are
-  // all -inf / NaN still names a cell -- the first one, the x-searching backward's (and tf.nn.max_pool's) choice
+  // VALUE: the maximum starts at -inf and is replaced on a strict '>' only -- a NaN never wins, wherever it sits, exactly as in
+  // maxpool_kernel / maxpool3_kernel (the training forward's pooled tensor is bitwise the inference pool's on ANY input).
+  // POSITION: the first VALID cell names the window until a cell wins the comparison, so a window whose valid cells are all
+  // -inf / NaN still names a cell -- the first one, as the x-searching backward kernels do.
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int e = 0; e < V; ++e)
-      if (ok[t] && (pos[e] == 255 || v[t][e] > m[e])) { m[e] = v[t][e]; pos[e] = (unsigned char)t; }
+      if (ok[t]) {
+        if (pos[e] == 255) pos[e] = (unsigned char)t;
+        if (v[t][e] > m[e]) { m[e] = v[t][e]; pos[e] = (unsigned char)t; }
+      }
   *reinterpret_cast<vec*>(y + idx * V) = m;
   if constexpr (V == 8) {
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));

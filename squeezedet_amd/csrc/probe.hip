@@ -62,6 +62,64 @@ __global__ __launch_bounds__(256) void calib_mfma_kernel(float* out, int iters) 
   out[blockIdx.x * 256 + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
+// Round 5: the same loop in the shapes that settle WHAT the box's ceiling is (the 16x16x32 figure reads half of the
+// guide's 2.5 PF/s).  SHAPE 0 = 16x16x32 (8 independent accumulators of 4 registers), SHAPE 1 = 32x32x16 (4 independent
+// accumulators of 16 registers: the instruction the guide's 2495 TF/s was measured with); one wave per SIMD per workgroup, the
+// launcher makes `waves_per_simd` workgroups per CU co-resident; zero != 0: all-zero operands (the chip's power management gives
+// clock back on them -- MI355X_MICROARCH.md "DVFS give-back" -- so zero vs non-trivial operands on the SAME instruction stream
+// separates "the instruction stream cannot issue faster" from "the box is power-limited").  Wave 0 of every workgroup brackets its
+// loop with s_memtime (shader cycles) and s_memrealtime (constant 100 MHz): ticks[2 * wg] / ticks[2 * wg + 1] give the EFFECTIVE
+// shader clock and the cycles per MFMA without a profiler (rocprofv3's GRBM_GUI_ACTIVE / SQ_VALU_MFMA_BUSY_CYCLES of the same
+// launches: tools/calib_pmc.sh -> profiles/r05_box_calibration.txt).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int SHAPE>
+__global__ __launch_bounds__(256) void calib_mfma2_kernel(float* out, unsigned long long* ticks, int iters, int zero) {
+  const int l = threadIdx.x & 63;
+  f16x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a[i] = zero ? (f16)0.f : (f16)(0.01f * (float)((l * 7 + i * 3) % 13 - 6));
+    b[i] = zero ? (f16)0.f : (f16)(0.02f * (float)((l * 5 + i) % 11 - 5));
+  }
+  float r = 0.f;
+  unsigned long long c0, c1, w0, w1;
+  if constexpr (SHAPE == 0) {
+    f32x4 acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    c0 = __builtin_readcyclecounter(); w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[k], 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r += acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
+    c1 = __builtin_readcyclecounter(); w1 = wall_clock64();
+  } else {
+    f32x16 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+    c0 = __builtin_readcyclecounter(); w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[k], 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) r += acc[k][e];
+    c1 = __builtin_readcyclecounter(); w1 = wall_clock64();
+  }
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = r;
+  if (threadIdx.x == 0) {
+    ticks[2 * (size_t)blockIdx.x] = c1 - c0;
+    ticks[2 * (size_t)blockIdx.x + 1] = w1 - w0;
+  }
+}
+
 __global__ __launch_bounds__(256) void calib_copy_kernel(const i32x4* __restrict__ src, i32x4* __restrict__ dst, size_t n16) {
   const size_t stride = (size_t)gridDim.x * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
@@ -76,6 +134,21 @@ extern "C" int sqdet_calib_mfma(float* scratch, size_t scratch_floats, int iters
   hipLaunchKernelGGL(calib_mfma_kernel, dim3(GRID), dim3(256), 0, as_stream(stream), scratch, iters);
   SQDET_CHECK_HIP(hipGetLastError());
   *flops = (double)GRID * 4.0 * (double)iters * 8.0 * (2.0 * 16 * 16 * 32);
+  return SQDET_OK;
+}
+
+extern "C" int sqdet_calib_mfma2(float* scratch, size_t scratch_floats, unsigned long long* ticks, size_t ticks_count, int iters, int shape,
+                                 int waves_per_simd, int zero_operands, double* flops, int* workgroups, sqdet_stream_t stream) {
+  using namespace sqdet;
+  SQDET_REQUIRE(scratch && ticks && flops && workgroups && iters > 0, "calib_mfma2: null pointer / iters");
+  SQDET_REQUIRE((shape == 0 || shape == 1) && waves_per_simd >= 1 && waves_per_simd <= 8, "calib_mfma2: shape 0 | 1, 1..8 waves per SIMD");
+  const int grid = cu_count() * waves_per_simd;
+  SQDET_REQUIRE(scratch_floats >= (size_t)grid * 256 && ticks_count >= (size_t)grid * 2, "calib_mfma2: scratch >= %d floats, ticks >= %d", grid * 256, grid * 2);
+  if (shape == 0) hipLaunchKernelGGL(calib_mfma2_kernel<0>, dim3(grid), dim3(256), 0, as_stream(stream), scratch, ticks, iters, zero_operands);
+  else hipLaunchKernelGGL(calib_mfma2_kernel<1>, dim3(grid), dim3(256), 0, as_stream(stream), scratch, ticks, iters, zero_operands);
+  SQDET_CHECK_HIP(hipGetLastError());
+  *flops = (double)grid * 4.0 * (double)iters * (shape == 0 ? 8.0 * (2.0 * 16 * 16 * 32) : 4.0 * (2.0 * 32 * 32 * 16));
+  *workgroups = grid;
   return SQDET_OK;
 }
 

@@ -325,7 +325,7 @@ template <int PPRT> struct PGeo {
 };
 
 __device__ __forceinline__ void stem_dma16(int voff, const i32x4& rsrc, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_dst) : "memory", "m0");
 }
 template <int N> __device__ __forceinline__ void stem_vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -598,13 +598,10 @@ static void launch_phase_dma(StemArgs a, int dbg, hipStream_t st) {
   a.tiles_y = (a.Hp + PPRT - 1) / PPRT;
   const int ntiles = a.N * a.tiles_x * a.tiles_y;
   const int per_xcd = (ntiles + 7) / 8;
-  int grid = 256 * WPC;
+  int grid = cu_count() * WPC;
   if (per_xcd < grid / 8) grid = per_xcd * 8;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_phase_dma<SQ, PPRT, WPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  static PerDevice once;
+  (void)once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_phase_dma<SQ, PPRT, WPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
   hipLaunchKernelGGL((stem_phase_dma<SQ, PPRT, WPC>), dim3(grid), dim3(256), G::LDS, st, a, ntiles, per_xcd, dbg);
 }
 

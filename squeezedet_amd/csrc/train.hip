@@ -231,8 +231,12 @@ __global__ void maxpool3s2_bwd_kernel(const T* __restrict__ x, const T* __restri
             if (xx < 0 || xx >= W) continue;
             const V v = *reinterpret_cast<const V*>(x + ((((size_t)n * H + yy) * W + xx) * C + cv * EV));
 #pragma unroll
-            for (int e = 0; e < EV; ++e)
-              if (bpos[e] < 0 || (float)v[e] > best[e]) { best[e] = (float)v[e]; bpos[e] = 3 * r + c; }   // (the first valid cell initialises: a window of -inf / NaN cells still routes its gradient, to that cell -- as maxpool3_idx_kernel's index does)
+            for (int e = 0; e < EV; ++e) {
+              // the first valid cell NAMES the window until a cell wins the strict comparison against -inf (a NaN never wins): a
+              // window of -inf / NaN cells still routes its gradient, to that cell -- maxpool3_idx_kernel's rule, bit for bit
+              if (bpos[e] < 0) bpos[e] = 3 * r + c;
+              if ((float)v[e] > best[e]) { best[e] = (float)v[e]; bpos[e] = 3 * r + c; }
+            }
           }
         }
         const V d = *reinterpret_cast<const V*>(dy + ((((size_t)n * Ho + oy) * Wo + ox) * C + cv * EV));
@@ -376,8 +380,10 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict_
             if (xx < 0 || xx >= W) continue;
             const V v = *reinterpret_cast<const V*>(x + ((((size_t)n * H + yy) * W + xx) * C + cv * EV));
 #pragma unroll
-            for (int e = 0; e < EV; ++e)
+            for (int e = 0; e < EV; ++e) {
+              if (bpos[e] < 0) bpos[e] = yy * W + xx;      // (the first valid cell names a window nothing wins: all -inf / NaN)
               if ((float)v[e] > best[e]) { best[e] = (float)v[e]; bpos[e] = yy * W + xx; }
+            }
           }
         }
         const V d = *reinterpret_cast<const V*>(dy + ((((size_t)n * Ho + oy) * Wo + ox) * C + cv * EV));

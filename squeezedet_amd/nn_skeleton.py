@@ -9,7 +9,6 @@ executes them on the GPU.  There is no CPU execution path.
 import collections
 import contextlib
 import os
-import time
 
 import numpy as np
 import torch
@@ -101,6 +100,13 @@ class ModelSkeleton:
         self._plan_stale = True
         self._anchors_f32 = None
         self.caffemodel_weight = None
+        # serving lanes of detect_filter_pipelined(defer=True): BATCHES IN FLIGHT (see its docstring: the completion contract of a
+        # deferred call depends on it).  None = SQDET_SERVE_LANES from the environment, default 2; the `lanes` argument overrides.
+        self.serve_lanes = None
+        self._lanes, self._lane_next, self._lanes_checked, self._lane_check = None, 0, False, None
+        # measurement hook (bench.py's latency_ms_per_batch): a list -> every detect_filter_pipelined call appends
+        # (lane, (event before the call's device work, event behind it)) on the stream the call runs on
+        self._latency_probe = None
 
     # ------------------------------------------------------------------ builders
     def _add_forward_graph(self):
@@ -430,22 +436,22 @@ class ModelSkeleton:
         return tuple(self.run([self.det_boxes, self.det_probs, self.det_class], {self.image_input: images},
                               use_plan=use_plan))
 
-    def detect_filter_pipelined(self, images, to_host=False, defer=False):
+    def detect_filter_pipelined(self, images, to_host=False, defer=False, lanes=None):
         """One step of the serving loop as a two-stage pipeline: the network forward runs on the caller's stream,
         interpret_output + filter_prediction (a few dozen microseconds of latency-bound work on 32 workgroups)
         run on a side HIP stream behind an event, so the NEXT batch's forward starts while this batch's boxes
-        are being decoded and suppressed.  Returns filter_prediction_batch's tuple; the tensors are produced on
-        `self.post_stream` -- synchronise with it (or the device) before reading them.
+        are being decoded and suppressed.  Returns filter_prediction_batch's tuple; the tensors are complete once
+        flush_pipeline() has been called and the caller's stream (or the device) is synchronised.
 
         Models with a native plan run it on TWO static sets of buffers (preds, det_*, outputs) used alternately, with
         explicit events in both directions -- no allocation per step.  (Per-step torch allocations were the first
         version: preds had to be record_stream'ed for the side stream, so the caching allocator could not reuse a
         block until its event had completed; a host running a hundred steps ahead then asked for a hundred preds
         buffers, i.e. hipMalloc inside the serving loop -- the same binary measured 0.77 or 1.0-1.2 ms per step from
-        one run to the next.)  The returned tensors are those of the slot: valid until the second-next call.
+        one run to the next.)  The returned tensors are those of the slot: valid until the second-next call of the lane.
         to_host=True: the filtered rows (<= TOP_N per image: boxes, probs, classes, anchor indices, counts) are also copied
         to the slot's PINNED host buffers on the side stream -- what sess.run + filter_prediction hand the reference's
-        caller -- and those host tensors are returned (complete once the side stream / the device is synchronised).
+        caller -- and those host tensors are returned.
 
         defer=True (plans with the score epilogue and fire_chain launches: float16 SqueezeDet): the decode + filter of this
         call is carried out BY THE NEXT CALL's forward (or by flush_pipeline()): it is handed to the plan as a post job
@@ -455,103 +461,113 @@ class ModelSkeleton:
         tiles per workgroup), so side work on another stream costs a whole round of whatever it lands beside, and every
         event ordering the two streams drains the forward's queue: measured 35 us per 0.49 ms step wherever the filter
         launch was placed (side stream, same stream, with or without the score kernel, beside the stem or beside the
-        fire_chain launches) -- whereas the six fire_chain launches occupy 240 of the 256 CUs at batch 32.  The returned
-        tensors are this call's, complete after the NEXT call (or flush_pipeline()) and a synchronisation of the caller's
-        stream.  (SQDET_POST_DEFER=signal: the previous form -- the side stream's launch gated on a mid-forward event.)
+        fire_chain launches) -- whereas the six fire_chain launches occupy 240 of the 256 CUs at batch 32.
+        (SQDET_POST_DEFER=signal: the previous form -- the side stream's launch gated on a mid-forward event.)
 
-        Since round 4 deferred calls on native plans keep TWO batches in flight: consecutive calls alternate between two serving
-        LANES (each its own plan = workspace, HIP stream and pipeline slots; SQDET_SERVE_LANES=1: one lane, the round-3 behaviour),
-        so a call's rows are complete after the SECOND-next call -- the next one of its lane -- or after flush_pipeline(), which
-        also makes the caller's stream wait for the lanes."""
+        lanes (deferred calls on native plans; None = the model attribute `serve_lanes`, whose default is 2, or the environment's
+        SQDET_SERVE_LANES): the number of BATCHES IN FLIGHT.  Consecutive calls alternate between `lanes` serving lanes -- each its
+        own plan (workspace), HIP stream and pipeline slots, nothing ordering the lanes against each other -- so one lane's launch
+        ramps and tails are filled by the other lanes' launches (throughput +20 % at batch 32 with two; three pay at batch 1).
+        THE COMPLETION CONTRACT DEPENDS ON IT: the rows a deferred call returns are complete after the next call OF ITS LANE, i.e.
+        after `lanes` further calls -- or after flush_pipeline() -- plus a synchronisation of the caller's stream behind that
+        call; lanes=1 is the single-stream behaviour (complete after the NEXT call).  The result latency of a steady serving
+        loop is therefore `lanes` step times (bench.py reports it as latency_ms_per_batch)."""
         with torch.cuda.device(self.device):
-            lanes = self._serving_lanes(defer)
-            if lanes is None:
-                return self._detect_filter_pipelined(images, to_host, defer)
-            # TWO batches in flight (round 4): consecutive calls alternate between two LANES -- each with its own plan (workspace),
-            # HIP stream and pipeline slots -- and nothing orders the lanes against each other.  Every launch of the forward is one
-            # wave of persistent workgroups: its ramp and its tail leave CUs idle that the other lane's launch fills (forward only,
-            # same box: 0.389 against 0.475 ms per 32-image batch).  A lane starts behind the caller's stream (the input may have
-            # been produced there); the results of a call are complete after the second-next call or flush_pipeline().
-            if not getattr(self, "_lanes_checked", False):
-                self._check_lane_streams(images)
-            lane = lanes[self._lane_next % len(lanes)]
-            self._lane_next = (self._lane_next + 1) % len(lanes)
+            lane_set = self._serving_lanes(defer, lanes)
+            probe = self._latency_probe
+            if lane_set is None:
+                if probe is None:
+                    return self._detect_filter_pipelined(images, to_host, defer)
+                evs = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                evs[0].record()
+                out = self._detect_filter_pipelined(images, to_host, defer)
+                evs[1].record()
+                probe.append((0, evs))
+                return out
+            # A lane starts behind the caller's stream (the input may have been produced there).
+            if not self._lanes_checked:
+                self.warm_up_lanes(images)
+            lane = lane_set[self._lane_next % len(lane_set)]
+            self._lane_next = (self._lane_next + 1) % len(lane_set)
             cur = torch.cuda.current_stream()
             lane["in_ev"].record(cur)
             with torch.cuda.stream(lane["stream"]), self._lane_state(lane):
                 lane["stream"].wait_event(lane["in_ev"])
-                self._lane_signal = self._lane_phase(lanes, lane)
-                try:
-                    out = self._detect_filter_pipelined(images, to_host, defer)
-                finally:
-                    self._lane_signal = None
+                if probe is not None:
+                    evs = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    evs[0].record()
+                out = self._detect_filter_pipelined(images, to_host, defer)
+                if probe is not None:
+                    evs[1].record()
+                    probe.append((lane["which"], evs))
                 if isinstance(images, torch.Tensor) and images.is_cuda:
                     images.record_stream(lane["stream"])
             return out
 
-    def _lane_phase(self, lanes, lane):
-        """Experiment knob SQDET_LANE_PHASE=m[b] (default: off -- nothing orders the lanes): lane 1's forward starts when lane 0's
-        current forward reaches layer m (an event recorded ahead of that launch, sqdet_net_set_signal), so that one lane's early,
-        bandwidth-leaning launches run beside the other's late, matrix-bound ones; `b`: lane 0's next forward also waits for lane
-        1's.  Returns the (layer, event) this forward signals, or None."""
-        spec = os.environ.get("SQDET_LANE_PHASE", "")
-        if not spec or len(lanes) != 2:
-            return None
-        both, m = spec.endswith("b"), int(spec.rstrip("b"))
-        k = 0 if lane is lanes[0] else 1
-        other = lanes[1 - k]
-        for ln in lanes:
-            if "phase_ev" not in ln:
-                ln["phase_ev"] = torch.cuda.Event()
-                ln["phase_ev"].record(ln["stream"])          # (creates the handle)
-                ln["phase_armed"] = False
-        if (k == 1 or both) and other["phase_armed"]:
-            lane["stream"].wait_event(other["phase_ev"])
-        lane["phase_armed"] = True
-        return (m, lane["phase_ev"])
+    def warm_up_lanes(self, images, lanes=None):
+        """Builds the serving lanes' plans for this batch and makes sure their HIP streams really run CONCURRENTLY; called by the
+        first deferred detect_filter_pipelined of a lane set (a caller that must not pay ~20-40 ms inside its first serving call,
+        or that captures streams, calls it ahead of time).  Which hardware queue a HIP stream lands on is the runtime's business,
+        and two streams that share one serialise -- measured on this stack: of ten streams of torch's pool, the pairs containing
+        one particular stream gave 0.468 ms per forward (= one stream) where every other pair gave 0.371.  For every lane k >= 1:
+        16 forwards alternating between lane 0's stream and lane k's are timed with HIP events against 16 on lane 0's stream
+        alone (median of three repetitions each, plans built and warmed on the lane streams first); a pair that gains less than
+        6 % has lane k's stream replaced (up to four candidates, the best kept).  Result: self._lane_check."""
+        with torch.cuda.device(self.device):
+            lane_set = self._serving_lanes(True, lanes)
+            self._lanes_checked = True
+            if lane_set is None or os.environ.get("SQDET_LANE_CHECK", "1") == "0":
+                return None
+            x = self._to_input(images)
+            B = int(x.shape[0])
+            cur = torch.cuda.current_stream()
+            plans, pre = [], []
+            for lane in lane_set:
+                lane["stream"].wait_stream(cur)
+                with torch.cuda.stream(lane["stream"]):
+                    plans.append(self._native_plan(B, lane["which"]))
+                    pre.append(torch.empty((B, plans[0].gh, plans[0].gw, plans[0].out_ch), dtype=self.dtype, device=self.device))
+            NF, REPS = 16, 3
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def _check_lane_streams(self, images):
-        """One-time, at the first two-lane call: make sure the lanes' HIP streams really run CONCURRENTLY.  Which hardware queue a HIP
-        stream lands on is the runtime's business, and two streams that share one serialise -- measured on this stack: of ten
-        streams of torch's pool, the pairs containing one particular stream gave 0.468 ms per forward (= one stream) where every
-        other pair gave 0.371 (tools/exp_two_pipelines.py).  Four alternating forwards on the lane pair are timed against four on
-        one stream; a pair that gains less than 6 % has its second stream replaced (up to four candidates).  ~10 ms, once."""
-        self._lanes_checked = True
-        lanes = self._lanes
-        if len(lanes) != 2 or os.environ.get("SQDET_LANE_CHECK", "1") == "0":
-            return
-        x = self._to_input(images)
-        B = int(x.shape[0])
-        plans = [self._native_plan(B, 0), self._native_plan(B, 1)]
-        pre = [torch.empty((B, plans[0].gh, plans[0].gw, plans[0].out_ch), dtype=self.dtype, device=self.device) for _ in range(2)]
-        cur = torch.cuda.current_stream()
+            def timed(k, sb):
+                """ms per forward: NF forwards alternating between lane 0 (plan 0, its stream) and lane k's plan on stream sb"""
+                sa = lane_set[0]["stream"]
+                ts = []
+                for rep in range(REPS + 1):               # (first repetition: warm-up of streams / plans)
+                    torch.cuda.synchronize(self.device)
+                    e0.record(sa)
+                    if sb is not sa:
+                        sb.wait_event(e0)
+                    for i in range(NF):
+                        j, st = (0, sa) if i % 2 == 0 else (k, sb)
+                        with torch.cuda.stream(st):
+                            plans[j].forward(x, pre[j])
+                    if sb is not sa:
+                        sa.wait_stream(sb)
+                    e1.record(sa)
+                    e1.synchronize()
+                    ts.append(e0.elapsed_time(e1) / NF)
+                return float(np.median(ts[1:]))
 
-        def timed(sa, sb):
-            for rep in range(2):                      # (first pass: warm-up of streams / plans)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for i in range(4):
-                    with torch.cuda.stream(sa if i % 2 == 0 else sb):
-                        plans[i % 2].forward(x, pre[i % 2])
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t0
-            return dt
-
-        a = lanes[0]["stream"]
-        a.wait_stream(cur)
-        single = timed(a, a)
-        best, best_t = lanes[1]["stream"], None
-        cand = lanes[1]["stream"]
-        for attempt in range(4):
-            cand.wait_stream(cur)
-            t = timed(a, cand)
-            if best_t is None or t < best_t:
-                best, best_t = cand, t
-            if t < 0.94 * single:
-                break
-            cand = torch.cuda.Stream(device=self.device)
-        lanes[1]["stream"] = best
-        self._lane_check = dict(single_ms=single * 250.0, pair_ms=best_t * 250.0, attempts=attempt + 1)   # per forward
+            single = timed(0, lane_set[0]["stream"])
+            report = dict(single_ms=single, forwards_per_sample=NF, repetitions=REPS, pairs=[])
+            for k in range(1, len(lane_set)):
+                best, best_t, cand = None, None, lane_set[k]["stream"]
+                for attempt in range(4):
+                    t = timed(k, cand)
+                    if best_t is None or t < best_t:
+                        best, best_t = cand, t
+                    if t < 0.94 * single:
+                        break
+                    cand = torch.cuda.Stream(device=self.device)
+                lane_set[k]["stream"] = best
+                report["pairs"].append(dict(lane=k, pair_ms=best_t, attempts=attempt + 1))
+            report["pair_ms"] = max(p["pair_ms"] for p in report["pairs"])
+            report["attempts"] = max(p["attempts"] for p in report["pairs"])
+            cur.wait_stream(lane_set[0]["stream"])
+            self._lane_check = report
+            return report
 
     @contextlib.contextmanager
     def _lane_state(self, lane):
@@ -566,38 +582,50 @@ class ModelSkeleton:
             self._lane_plan = 0
             self._pipe, self.post_stream, self._post_event = saved
 
-    def _serving_lanes(self, defer):
-        """The serving lanes of detect_filter_pipelined (None: single-lane operation).  Used for deferred (rider) steps on native
-        plans; SQDET_SERVE_LANES=n or the attribute serve_lanes (default 2; 1 = off).  At batch 32 three lanes are no better than two
-        (0.396 against 0.390 ms per step); at batch 1, where a forward leaves most of the chip idle, three give 11.1-11.8 k img/s
-        against 8.3 k with two and four fall back to 8.4 k (bench.py's sqdet_sample_b1 config asks for three); SqueezeDet+ at batch 8
-        loses 11 % with three (1.147 against 1.018 ms)."""
-        n = getattr(self, "serve_lanes", None)          # (attribute: set by a caller that measures both forms in one process)
+    def _serving_lanes(self, defer, lanes=None):
+        """The serving lanes of detect_filter_pipelined (None: single-lane operation).  Used for deferred steps on native plans.
+        Count: the `lanes` argument, else the attribute serve_lanes (None = SQDET_SERVE_LANES from the environment, default 2).
+        At batch 32 three lanes are no better than two (0.396 against 0.390 ms per step); at batch 1, where a forward leaves most of
+        the chip idle, three give 11.1-11.8 k img/s against 8.3 k with two and four fall back to 8.4 k (bench.py's sqdet_sample_b1
+        config asks for three); SqueezeDet+ at batch 8 loses 11 % with three (1.147 against 1.018 ms).  A change of the count
+        flushes the old lanes first; the new set's streams are checked again at its first use (warm_up_lanes)."""
+        n = lanes if lanes is not None else self.serve_lanes
         if n is None:
             n = int(os.environ.get("SQDET_SERVE_LANES", "2"))
+        n = int(n)
+        if n < 1:
+            raise SqdetError("detect_filter_pipelined: lanes must be >= 1, got %r" % (n,))
         if not defer or self.NATIVE_ARCH is None or n < 2:
+            if self._lanes is not None and defer:
+                self.flush_pipeline()                     # (the lane set may hold pending rows: carried out ahead of the single-lane call; the set is kept)
             return None
-        if getattr(self, "_lanes", None) is None or len(self._lanes) != n:
-            if getattr(self, "_lanes", None) is not None:
+        if self._lanes is None or len(self._lanes) != n:
+            if self._lanes is not None:
                 self.flush_pipeline()
-            prio = [int(v) for v in os.environ.get("SQDET_LANE_PRIORITIES", "").split(",") if v] + [0] * n      # (experiments)
-            self._lanes = [dict(which=k, stream=torch.cuda.Stream(device=self.device, priority=prio[k]), in_ev=torch.cuda.Event(), pipe=None,
+            self._lanes = [dict(which=k, stream=torch.cuda.Stream(device=self.device), in_ev=torch.cuda.Event(), pipe=None,
                                 post_stream=None, post_event=None) for k in range(n)]
             self._lane_next = 0
+            self._lanes_checked = False
+            self._lane_check = None
         return self._lanes
 
     def flush_pipeline(self):
-        """defer=True: enqueue the side work of the last call(s) now (nothing to overlap it with); the caller's stream then waits
-        for the serving lanes."""
+        """Enqueues the side work of the last call(s) now (nothing to overlap it with) and makes the CALLER's stream wait for all of
+        it: every serving lane's stream AND every post-processing side stream (a lane's own, and the single-lane one).  After
+        flush_pipeline() a synchronisation of the caller's stream alone (torch.cuda.current_stream().synchronize()) is enough to
+        read every returned row, device or pinned host."""
         with torch.cuda.device(self.device):
-            lanes = getattr(self, "_lanes", None)
-            if lanes is not None:
-                cur = torch.cuda.current_stream()
-                for lane in lanes:
+            cur = torch.cuda.current_stream()
+            if self._lanes is not None:
+                for lane in self._lanes:
                     with torch.cuda.stream(lane["stream"]), self._lane_state(lane):
                         self._flush_pipe(self._pipe)
                     cur.wait_stream(lane["stream"])
+                    if lane["post_stream"] is not None:
+                        cur.wait_stream(lane["post_stream"])
             self._flush_pipe(getattr(self, "_pipe", None))
+            if getattr(self, "post_stream", None) is not None:
+                cur.wait_stream(self.post_stream)
 
     def _flush_pipe(self, pipe):
         if pipe is not None and pipe.get("pending") is not None:
@@ -706,8 +734,7 @@ class ModelSkeleton:
                                           mc.TOP_N_DETECTION, mc.NMS_THRESH)
                     else:
                         self._enqueue_post(prev, None)
-                sig = getattr(self, "_lane_signal", None)
-                plan.set_signal(*(sig if sig else (-1, None)))
+                plan.set_signal(-1, None)
                 plan.forward(x, s["preds"], scores=s["det"][1])
                 pipe["pending"] = s
                 s["used"] = False                       # (no side-stream reader to wait for)

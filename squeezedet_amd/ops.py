@@ -852,8 +852,58 @@ def box_calibration(device, mfma_iters=8192, copy_mib=1024, reps=3):
         tm, tc = e0.elapsed_time(e1), e1.elapsed_time(e2)
         best_m = tm if best_m is None else min(best_m, tm)
         best_c = tc if best_c is None else min(best_c, tc)
-    return {"box_mfma_tflops": round(flops.value / (best_m * 1e-3) / 1e12, 1), "box_mfma_ms": round(best_m, 4),
-            "box_copy_gbs": round(2.0 * n / (best_c * 1e-3) / 1e9, 1), "box_copy_ms": round(best_c, 4)}
+    res = {"box_mfma_tflops": round(flops.value / (best_m * 1e-3) / 1e12, 1), "box_mfma_ms": round(best_m, 4),
+           "box_copy_gbs": round(2.0 * n / (best_c * 1e-3) / 1e9, 1), "box_copy_ms": round(best_c, 4)}
+    # round 5: what IS the box's MFMA ceiling -- 32x32x16 at four waves per SIMD (the guide's 2495 TF/s form) on non-trivial and
+    # on all-zero operands, with the effective shader clock and the matrix pipe's busy fraction from in-kernel counters
+    try:
+        v = calib_mfma_variant(device, 1, 4, False, reps=reps)
+        z = calib_mfma_variant(device, 1, 4, True, reps=reps)
+        res.update(box_mfma_tflops_32x32=v["tflops"], effective_clock_mhz=v["effective_clock_mhz"], mfma_busy_frac_32x32=v["mfma_busy_frac"],
+                   box_mfma_tflops_32x32_zero_operands=z["tflops"], effective_clock_mhz_zero_operands=z["effective_clock_mhz"])
+    except _lib.SqdetError as e:      # (never voids the two figures above)
+        res["box_mfma_32x32_error"] = str(e)[:120]
+    return res
+
+
+# pipe cycles one MFMA occupies its SIMD's matrix unit for (MI355X_MICROARCH.md, per-instruction cycle constants: 32x32x16 f16 issues
+# back to back at 32 cycles per SIMD = SQ_VALU_MFMA_BUSY_CYCLES per instruction; 16x16x32 at half that)
+MFMA_PIPE_CYCLES = {0: 16.0, 1: 32.0}
+
+
+def calib_mfma_variant(device, shape, waves_per_simd, zero_operands, iters=None, reps=3):
+    """sqdet_calib_mfma2 timed with events: {tflops, ms, effective_clock_mhz, cycles_per_mfma_per_simd, mfma_busy_frac, workgroups}.
+    shape 0 = 16x16x32, 1 = 32x32x16 (float16); `waves_per_simd` co-resident workgroups per CU; zero_operands: all-zero A / B.
+    effective_clock_mhz = 100 MHz x (s_memtime cycles / s_memrealtime ticks), median over the workgroups; cycles_per_mfma_per_simd =
+    a wave's cycles / its MFMAs / waves_per_simd (the SIMD's issue interval); mfma_busy_frac = MFMA_PIPE_CYCLES / that."""
+    import numpy as np
+    nacc = 8 if shape == 0 else 4
+    if iters is None:
+        iters = (8192 * 2 // waves_per_simd) if shape == 0 else (8192 // waves_per_simd)       # ~2 ms at the guide's rate
+    cap = 256 * 8 * 8
+    scratch = torch.empty(cap * 256 // 8, dtype=torch.float32, device=device)
+    ticks = torch.zeros(cap * 2 // 8 * 8, dtype=torch.int64, device=device)
+    flops, wgs = C.c_double(0.0), C.c_int(0)
+    best = None
+    for r in range(reps + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().sqdet_calib_mfma2(_dev(scratch, "scratch"), scratch.numel(), _dev(ticks, "ticks"), ticks.numel(), int(iters), int(shape),
+                                      int(waves_per_simd), int(bool(zero_operands)), C.byref(flops), C.byref(wgs), stream_ptr()), "sqdet_calib_mfma2")
+        e1.record()
+        torch.cuda.synchronize()
+        if r == 0:
+            continue
+        ms = e0.elapsed_time(e1)
+        if best is None or ms < best[0]:
+            t = ticks[:2 * wgs.value].cpu().numpy().reshape(-1, 2).astype(np.float64)
+            best = (ms, float(np.median(t[:, 0])), float(np.median(t[:, 1])))
+    ms, cyc, wall = best
+    per_simd = cyc / (iters * nacc) / waves_per_simd
+    return {"shape": "16x16x32" if shape == 0 else "32x32x16", "waves_per_simd": waves_per_simd, "zero_operands": bool(zero_operands),
+            "tflops": round(flops.value / (ms * 1e-3) / 1e12, 1), "ms": round(ms, 4), "workgroups": wgs.value,
+            "effective_clock_mhz": round(100.0 * cyc / max(wall, 1.0), 1), "cycles_per_mfma_per_simd": round(per_simd, 2),
+            "mfma_busy_frac": round(MFMA_PIPE_CYCLES[shape] / per_simd, 4)}
 
 
 def set_option(name, value):

@@ -2,6 +2,7 @@
 checkpoints): KITTI-shaped images as demo.py:187-190 feeds them, and random-init weights of
 the reference architecture (truncated normal like nn_skeleton.py:527-528 but
 He-scaled so activations do not collapse and scores spread)."""
+import functools
 import math
 
 import numpy as np
@@ -69,31 +70,50 @@ def synthetic_params(model, seed=0):
 #     PLANT_IOU_MARGIN of NMS_THRESH (the boxes are a closed form of cell, shape and the constant deltas).
 PLANT_W = 2.0 ** -10
 PLANT_OBJ, PLANT_OFF, PLANT_BG = 144.0, -100.0, 16          # object colour / other colours / background amplitude (integers)
-PLANT_Q, PLANT_DET_SCALE = 0.875, 16.0
+PLANT_DET_SCALE = 16.0
 PLANT_CONF_BIAS, PLANT_CONF_GAIN = -6.0, 4.0
 PLANT_IOU_MARGIN = 0.04
 FIRES = ["fire%d" % i for i in range(2, 12)]
+# Per architecture: conv1 (size, stride, padding), the padding of its three 3x3/s2 max-pools, the object's side (= conv1's window)
+# and the detector threshold q of fire11/expand1x1 (relu(16 * (x - q))).
+#   squeezeDet  (nets/squeezeDet.py:40-57):     3x3/s2 SAME, SAME pools; a 3x3 object reads 9*144*2^-10 = 1.265625, every partial
+#                                               window overlap <= 0.52 -> q = 0.875;
+#   squeezeDet+ (nets/squeezeDetPlus.py:40-61): 7x7/s2 VALID, VALID pools; a 7x7 object reads 49*144*2^-10 = 6.890625, the largest
+#                                               partial overlap (a window two pixels off: 35 object pixels + 14 of background) <= 5.15
+#                                               -> q = 6.0 (detector 14.25 on an object, exact zero elsewhere).
+PLANT_GEOM = {"squeezeDet": dict(conv=(3, 2, "SAME"), pools=("SAME",) * 3, q=0.875),
+              "squeezeDet+": dict(conv=(7, 2, "VALID"), pools=("VALID",) * 3, q=6.0)}
+PLANT_Q = PLANT_GEOM["squeezeDet"]["q"]
 
 
-def _same_geom(n, k=3, s=2):
-    """TF SAME: (output size, pad before)."""
+def _geom(n, k=3, s=2, padding="SAME"):
+    """TF geometry of one conv / pool dimension: (output size, pad before)."""
+    if padding == "VALID":
+        return (n - k) // s + 1, 0
     o = -(-n // s)
     return o, max((o - 1) * s + k - n, 0) // 2
 
 
-def _single_cell_positions(n_img):
+def _same_geom(n, k=3, s=2):
+    return _geom(n, k, s, "SAME")
+
+
+@functools.lru_cache(maxsize=None)
+def _single_cell_positions(n_img, arch="squeezeDet"):
     """Per final-grid index c (one image dimension of n_img pixels): the conv1 output positions whose value reaches final cell c
-    and NO other through the three SAME 3x3/s2 max-pools, and whose conv1 window lies inside the image.  Returns
+    and NO other through the three 3x3/s2 max-pools, and whose conv1 window lies inside the image.  Returns
     ({c: [positions]}, conv1 pad before, final size)."""
-    n1, p0 = _same_geom(n_img)
+    g = PLANT_GEOM[arch]
+    ck, cs, cpad = g["conv"]
+    n1, p0 = _geom(n_img, ck, cs, cpad)
     sizes, pads = [n1], []
-    for _ in range(3):
-        o, p = _same_geom(sizes[-1])
+    for mode in g["pools"]:
+        o, p = _geom(sizes[-1], 3, 2, mode)
         sizes.append(o)
         pads.append(p)
     out = {}
     for pos in range(n1):
-        if not (2 * pos - p0 >= 0 and 2 * pos - p0 + 2 < n_img):
+        if not (cs * pos - p0 >= 0 and cs * pos - p0 + ck - 1 < n_img):
             continue
         reach = {pos}
         for lvl in range(3):
@@ -108,11 +128,17 @@ def _single_cell_positions(n_img):
     return out, p0, sizes[-1]
 
 
-def _planted_boxes(mc, cell_y, cell_x, c, shapes=None):
+def _grid(mc, arch="squeezeDet"):
+    """(gh, gw) of the final map of `arch` on mc's image size."""
+    return _single_cell_positions(int(mc.IMAGE_HEIGHT), arch)[2], _single_cell_positions(int(mc.IMAGE_WIDTH), arch)[2]
+
+
+def _planted_boxes(mc, cell_y, cell_x, c, shapes=None, arch="squeezeDet"):
     """[3, 4] (cx, cy, w, h) of the anchors an object of colour c plants at a cell (or of the given shapes), as
     interpret_output decodes them (nn_skeleton.py:175-215: delta decode, clip to the image, back to centre form)."""
     K = mc.ANCHOR_PER_GRID
-    gw = int(round(len(mc.ANCHOR_BOX) / K / _same_geom(_same_geom(_same_geom(_same_geom(mc.IMAGE_HEIGHT)[0])[0])[0])[0]))
+    gw = _grid(mc, arch)[1]
+    assert len(mc.ANCHOR_BOX) == K * gw * _grid(mc, arch)[0], "mc.ANCHOR_BOX does not belong to the %s grid" % arch
     out = []
     for k in (shapes if shapes is not None else range(c, K, 3)):
         ax, ay, aw, ah = [float(v) for v in mc.ANCHOR_BOX[(cell_y * gw + cell_x) * K + k]]
@@ -145,20 +171,22 @@ def planted_deltas(k):
     return (0.125 * ((k % 3) - 1), 0.0625 * ((k % 2) * 2 - 1), 0.25 * (k % 2), -0.125 * (k % 3))
 
 
-def planted_images(mc, batch, seed=0, objects_per_colour=4):
+def planted_images(mc, batch, seed=0, objects_per_colour=4, arch="squeezeDet"):
     """float32 [B,H,W,3] integer-valued images (exact in float16) with `objects_per_colour` objects of each of the three
-    colours per image, and the list of planted (image, cell_y, cell_x, colour)."""
+    colours per image, and the list of planted (image, cell_y, cell_x, colour).  arch: whose conv1 / pool geometry the objects
+    are placed for (PLANT_GEOM); an object is one conv1 window wide."""
     rng = np.random.RandomState(seed)
     H, W = int(mc.IMAGE_HEIGHT), int(mc.IMAGE_WIDTH)
-    rows, py0, gh = _single_cell_positions(H)
-    cols, px0, gw = _single_cell_positions(W)
+    side, stride = PLANT_GEOM[arch]["conv"][:2]
+    rows, py0, gh = _single_cell_positions(H, arch)
+    cols, px0, gw = _single_cell_positions(W, arch)
     x = rng.randint(-PLANT_BG, PLANT_BG + 1, size=(batch, H, W, 3)).astype(np.float32)
     planted = []
     # the top-N is filled, behind the 9 * objects_per_colour planted anchors, with the highest-index anchors of shape 8 (the
     # highest background level; class 2): their boxes take part in class 2's NMS and in its IoU margins
     K = mc.ANCHOR_PER_GRID
     nfill = max(0, mc.TOP_N_DETECTION - 3 * 3 * objects_per_colour)
-    fill = [_planted_boxes(mc, cell // gw, cell % gw, 2, shapes=[K - 1])[0] for cell in range(gh * gw - 1, gh * gw - 1 - nfill, -1)]
+    fill = [_planted_boxes(mc, cell // gw, cell % gw, 2, shapes=[K - 1], arch=arch)[0] for cell in range(gh * gw - 1, gh * gw - 1 - nfill, -1)]
     for b in range(batch):
         for attempt in range(400):
             cells, boxes, ok = [], {0: [], 1: [], 2: list(fill)}, True
@@ -168,7 +196,7 @@ def planted_images(mc, batch, seed=0, objects_per_colour=4):
                     if any(abs(cy - oy) < 2 and abs(cx - ox) < 2 for oy, ox, _ in cells):
                         ok = False              # (two objects never share or touch a cell: no window sees two of them)
                     cells.append((cy, cx, c))
-                    boxes[c].extend(_planted_boxes(mc, cy, cx, c))
+                    boxes[c].extend(_planted_boxes(mc, cy, cx, c, arch=arch))
             for c in range(3):
                 bl = boxes[c]
                 for i in range(len(bl)):
@@ -181,16 +209,17 @@ def planted_images(mc, batch, seed=0, objects_per_colour=4):
             raise RuntimeError("planted_images: no object layout with IoU margins found for image %d" % b)
         for cy, cx, c in cells:
             y1, x1 = rows[cy][rng.randint(len(rows[cy]))], cols[cx][rng.randint(len(cols[cx]))]
-            iy, ix = 2 * y1 - py0, 2 * x1 - px0
-            x[b, iy:iy + 3, ix:ix + 3, :] = PLANT_OFF
-            x[b, iy:iy + 3, ix:ix + 3, c] = PLANT_OBJ
+            iy, ix = stride * y1 - py0, stride * x1 - px0
+            x[b, iy:iy + side, ix:ix + side, :] = PLANT_OFF
+            x[b, iy:iy + side, ix:ix + side, c] = PLANT_OBJ
             planted.append((b, cy, cx, c))
     return torch.from_numpy(x), planted
 
 
-def planted_params(params, anchors_per_grid=9, classes=3):
+def planted_params(params, anchors_per_grid=9, classes=3, arch="squeezeDet"):
     """params with the three detector channels and the planted head installed (a new dict; untouched tensors are shared)."""
     K, C = int(anchors_per_grid), int(classes)
+    q = PLANT_GEOM[arch]["q"]
     assert C == 3, "three colours <-> three classes"
     p = dict(params)
 
@@ -219,7 +248,7 @@ def planted_params(params, anchors_per_grid=9, classes=3):
         for c in range(3):
             t[0, 0, c, c] = PLANT_DET_SCALE
     upd("fire11/expand1x1/kernels", det_k)
-    upd("fire11/expand1x1/biases", lambda t: t[:3].fill_(-PLANT_Q * PLANT_DET_SCALE))
+    upd("fire11/expand1x1/biases", lambda t: t[:3].fill_(-q * PLANT_DET_SCALE))
     w12 = torch.zeros_like(p["conv12/kernels"], dtype=torch.float32)
     b12 = torch.zeros(K * (C + 5), dtype=torch.float32)
     for k in range(K):

@@ -52,35 +52,42 @@ def image_margins(mc, ref, got):
     return dict(m_sel=m_sel, m_ord=m_ord, m_cls=m_cls, m_iou=float(m_iou), n_p=n_p, n_iou=n_iou, decidable=bool(decidable))
 
 
-def run(size, dtype_name, nimg=16, seed=40, device="cuda:0", planted=False, batch=None, pipelined=False):
+def run(size, dtype_name, nimg=16, seed=40, device="cuda:0", planted=False, batch=None, pipelined=False, arch="squeezeDet", lanes=None):
     """Runs seeded images through the device path and the oracle; returns (rows, summary) for the first nimg.
     planted: planted-object images + detector channels + head (squeezedet_amd/synthetic.py) on both sides.  batch: device batch
     (>= nimg; default nimg).  pipelined: the device picks come from detect_filter_pipelined (bench.py's step) instead of
-    detect -> filter_prediction_batch."""
+    detect -> filter_prediction_batch; lanes: that call is then a DEFERRED one on `lanes` serving lanes, completed by
+    flush_pipeline().  arch: "squeezeDet" (size = (H, W)) or "squeezeDet+" (its one size, 375x1242: size is ignored)."""
     import torch
 
     import squeezedet_amd as S
     from squeezedet_amd import nets
     tdt = torch.float16 if dtype_name == "fp16" else torch.float32
-    mc = S.kitti_squeezeDet_config_for_input(*size)
+    if arch == "squeezeDet+":
+        mc, omc, cls = S.kitti_squeezeDetPlus_config(), O.kitti_squeezeDetPlus_config(), nets.SqueezeDetPlus
+        size = (omc.IMAGE_HEIGHT, omc.IMAGE_WIDTH)
+    else:
+        mc, omc, cls = S.kitti_squeezeDet_config_for_input(*size), O.squeezeDet_config_for_input(*size), nets.SqueezeDet
     mc.LOAD_PRETRAINED_MODEL = False
     batch = batch or nimg
     mc.BATCH_SIZE = batch
-    m = nets.SqueezeDet(mc, gpu_id="0", dtype=tdt)
-    params = O.init_params("squeezeDet", seed=seed, storage=dtype_name)
-    omc = O.squeezeDet_config_for_input(*size)
+    m = cls(mc, gpu_id="0", dtype=tdt)
+    params = O.init_params(arch, seed=seed, storage=dtype_name)
     if planted:
         # planted objects (squeezedet_amd/synthetic.py: a data generator, not arithmetic under test): objects in the image, three
         # exact detector channels through every launch, a saturating head -- every decision has a margin by construction
         from squeezedet_amd import synthetic as SY
-        params = SY.planted_params(params, omc.ANCHOR_PER_GRID, omc.CLASSES)
-        x, _ = SY.planted_images(omc, batch, seed=seed + 1)
+        params = SY.planted_params(params, omc.ANCHOR_PER_GRID, omc.CLASSES, arch=arch)
+        x, _ = SY.planted_images(omc, batch, seed=seed + 1, arch=arch)
     else:
         x = O.synthetic_images(batch, size[0], size[1], seed=seed + 1, storage=dtype_name)
     m.load_params(params)
     xd = x.to(device, tdt)
     outs = m.run([m.det_boxes, m.det_probs, m.det_class, m.pred_class_probs, m.pred_conf], {m.image_input: xd})
-    if pipelined:
+    if pipelined and lanes:
+        ob, op, oc, oi, cnt = m.detect_filter_pipelined(xd, to_host=True, defer=True, lanes=lanes)   # pinned host rows ...
+        m.flush_pipeline()                                                     # ... carried out by the flush, complete after the sync below
+    elif pipelined:
         ob, op, oc, oi, cnt = m.detect_filter_pipelined(xd, to_host=True)      # pinned host rows, complete after the sync below
     else:
         ob, op, oc, oi, cnt = m.filter_prediction_batch(outs[0], outs[1], outs[2])
@@ -88,7 +95,7 @@ def run(size, dtype_name, nimg=16, seed=40, device="cuda:0", planted=False, batc
     g = [o.cpu().numpy()[:nimg] for o in outs]
     ob, op, oc = ob.cpu().numpy(), op.cpu().numpy(), oc.cpu().numpy()
     oi, cnt = oi.cpu().numpy(), cnt.cpu().numpy()
-    _, ref, dets = O.detect("squeezeDet", omc, params, x[:nimg], storage=dtype_name)
+    _, ref, dets = O.detect(arch, omc, params, x[:nimg], storage=dtype_name)
     rows = []
     for i in range(nimg):
         r = {k: ref[k][i] for k in ("det_boxes", "det_probs", "det_class", "pred_class_probs", "pred_conf")}

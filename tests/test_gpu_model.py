@@ -252,19 +252,20 @@ def test_pipelined_step_equals_sequential():
                 assert torch.equal(got[t][i, :n[i]], want[t][i, :n[i]])
 
 
-@pytest.mark.parametrize("lanes", [2, 1])
+@pytest.mark.parametrize("lanes", [3, 2, 1])
 @pytest.mark.parametrize("mode", ["ride", "signal"])
-@pytest.mark.parametrize("batch", [32, 5])
+@pytest.mark.parametrize("batch", [32, 5, 1])
 def test_deferred_pipelined_step_equals_sequential(mode, batch, lanes, monkeypatch):
-    """defer=True (bench.py's step): the decode + filter of call k is carried out by call k+1 -- "ride": as rider workgroups
-    of that forward's fire_chain launches (sqdet_net_set_post_job: same stream, rows written straight to pinned host
+    """defer=True (bench.py's step): the decode + filter of call k is carried out by call k+1 of its lane -- "ride": as rider
+    workgroups of that forward's fire_chain launches (sqdet_net_set_post_job: same stream, rows written straight to pinned host
     memory; 512-thread form of the filter body); "signal": on the side stream behind that forward's mid-point event, the
-    images walked by 16 workgroups -- and flush_pipeline() carries out the last one.  Every step's rows, read after the
-    NEXT call (or the flush), equal detect -> filter_prediction_batch exactly.  lanes = 2 (the default since round 4): consecutive
-    calls alternate between two serving lanes (two plans, two HIP streams, nothing ordering them), so a call's rows are carried out
-    by the SECOND-next call (the next one of its lane) -- read there, they must be the same."""
+    images walked by 16 workgroups -- and flush_pipeline() carries out the last ones.  `lanes` (the explicit argument; 2 is the
+    model default, bench.py's sqdet_sample_b1 config runs 3 at batch 1, 1 is the single-stream form): consecutive calls alternate
+    between `lanes` serving lanes (plans, HIP streams, nothing ordering them), so a call's rows are carried out by the call
+    `lanes` later -- read there, and for the last `lanes` calls after flush_pipeline() + a synchronisation of the CALLER's stream
+    only, they must equal detect -> filter_prediction_batch exactly."""
     monkeypatch.setenv("SQDET_POST_DEFER", mode)
-    monkeypatch.setenv("SQDET_SERVE_LANES", str(lanes))
+    monkeypatch.delenv("SQDET_SERVE_LANES", raising=False)
     m, mc, params, storage = _model("squeezeDet", torch.float16, batch, (375, 1242))
     xs = [O.synthetic_images(batch, 375, 1242, seed=s, storage=storage).to(DEV, torch.float16) for s in (3, 4, 5)]
     seq = []
@@ -275,23 +276,97 @@ def test_deferred_pipelined_step_equals_sequential(mode, batch, lanes, monkeypat
     plan = m._native_plan(batch)
     assert plan.overlap_layer() >= 0 and plan.scores_supported() and plan.rider_capacity() >= batch
     outs, hist = [], []
-    for x in xs + xs:
-        hist.append(m.detect_filter_pipelined(x, to_host=True, defer=True))
+    for x in xs + xs + xs[:1]:
+        hist.append(m.detect_filter_pipelined(x, to_host=True, defer=True, lanes=lanes))
         if len(hist) > lanes:                                   # the rows of the call `lanes` back: enqueued by THIS call
             torch.cuda.synchronize()
             outs.append([t.clone() for t in hist[-1 - lanes]])
+    assert (m._lanes is not None and len(m._lanes) == lanes) if lanes > 1 else True
+    if lanes > 1:
+        chk = m._lane_check                                     # warm_up_lanes ran at the first call: every lane k >= 1 was paired with lane 0
+        assert chk is not None and len(chk["pairs"]) == lanes - 1 and chk["forwards_per_sample"] >= 16
     m.flush_pipeline()
-    torch.cuda.synchronize()
+    torch.cuda.current_stream().synchronize()                   # the caller's stream alone (flush_pipeline made it wait for every lane)
     for out in hist[-lanes:]:
         outs.append([t.clone() for t in out])
-    seq = seq + seq
-    assert len(outs) == 6
+    seq = seq + seq + seq[:1]
+    assert len(outs) == 7
     for got, want in zip(outs, seq):
         n = want[4].cpu().numpy()
         assert np.array_equal(got[4].numpy(), n)
         for i in range(batch):
             for t in range(4):
                 assert torch.equal(got[t][i, :n[i]], want[t][i, :n[i]].cpu())
+
+
+@pytest.mark.parametrize("arch,dtype,batch", [("squeezeDet", torch.float32, 3), ("squeezeDet+", torch.float16, 8)], ids=["sqdet-fp32", "plus-fp16-b8"])
+def test_deferred_step_on_plans_without_riders_is_complete_after_flush(arch, dtype, batch):
+    """Plans that cannot carry riders (float32 SqueezeDet; SqueezeDet+, which has no fire_chain launches -- BASELINE configs[3],
+    bench.py's sqdetplus_infer: batch 8, two lanes) run decode + filter + the row copy on each lane's own side stream.
+    flush_pipeline() must cover those too: after it, a synchronisation of the caller's stream ALONE makes every row readable, and
+    every step's rows equal detect -> filter_prediction_batch bitwise."""
+    size = (375, 1242) if arch == "squeezeDet+" else (128, 256)
+    m, mc, params, storage = _model(arch, dtype, batch, None if arch == "squeezeDet+" else size)
+    xs = [O.synthetic_images(batch, size[0], size[1], seed=s, storage=storage).to(DEV, dtype) for s in (21, 22, 23)]
+    seq = []
+    for x in xs:
+        b, p, c = m.detect(x)
+        seq.append([t.clone() for t in m.filter_prediction_batch(b, p, c)])
+    torch.cuda.synchronize()
+    assert m._native_plan(batch).rider_capacity() < batch
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                               # a caller on its own stream
+        hist = [m.detect_filter_pipelined(x, to_host=True, defer=True) for x in xs]        # (default lane count: 2)
+        assert m._lanes is not None and len(m._lanes) == 2 and all(ln["post_stream"] is not None for ln in m._lanes)
+        m.flush_pipeline()
+        side.synchronize()                                      # NOT a device-wide synchronize
+        outs = [[t.clone() for t in out] for out in hist[-2:]]  # (slot reuse: the rows of the last `lanes` x 2 calls are live)
+    for got, want in zip(outs, seq[-2:]):
+        n = want[4].cpu().numpy()
+        assert np.array_equal(got[4].numpy(), n) and (n >= 1).all()
+        for i in range(batch):
+            for t in range(4):
+                assert torch.equal(got[t][i, :n[i]], want[t][i, :n[i]].cpu())
+
+
+def test_squeezedet_plus_serving_step_picks_identical_planted_objects(capsys):
+    """BASELINE configs[3] as bench.py runs it (sqdetplus_infer: SqueezeDet+ float16, batch 8, detect_filter_pipelined(defer=True) on two
+    lanes) pinned image -> picks on the 22x76 / 15048-anchor grid against the float16-storage oracle, on planted objects
+    (squeezedet_amd/synthetic.py, SqueezeDet+ geometry: 7x7 objects through the 7x7/s2 VALID stem and the VALID pools): all 8
+    images decidable, anchor indices in output order / classes identical, boxes to 2e-6."""
+    from tests import decision_margins as DM
+    rows, summary = DM.run(None, "fp16", nimg=8, seed=60, planted=True, batch=8, pipelined=True, arch="squeezeDet+", lanes=2)
+    with capsys.disabled():
+        print("\n[planted objects, SqueezeDet+] " + DM.format_report(rows, summary))
+    for r in rows:
+        assert r["decidable"], "image %d: a decision margin is within the measured noise: %r" % (r["image"], r)
+        assert r["same_picks"] and r["same_boxes"], "image %d: the picks differ: %r" % (r["image"], r)
+        assert r["n_strong"] >= 8 and r["m_iou"] >= 0.03, r
+    assert summary["all_same"] == 8 and summary["decidable"] == 8, summary
+
+
+def test_pipelined_default_path_preds_vs_oracle_random_weights():
+    """The serving step's OWN forward -- the default kernels of the float16 plan (DMA stem, fire_dma, fire_chain, ConvDet's SCORE
+    form) as detect_filter_pipelined(defer=True) launches them on its lanes, batch 32, random weights (every channel matters, unlike
+    the planted head) -- against the float16-storage oracle at preds level: the slot's preds tensor of images 0 and 17 within the
+    float16 tolerance, and bitwise equal to the plain plan forward."""
+    m, mc, params, storage = _model("squeezeDet", torch.float16, 32, (375, 1242))
+    x = O.synthetic_images(32, 375, 1242, seed=5, storage="fp16")
+    xd = x.to(DEV, torch.float16)
+    for _ in range(2):                                           # one call per lane
+        m.detect_filter_pipelined(xd, to_host=True, defer=True)
+    m.flush_pipeline()
+    torch.cuda.synchronize()
+    plain = m.run([m.preds], {m.image_input: xd})[0]
+    torch.cuda.synchronize()
+    for lane in m._lanes:
+        used = [s for s in lane["pipe"]["slots"] if s.get("ride")]
+        assert len(used) == 1
+        preds = used[0]["preds"]
+        assert torch.equal(preds, plain)
+        for i in (0, 17):
+            ref = O.forward("squeezeDet", params, x[i:i + 1], "fp16")
+            _check_layers(preds[i:i + 1], ref, torch.float16, "preds[%d] (pipelined, lane %d)" % (i, lane["which"]))
 
 
 def test_post_job_riders_equal_the_filter_launch():

@@ -303,6 +303,42 @@ def test_resnet50_mixed_precision_training_step_vs_oracle():
     assert min(hist[1:]) < hist[0], hist
 
 
+def test_resnet50_full_size_mixed_precision_training_step_vs_oracle():
+    """BASELINE configs[4]'s kernel selection (bench.py res50_train_fp16: 375x1242, batch 8): one mixed-precision step at
+    5x375x1242 -- the 47x155 and 24x78 maps are then above the 8 k-pixel threshold of the streaming 1x1 as at batch 8, the 7x7
+    stem, the 93x310 pools and the many-slab weight gradients run at their benchmark shapes -- losses and preds against the
+    float16-storage oracle, every gradient against the oracle's backward with the forward values pinned to the device's
+    activations (tests/test_gpu_train.py has the reasoning)."""
+    from oracle import train_oracle as TO
+    size, B = (375, 1242), 5
+    tr, mc, params = _trainer(size, B, dtype=torch.float16, loss_scale=256.0)
+    x = O.synthetic_images(B, size[0], size[1], seed=71)
+    mask, delta, box, labels = TO.synthetic_labels(mc, B, seed=72)
+    gh, gw = tr.model.preds.get_shape()[1:3]
+    assert (gh, gw) == (24, 78)
+    dm = torch.from_numpy((np.random.RandomState(73).uniform(size=(B, gh, gw, 1024)) < 0.5).astype(np.float32))
+    ref = R.loss_and_grads(mc, params, x, dm, mask, delta, box, labels, storage="fp16")
+    for _ in range(24):
+        out = tr.step(x, mask, delta, box, labels, dropout_mask=dm, apply_update=False, keep_activations=True)
+        if bool(torch.isfinite(tr.flat_grads).all()):
+            break
+        tr.loss_scale /= 4.0
+    torch.cuda.synchronize()
+    assert out["preds"].dtype == torch.float16 and bool(torch.isfinite(tr.flat_grads).all()), tr.loss_scale
+    for k in ("class_loss", "conf_loss", "bbox_loss"):
+        np.testing.assert_allclose(float(out[k]), ref[k], rtol=2e-2)
+    _close(out["preds"], ref["preds"], torch.float16, "preds (full-size float16 training forward)")
+    acts = {k: v.float().cpu() for k, v in out["activations"].items()}
+    pinned = R.loss_and_grads(mc, params, x, dm, mask, delta, box, labels, storage="fp16", override=acts)
+    assert set(pinned["grads"]) == set(tr.names)
+    for name, gref in pinned["grads"].items():
+        wdg = mc.WEIGHT_DECAY * params[name] if name.endswith("/kernels") else 0.0
+        got = tr.gview[name].cpu() + wdg
+        scale = float(gref.abs().max())
+        err = float((got - gref).abs().max())
+        assert err <= 1e-2 * scale + 1e-7, "%s: grad err %g vs scale %g" % (name, err, scale)
+
+
 def test_resnet50_training_reduces_loss():
     from oracle import train_oracle as TO
     tr, mc, params = _trainer(seed=5)

@@ -193,6 +193,20 @@ def test_maxpool_window_index_forward_and_backward(dtype):
     assert bool((idx[0, 0, 0] == first).all())
     dy = torch.from_numpy(rs.randn(*y.shape).astype(np.float32)).to(DEV, dtype)
     assert torch.equal(ops.maxpool_bwd_idx(idx, y, dy, (9, 11), 3, 2, "SAME", relu=False), ops.maxpool_bwd(x, dy, 3, 2, "SAME", relu=False))
+    # NaN cells (round-4 ADVICE): a NaN never wins the comparison wherever it sits in the window -- first valid cell or not -- so the
+    # training forward's pooled tensor stays BITWISE the inference pool's, the index names the first maximum among the other cells
+    # (the first valid cell when there is none), and both backward kernels route the gradient alike
+    xn = torch.from_numpy(np.round(rs.randn(2, 13, 17, ev) * 2).astype(np.float32) / 2).to(DEV, dtype)
+    xn[0, 0, 0, :] = float("nan")            # the FIRST valid cell of window (0, 0)
+    xn[0, 5, 6, :] = float("nan")            # an inner cell of several windows
+    xn[1, 3:6, 3:6, :] = float("nan")        # a whole window of NaN (output cell (2, 2): -inf, the first cell named)
+    yn0 = ops.maxpool_nhwc(xn, 3, 2, "SAME")
+    yn, idxn = ops.maxpool_nhwc_idx(xn, 3, 2, "SAME")
+    torch.cuda.synchronize()
+    assert torch.equal(yn.view(torch.int16 if dtype == torch.float16 else torch.int32), yn0.view(torch.int16 if dtype == torch.float16 else torch.int32))
+    assert not bool(torch.isnan(yn).any()) and int(idxn.max()) < 9
+    dyn = torch.from_numpy(rs.randn(*yn.shape).astype(np.float32)).to(DEV, dtype)
+    assert torch.equal(ops.maxpool_bwd_idx(idxn, yn, dyn, (13, 17), 3, 2, "SAME", relu=False), ops.maxpool_bwd(xn, dyn, 3, 2, "SAME", relu=False))
 
 
 def test_fire_backward_channel_slices_and_accumulate():
@@ -757,6 +771,38 @@ def test_squeezedet_plus_training_step_vs_oracle():
         scale = float(gref.abs().max())
         err = float((got - gref).abs().max())
         assert err <= 1e-3 * scale + 1e-7, "%s: grad err %g vs scale %g" % (name, err, scale)
+
+
+def test_squeezedet_full_size_training_step_vs_oracle():
+    """BASELINE configs[2]'s kernel selection (bench.py sqdet_train_fp32: 384x1248, batch 20): at full size the training
+    forward / backward run other kernels than at the 128x256 of test_full_training_step_vs_oracle -- conv1x1_deepk on every
+    >= 8 k-pixel 1x1 (batch 5 puts the 24x78 maps above that too), fire_stream's keep forms, many-slab weight gradients, the
+    index pools on 192x624 maps.  One float32 step at 5x384x1248: losses, preds and every gradient against the oracle's
+    autograd (forward values pinned to the device's activations for the gradients, as in the SqueezeDet+ test below)."""
+    B, size = 5, (384, 1248)
+    tr, mc, params = _trainer(size, B)
+    omc = O.squeezeDet_config_for_input(*size)
+    omc.IS_TRAINING = True
+    x = O.synthetic_images(B, size[0], size[1], seed=61)
+    mask, delta, box, labels = TO.synthetic_labels(omc, B, seed=62)
+    gh, gw = O.squeezedet_grid(*size)
+    dm = torch.from_numpy((np.random.RandomState(63).uniform(size=(B, gh, gw, 768)) < 0.5).astype(np.float32))
+    ref = TO.loss_and_grads("squeezeDet", omc, params, x, dm, mask, delta, box, labels)
+    out = tr.step(x, mask, delta, box, labels, dropout_mask=dm, apply_update=False, keep_activations=True)
+    torch.cuda.synchronize()
+    for k in ("class_loss", "conf_loss", "bbox_loss"):
+        np.testing.assert_allclose(float(out[k]), ref[k], rtol=5e-4)
+    _close(out["preds"], ref["preds"], rel=1e-3, what="preds (full-size training forward)")
+    _close(out["dpreds"], ref["dpreds"], rel=1e-3, what="dpreds")
+    acts = {k: v.float().cpu() for k, v in out["activations"].items()}
+    ref = TO.loss_and_grads("squeezeDet", omc, params, x, dm, mask, delta, box, labels, override=acts)
+    assert set(ref["grads"]) == set(tr.gview)
+    for name, gref in ref["grads"].items():
+        wdg = omc.WEIGHT_DECAY * params[name] if name.endswith("/kernels") else 0.0
+        got = tr.gview[name].cpu() + wdg
+        scale = float(gref.abs().max())
+        err = float((got - gref).abs().max())
+        assert err <= 1e-3 * scale + 1e-7, "%s: grad err %g vs scale %g" % (name, err, scale)   # north_star 1e-3 rel
 
 
 @pytest.mark.parametrize("name", __import__("tests.golden.cases", fromlist=["x"]).LABEL_CASES)

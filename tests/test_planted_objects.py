@@ -30,3 +30,25 @@ def test_planted_objects_fire_exactly_their_anchors(size, storage):
         cls = out["det_class"][b][got]
         assert all(int(c) == (a % 9) % 3 for a, c in zip(got, cls))
         assert 8 <= len(dets[b][3]) <= 64
+
+
+@pytest.mark.parametrize("storage", ["fp32", "fp16"])
+def test_planted_objects_squeezedet_plus_geometry(storage):
+    """The same generator on SqueezeDet+'s geometry (nets/squeezeDetPlus.py:40-61: 7x7/s2 VALID conv1, VALID pools, 22x76 grid,
+    15048 anchors): 7x7 objects, detector threshold 6.0 -- exactly the planted (cell, shape) triples fire."""
+    omc = O.kitti_squeezeDetPlus_config()
+    gh, gw = SY._grid(omc, "squeezeDet+")
+    assert (gh, gw) == (22, 76) and omc.ANCHORS == gh * gw * 9
+    params = SY.planted_params(O.init_params("squeezeDet+", seed=40, storage=storage), omc.ANCHOR_PER_GRID, omc.CLASSES, arch="squeezeDet+")
+    x, planted = SY.planted_images(omc, 2, seed=41, arch="squeezeDet+")
+    assert float(x.abs().max()) <= 144.0 and bool((x == x.round()).all())
+    preds, out, dets = O.detect("squeezeDet+", omc, params, x, storage=storage)
+    for b in range(2):
+        want = sorted((cy * gw + cx) * 9 + k for (bb, cy, cx, c) in planted if bb == b for k in range(c, 9, 3))
+        assert len(want) == 36
+        p = out["det_probs"][b]
+        got = sorted(np.nonzero(p > 0.5)[0].tolist())
+        assert got == want
+        assert len(set(np.round(p[got], 5))) == 9
+        assert float(np.max(np.delete(p, got))) < 0.003
+        assert 8 <= len(dets[b][3]) <= 64

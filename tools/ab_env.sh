@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of the headline step over ENVIRONMENT variants: alternates bench.py runs, N rounds.
-#   gpurun -- 'bash tools/ab_env.sh 2 "" "SQDET_LANE_PHASE=6" "SQDET_LANE_PHASE=6b"'
+#   gpurun -- 'bash tools/ab_env.sh 2 "" "SQDET_SERVE_LANES=1" "SQDET_SERVE_LANES=3"'
 N=${1:-2}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 for i in $(seq 1 $N); do
