@@ -47,10 +47,15 @@ SOURCES = [
     ("filter_fast.hip", ["-ffp-contract=off"]),
     ("train.hip", ["-ffp-contract=off"]),
     ("wgrad.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
-    ("probe.hip", []),
+    # (the calibration loops: hipcc's default AGPR form ROTATES the 16x16x32 loop's accumulators -- a[24:27] = mfma(.., a[22:25]) plus
+    # v_accvgpr copies inside the loop -- so consecutive MFMAs depend on each other and the "bare MFMA loop" of rounds 3-4 read half
+    # of what the box sustains: 1.07-1.29 PF/s where the clean loop reads ~1.7; found in round 5 with the counters)
+    ("probe.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("net.cpp", []),
 ]
-COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+# (-Wno-inline-asm: the LDS-DMA helpers write M0 inside their asm and say so in the clobber list -- round-4 ADVICE; clang then warns
+# once per inlined copy that M0 is a reserved register.  The clobber only makes the compiler re-materialise M0 for its own uses.)
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 

@@ -81,6 +81,17 @@ __device__ __forceinline__ void glds16(unsigned voff, const unsigned char* sbase
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 
+// -DSQDET_CHAIN_TIMELINE (experiments only, tools/chain_timeline.py): eight s_memrealtime (100 MHz) stamps per workgroup of the
+// ring kernel -- entry, loads issued, squeeze tile in LDS, first weight stage landed, end of the expand1x1 blocks, end of the
+// expand3x3 blocks, ring drained, last store issued -- kept in scalar registers and written once at the very end (a store in
+// the loop would join the hand-counted vmcnt queue).
+#ifdef SQDET_CHAIN_TIMELINE
+__device__ unsigned long long g_chain_tl[4096 * 8];
+#define CTL(k) do { ctl[k] = wall_clock64(); } while (0)
+#else
+#define CTL(k) do {} while (0)
+#endif
+
 template <int N>
 __device__ __forceinline__ void vm_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -117,6 +128,10 @@ __global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int pg = wave & 3, h = wave >> 2;
   const int j = lane & 15, g = lane >> 4;
+#ifdef SQDET_CHAIN_TIMELINE
+  unsigned long long ctl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  CTL(0);
 
   if ((int)(blockIdx.x >> 3) >= a.per_xcd) {
     // ---- RIDER: this workgroup sits on a CU the launch would leave idle (240 chain workgroups on 256 CUs at batch 32) and
@@ -185,6 +200,7 @@ __global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
   };
 #pragma unroll
   for (int s = 0; s < LOOK; ++s) refill();
+  CTL(1);
 
   // ---------------------------------------------------------------- squeeze tile + biases -> LDS
   {
@@ -202,6 +218,7 @@ __global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
       bl[i] = i < a.E1 ? a.b1[i] : (i < a.E1 + a.E3 ? a.b3[i - a.E1] : a.bs2[i - a.E1 - a.E3]);
   }
   __syncthreads();
+  CTL(2);
 
   const int img = pg >> 1, r0 = (pg & 1) * 4;
   const unsigned char* simg = stile + img * NCH * CCHUNK;
@@ -249,6 +266,7 @@ __global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
 
   i32x4 an[2];      // this wave's two fragments (tiles 2h, 2h+1) of slot 0 of the stage about to be consumed
   sync(false);      // stage 0
+  CTL(3);
   refill();
 #pragma unroll
   for (int n = 0; n < 2; ++n) an[n] = lda(0, 2 * h + n);
@@ -357,6 +375,7 @@ __global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
     }
   }
 
+  CTL(4);
   // ---------------------------------------------------------------- expand3x3 blocks
   // The 18 B fragments of a K chunk (6 halo rows x 3 column shifts) serve its nine taps.  They are fetched while
   // the MFMAs run: rows 0,1 of the NEXT chunk during this chunk's last tap row (which reads rows 2..5), rows 2..4
@@ -433,7 +452,9 @@ __global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
       finish_block(acc, a.E1 + blk * 64);
     }
   }
+  CTL(5);
   vm_wait<0>();   // the dummy stages have landed (nobody reads them) before this workgroup's LDS is handed on
+  CTL(6);
 
   // ---------------------------------------------------------------- next squeeze: bias + ReLU -> sq_out
   if constexpr (NSQ > 0) {
@@ -455,6 +476,13 @@ __global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
       }
     }
   }
+#ifdef SQDET_CHAIN_TIMELINE
+  CTL(7);
+  if (threadIdx.x == 0 && blockIdx.x < 4096) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g_chain_tl[(size_t)blockIdx.x * 8 + k] = ctl[k];
+  }
+#endif
 }
 
 // ---- weight stream: float32 HWIO kernels -> the ring stages in consumption order ----
@@ -937,3 +965,9 @@ int sqdet::fire_chain_launch_ride(const void* sq_in, const void* stream_buf, con
   if (g.nch == 2) return y ? dispatch_chain_nsq<2, true>(a, g.nsq, st) : dispatch_chain_nsq<2, false>(a, g.nsq, st);
   return y ? dispatch_chain_nsq<3, true>(a, g.nsq, st) : dispatch_chain_nsq<3, false>(a, g.nsq, st);
 }
+
+#ifdef SQDET_CHAIN_TIMELINE
+extern "C" int sqdet_debug_chain_timeline(unsigned long long* host, int count) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sqdet::g_chain_tl), sizeof(unsigned long long) * count);
+}
+#endif

@@ -183,7 +183,10 @@ int conv1x1_deepk_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStr
   if (c.k != 1 || c.stride != 1 || c.pt != 0 || c.pl != 0 || g.gather || c.accum || c.relu_of) return SQDET_OK;
   const int esz = dtype == SQDET_F16 ? 2 : 4;
   if (c.x_coffset != 0 || c.x_cstride != c.Cin || (c.Cin * esz) % 16 != 0) return SQDET_OK;
-  if (g.nchunk < 5 || g.nchunk > 48 || (size_t)g.nchunk * g.nt * 1024 > 152 * 1024 || c.P < 8192) return SQDET_OK;
+  // ("dbg" 53 / 54: in-step A/B of the pixel threshold -- 20000 / 65536 instead of 8192; stand-alone the tile kernel wins on most maps
+  //  below 60 k pixels, profiles/r04_conv1x1_shapes_ab.txt, inside the steps this kernel does: profiles/r05_conv1x1_threshold_ab.txt)
+  const int min_pixels = tune(TUNE_DBG) == 53 ? 20000 : (tune(TUNE_DBG) == 54 ? 65536 : 8192);
+  if (g.nchunk < 5 || g.nchunk > 48 || (size_t)g.nchunk * g.nt * 1024 > 152 * 1024 || c.P < min_pixels) return SQDET_OK;
   K1Args a;
   a.c = c;
   a.nblocks = (c.P + 15) / 16;

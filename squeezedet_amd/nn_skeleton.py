@@ -486,7 +486,7 @@ class ModelSkeleton:
                 return out
             # A lane starts behind the caller's stream (the input may have been produced there).
             if not self._lanes_checked:
-                self.warm_up_lanes(images)
+                self.warm_up_lanes(images, lanes=len(lane_set))
             lane = lane_set[self._lane_next % len(lane_set)]
             self._lane_next = (self._lane_next + 1) % len(lane_set)
             cur = torch.cuda.current_stream()

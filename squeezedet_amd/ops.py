@@ -899,10 +899,15 @@ def calib_mfma_variant(device, shape, waves_per_simd, zero_operands, iters=None,
             t = ticks[:2 * wgs.value].cpu().numpy().reshape(-1, 2).astype(np.float64)
             best = (ms, float(np.median(t[:, 0])), float(np.median(t[:, 1])))
     ms, cyc, wall = best
-    per_simd = cyc / (iters * nacc) / waves_per_simd
+    clock_mhz = 100.0 * cyc / max(wall, 1.0)
+    # the SIMD's issue interval: kernel duration x effective clock / MFMAs per SIMD (workgroups are not necessarily spread evenly over
+    # the CUs, so a single wave's cycle count is not the kernel's; the launch-level figure is what rocprofv3's
+    # SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE gives too: profiles/r05_box_calibration.txt)
+    simds = (wgs.value // waves_per_simd) * 4
+    per_simd = (ms * 1e-3 * clock_mhz * 1e6) / (wgs.value * 4.0 * iters * nacc / simds)
     return {"shape": "16x16x32" if shape == 0 else "32x32x16", "waves_per_simd": waves_per_simd, "zero_operands": bool(zero_operands),
             "tflops": round(flops.value / (ms * 1e-3) / 1e12, 1), "ms": round(ms, 4), "workgroups": wgs.value,
-            "effective_clock_mhz": round(100.0 * cyc / max(wall, 1.0), 1), "cycles_per_mfma_per_simd": round(per_simd, 2),
+            "effective_clock_mhz": round(clock_mhz, 1), "cycles_per_mfma_per_simd": round(per_simd, 2),
             "mfma_busy_frac": round(MFMA_PIPE_CYCLES[shape] / per_simd, 4)}
 
 

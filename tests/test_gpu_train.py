@@ -196,7 +196,7 @@ def test_maxpool_window_index_forward_and_backward(dtype):
     # NaN cells (round-4 ADVICE): a NaN never wins the comparison wherever it sits in the window -- first valid cell or not -- so the
     # training forward's pooled tensor stays BITWISE the inference pool's, the index names the first maximum among the other cells
     # (the first valid cell when there is none), and both backward kernels route the gradient alike
-    xn = torch.from_numpy(np.round(rs.randn(2, 13, 17, ev) * 2).astype(np.float32) / 2).to(DEV, dtype)
+    xn = torch.from_numpy(np.round(rs.randn(2, 13, 17, ev) * 2).astype(np.float32) / 2 + 0.0).to(DEV, dtype)   # (+ 0.0: no negative zeros -- the comparison below is on BITS)
     xn[0, 0, 0, :] = float("nan")            # the FIRST valid cell of window (0, 0)
     xn[0, 5, 6, :] = float("nan")            # an inner cell of several windows
     xn[1, 3:6, 3:6, :] = float("nan")        # a whole window of NaN (output cell (2, 2): -inf, the first cell named)
