@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libsqdet_hip.so")
+# (SQDET_LIB: another build of the same library -- same-box A/B of a compile-time variant, tools/ab_lib.sh)
+LIB_PATH = os.environ.get("SQDET_LIB") or os.path.join(_PKG, "libsqdet_hip.so")
 
 SQDET_OK = 0
 SQDET_EUNSUPPORTED = -2

@@ -10,6 +10,8 @@
 //   * the epilogue stores 4*NT consecutive channels per lane as 16-byte vectors.
 // Waves of different cout groups read the same pixels; K << Cout for the expand layers, so that
 // re-read (served by L2) is small next to the output stream.
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace sqdet {
@@ -18,6 +20,7 @@ struct C1Args {
   ConvArgs c;
   int ntiles;      // pixel tiles of MT*16
   int nstreams;    // waves per cout group
+  unsigned x_bytes, y_bytes;   // extents of the two tensors (buffer resources: offsets beyond them read zeros / store nothing)
 };
 
 // PERM (every cout group full: Cout % (16*NT) == 0): the wave gathers its A-fragment rows from the standard packing in ANOTHER
@@ -74,89 +77,142 @@ __global__ __launch_bounds__(256) void conv1x1_stream(C1Args a) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) nt_valid += cb + t * 4 < a.c.Cout ? 1 : 0;
 
-  const T* x = reinterpret_cast<const T*>(a.c.x);
-  T* y = reinterpret_cast<T*>(a.c.y);
-  const i32x4 zero = {0, 0, 0, 0};
-  bool k_ok[NCH];
+  // Everything inside the tile loop is branch-free: loads and stores are raw buffer operations whose offset is out of range (zeros /
+  // dropped) for pixels past the end, for K groups past Cin and for the prefetch past the last tile.  With `if (p < P)` blocks around
+  // them the loop was 39 basic blocks and hipcc's wait-count pass gave up at the joins: `s_waitcnt vmcnt(0)` at the top of every
+  // step, i.e. every wave waited for its own STORES to be acknowledged before asking for the next pixels, and a launch took
+  // stream time + compute time (fire2/expand1x1: 38-42 us where the same loads and stores without the arithmetic take 25,
+  // tools/microbench/store_shape.hip).  One block: the pass counts (`vmcnt(stores + loads issued behind the fragment)`).
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.c.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.c.y, 0, a.y_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xfffffff0u;
+  constexpr unsigned ES = sizeof(T);
+  const unsigned xrow = (unsigned)a.c.Cin * ES, yrow = (unsigned)a.c.y_cstride * ES;
+  unsigned kb[NCH];        // byte offset of this lane's K group inside a pixel row; OOB: the group lies past Cin (zeros)
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) k_ok[c] = c * KC + g * KG < a.c.Cin;
+  for (int c = 0; c < NCH; ++c) kb[c] = c * KC + g * KG < a.c.Cin ? (unsigned)(c * KC + g * KG) * ES : OOB;
+  const unsigned yb = (unsigned)(a.c.y_coffset + cb) * ES;
 
   auto load_tile = [&](int tile, i32x4 (&bf)[MT][NCH]) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int p = (tile * MT + m) * 16 + j;
-      const bool ok = p < a.c.P;
-      const T* src = x + (size_t)(ok ? p : 0) * a.c.Cin + g * KG;
+      const unsigned pb = (unsigned)p * xrow;
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) bf[m][c] = (ok && k_ok[c]) ? *reinterpret_cast<const i32x4*>(src + c * KC) : zero;
+      for (int c = 0; c < NCH; ++c)
+        bf[m][c] = __builtin_amdgcn_raw_buffer_load_b128(rx, (p < a.c.P && kb[c] != OOB) ? pb + kb[c] : OOB, 0, 0);
     }
   };
 
-  i32x4 bcur[MT][NCH], bnext[MT][NCH];
-  int tile = stream;
-  if (tile < a.ntiles) load_tile(tile, bcur);
-  for (; tile < a.ntiles; tile += a.nstreams) {
-    const int nxt = tile + a.nstreams;
-    if (nxt < a.ntiles) load_tile(nxt, bnext);
+  auto run = [&](auto relu_t) {
+    constexpr bool RELU = decltype(relu_t)::value;
+    // one step: the NEXT tile's fragments are requested into `nxt`, then the tile in `cur` is computed and stored.  The loop runs two
+    // steps per trip over two register sets (no copies: a copy placed behind the last MFMA of a fragment waits for the load that was
+    // only just issued -- the prefetch would be a load that is waited for at once).
+    auto step = [&](int tile, i32x4 (&cur)[MT][NCH], i32x4 (&nxt)[MT][NCH]) {
+      load_tile(tile + a.nstreams, nxt);             // (past the last tile: every offset out of range, nothing is fetched)
+      // (the fence keeps the scheduler from sinking these loads below the epilogue, into the registers the accumulators free)
+      __builtin_amdgcn_sched_barrier(0);
 
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
+      f32x4 acc[MT][NT];
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) mma16<T>(acc[m][t], af[c][t], bcur[m][c]);
+        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) mma16<T>(acc[m][t], af[c][t], cur[m][c]);
 
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int p = (tile * MT + m) * 16 + j;
-      if (p < a.c.P) {
+      for (int m = 0; m < MT; ++m) {
+        const int p = (tile * MT + m) * 16 + j;
+        const unsigned po = p < a.c.P ? (unsigned)p * yrow + yb : OOB;
         f32x4 v[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           v[t] = acc[m][t] + bias[t];
-          if (a.c.relu) {
+          if constexpr (RELU) {
             v[t][0] = fmaxf(v[t][0], 0.f); v[t][1] = fmaxf(v[t][1], 0.f);
             v[t][2] = fmaxf(v[t][2], 0.f); v[t][3] = fmaxf(v[t][3], 0.f);
           }
         }
-        T* dst = y + (size_t)p * a.c.y_cstride + a.c.y_coffset + cb;
-        if constexpr (PERM) {
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            if (sizeof(T) == 2 && (t | 1) < NT) {
-              if ((t & 1) == 0) {
-                const f16x8 h = {(f16)v[t][0], (f16)v[t][1], (f16)v[t][2], (f16)v[t][3],
-                                 (f16)v[t + 1 < NT ? t + 1 : t][0], (f16)v[t + 1 < NT ? t + 1 : t][1], (f16)v[t + 1 < NT ? t + 1 : t][2], (f16)v[t + 1 < NT ? t + 1 : t][3]};
-                *reinterpret_cast<f16x8*>(dst + coff(t)) = h;
-              }
+        for (int t = 0; t < NT; ++t) {
+          const bool pair = PERM && sizeof(T) == 2 && (t | 1) < NT;
+          if (pair && (t & 1)) continue;               // (stored with its even partner)
+          // non-PERM: whole 4-cout pieces beyond Cout do not exist
+          const unsigned off = (po != OOB && (PERM || t < nt_valid)) ? po + (unsigned)coff(t) * ES : OOB;
+          if constexpr (sizeof(T) == 2) {
+            if (pair) {
+              const int t1 = t + 1 < NT ? t + 1 : t;
+              const f16x8 h = {(f16)v[t][0], (f16)v[t][1], (f16)v[t][2], (f16)v[t][3],
+                               (f16)v[t1][0], (f16)v[t1][1], (f16)v[t1][2], (f16)v[t1][3]};
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, h), ry, off, 0, 0);
             } else {
-              store4<T>(dst + coff(t), v[t]);
+              const f16x4 h = {(f16)v[t][0], (f16)v[t][1], (f16)v[t][2], (f16)v[t][3]};
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, h), ry, off, 0, 0);
             }
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v[t]), ry, off, 0, 0);
           }
-        } else {
-          store_couts<T, NT>(dst, v, nt_valid);
         }
       }
-    }
-    if (nxt < a.ntiles) {
+    };
+    i32x4 b0[MT][NCH], b1[MT][NCH];
+    int tile = stream;
+    load_tile(tile, b0);
+    // One step's worth of stores that go nowhere (every offset out of range), so that the memory queue looks the same on both ways
+    // into the loop -- [fragments][stores] -- : hipcc's wait counts at a loop header are the minimum over the incoming paths, and
+    // coming from here with the fragments alone it made every first step wait until all but two of the PREVIOUS step's stores were
+    // acknowledged (vmcnt(6) where the back edge needs vmcnt(15)).
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) bcur[m][c] = bnext[m][c];
+      for (int t = 0; t < NT; ++t) {
+        const bool pair = PERM && sizeof(T) == 2 && (t | 1) < NT;
+        if (pair && (t & 1)) continue;
+        if (sizeof(T) == 2 && !pair) __builtin_amdgcn_raw_buffer_store_b64(i32x2{0, 0}, ry, OOB, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(i32x4{0, 0, 0, 0}, ry, OOB, 0, 0);
+      }
+    // (a trip's second step past the last tile computes on zeros and stores nothing)
+    for (; tile < a.ntiles; tile += 2 * a.nstreams) {
+      step(tile, b0, b1);
+      step(tile + a.nstreams, b1, b0);
     }
+  };
+  if (a.c.relu) run(std::true_type{});
+  else run(std::false_type{});
+}
+
+// resident 256-thread workgroups per CU of one instantiation (registers decide), asked once per device
+template <typename T, int NCH, int NT, int MT, bool PERM>
+static int c1_blocks_per_cu() {
+  static int cached[64] = {};
+  const int d = current_device() & 63;
+  if (cached[d] == 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&conv1x1_stream<T, NCH, NT, MT, PERM>), 256, 0) != hipSuccess || n < 1) {
+      (void)hipGetLastError();
+      n = 4;
+    }
+    cached[d] = n > 8 ? 8 : n;
   }
+  return cached[d];
 }
 
 template <typename T, int NCH, int NT, int MT>
 static void launch_c1(C1Args& a, hipStream_t st) {
   a.ntiles = (a.c.P + 16 * MT - 1) / (16 * MT);
-  // persistent: ~8 waves per SIMD-slot budget -> 256 CUs x 16 waves, split over the cout groups
-  const int budget = tune(TUNE_C1_WAVES) > 0 ? tune(TUNE_C1_WAVES) : cu_count() * 16;
+  // PERM: whole cout groups and 16-byte aligned rows (float16 pairs store 16 bytes at 16-byte channel offsets)
+  const bool perm = a.c.Cout % (16 * NT) == 0 && a.c.y_cstride % 8 == 0 && a.c.y_coffset % 8 == 0 &&
+                    (reinterpret_cast<uintptr_t>(a.c.y) & 15) == 0 && tune(TUNE_DBG) != 50;
+  // persistent: exactly the waves that are RESIDENT together (a wave that starts when another one ends repeats the ramp: with the
+  // fixed 16 waves per CU of rounds 1-4 a 159-register instantiation ran 1.33 rounds), split over the cout groups
+  const int per_cu = perm ? c1_blocks_per_cu<T, NCH, NT, MT, true>() : c1_blocks_per_cu<T, NCH, NT, MT, false>();
+  const int budget = tune(TUNE_C1_WAVES) > 0 ? tune(TUNE_C1_WAVES) : cu_count() * per_cu * 4;
   int streams = budget / a.c.ngroups;
   if (streams < 1) streams = 1;
   // a wave re-loads its weight fragments once: give it at least `min_tiles` pixel tiles to amortise them
@@ -166,9 +222,6 @@ static void launch_c1(C1Args& a, hipStream_t st) {
   if (streams < 1) streams = 1;
   a.nstreams = streams;
   const int waves = streams * a.c.ngroups;
-  // PERM: whole cout groups and 16-byte aligned rows (float16 pairs store 16 bytes at 16-byte channel offsets)
-  const bool perm = a.c.Cout % (16 * NT) == 0 && a.c.y_cstride % 8 == 0 && a.c.y_coffset % 8 == 0 &&
-                    (reinterpret_cast<uintptr_t>(a.c.y) & 15) == 0 && tune(TUNE_DBG) != 50;
   if (perm) hipLaunchKernelGGL((conv1x1_stream<T, NCH, NT, MT, true>), dim3((waves + 3) / 4), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv1x1_stream<T, NCH, NT, MT, false>), dim3((waves + 3) / 4), dim3(256), 0, st, a);
 }
@@ -209,8 +262,12 @@ int conv1x1_stream_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipSt
   if (conv_algo() != 0) return SQDET_OK;
   if (c.k != 1 || c.stride != 1 || g.gather) return SQDET_OK;
   if (g.nchunk > 4 || g.nchunk * g.nt > 18) return SQDET_OK;   // weights must fit in registers
+  const size_t es = dtype == SQDET_F16 ? 2 : 4;
+  const size_t xb = (size_t)c.P * c.Cin * es, yb = (size_t)c.P * c.y_cstride * es;
+  if (xb >= (1ull << 31) || yb >= (1ull << 31)) return SQDET_OK;   // 32-bit buffer offsets (the generic kernel takes over)
   C1Args a;
   a.c = c;
+  a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb;
   // register budget: accumulators MT*NT*4 + double-buffered B 2*MT*NCH*4 + A NCH*NT*4
   int mt = 4;
   if (4 * g.nt * 4 + 2 * 4 * g.nchunk * 4 + g.nchunk * g.nt * 4 > 200) mt = 2;

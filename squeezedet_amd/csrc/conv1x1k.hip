@@ -22,6 +22,7 @@ struct K1Args {
   int nblocks;     // 16-pixel blocks
   int nchunk;      // 64-byte K chunks
   int wgs_per_group;
+  unsigned x_bytes, y_bytes;   // extents of the two tensors (buffer resources: offsets beyond them read zeros / store nothing)
 };
 
 constexpr int KB = 8;    // chunks per load group
@@ -36,22 +37,28 @@ __global__ __launch_bounds__(NWAVES * 64) void conv1x1_deepk(K1Args a) {
   const int j = lane & 15, g = lane >> 4;
   const int group = blockIdx.x / a.wgs_per_group, wg = blockIdx.x - group * a.wgs_per_group;
   const int nchunk = a.nchunk;
-  const T* x = reinterpret_cast<const T*>(a.c.x);
-  T* y = reinterpret_cast<T*>(a.c.y);
-  const i32x4 zero = {0, 0, 0, 0};
   const int stride = a.wgs_per_group * NWAVES;
+  // Loads and stores are raw buffer operations with an out-of-range offset where the old code had a branch (pixels past the end, K
+  // chunks past the last one, the channel padding of the last chunk, groups past the wave's last block): the tile loop is straight-line
+  // code around ONE wave-uniform branch (the epilogue) and hipcc's wait-count pass counts -- `vmcnt(8 + stores)` in front of a group's
+  // MFMAs.  With exec-masked loads in blocks of their own it put `s_waitcnt vmcnt(0)` in front of every MFMA group: the "two groups in
+  // flight" were one, and a wave waited for its own stores (rounds 4: 0.36-0.60 of 8 TB/s stand-alone).
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.c.x), 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.c.y, 0, a.y_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xfffffff0u;
+  constexpr unsigned ES = sizeof(T);
+  const unsigned xrow = (unsigned)a.c.Cin * ES, yrow = (unsigned)a.c.y_cstride * ES;
 
   // a load group = KB consecutive K chunks of one 16-pixel block; groups are walked block-major, the NEXT group's loads are issued
   // before the current group's MFMAs (two register sets)
   auto issue = [&](int blk, int c0, i32x4 (&bf)[KB]) {
     const int p = blk * 16 + j;
-    const bool ok = p < a.c.P;
-    const T* src = x + (size_t)(ok ? p : 0) * a.c.Cin + g * KG;
+    const unsigned pb = p < a.c.P ? (unsigned)p * xrow + (unsigned)(g * KG) * ES : OOB;
 #pragma unroll
     for (int u = 0; u < KB; ++u) {
       const int c = c0 + u;
       // (chunks past the last one and the channel padding of the last chunk read as zeros; the packed weights are zero there too)
-      bf[u] = (ok && c < nchunk && c * KC + g * KG < a.c.Cin) ? *reinterpret_cast<const i32x4*>(src + c * KC) : zero;
+      bf[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, (pb != OOB && c * KC + g * KG < a.c.Cin) ? pb + (unsigned)(c * KC) * ES : OOB, 0, 0);
     }
   };
   // two pointers walk the same sequence of groups: (ib, ic) = the next group to REQUEST, (cb_, cc_) = the next group to COMPUTE; two
@@ -64,8 +71,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv1x1_deepk(K1Args a) {
     ic = last ? 0 : ic + KB;
   };
   i32x4 bfa[KB], bfb[KB];
-  if (ib < a.nblocks) { issue(ib, ic, bfa); advance_issue(); }
-  if (ib < a.nblocks) { issue(ib, ic, bfb); advance_issue(); }
+  issue(ib, ic, bfa); advance_issue();
+  issue(ib, ic, bfb); advance_issue();
 
   // ---- the group's weights -> LDS (once) ----
   {
@@ -81,6 +88,9 @@ __global__ __launch_bounds__(NWAVES * 64) void conv1x1_deepk(K1Args a) {
     bias[t] = ok ? *reinterpret_cast<const f32x4*>(a.c.bias + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     nt_valid += ok ? 1 : 0;
   }
+  // 16-byte stores of float16 tile pairs need whole cout groups and 16-byte aligned row segments (wave-uniform: the group's first cout)
+  const bool wide = sizeof(T) == 2 && (NT & 1) == 0 && (group + 1) * 16 * NT <= a.c.Cout &&
+                    ((reinterpret_cast<uintptr_t>(a.c.y) + ((size_t)a.c.y_coffset + (size_t)group * 16 * NT) * ES) & 15) == 0 && (yrow & 15) == 0;
   __syncthreads();
 
   const unsigned char* wl = lds + lane * 16;
@@ -91,26 +101,43 @@ __global__ __launch_bounds__(NWAVES * 64) void conv1x1_deepk(K1Args a) {
     const bool last = cc_ + KB >= nchunk;
 #pragma unroll
     for (int u = 0; u < KB; ++u) {
-      if (cc_ + u < nchunk) {                           // wave-uniform
+      // a group's chunks past the last one multiply ZERO fragments (out-of-range loads) with the last chunk's weights: + 0, no branch
+      const int cw = cc_ + u < nchunk ? cc_ + u : nchunk - 1;         // wave-uniform
 #pragma unroll
-        for (int t = 0; t < NT; ++t) mma16<T>(acc[t], *reinterpret_cast<const i32x4*>(wl + ((cc_ + u) * NT + t) * 1024), cur[u]);
-      }
+      for (int t = 0; t < NT; ++t) mma16<T>(acc[t], *reinterpret_cast<const i32x4*>(wl + (cw * NT + t) * 1024), cur[u]);
     }
-    // the registers just consumed take the group two ahead
-    if (ib < a.nblocks) { issue(ib, ic, cur); advance_issue(); }
+    // the registers just consumed take the group two ahead (past the wave's last block: out of range, nothing is fetched)
+    issue(ib, ic, cur); advance_issue();
     if (last) {
       const int p = cb_ * 16 + j;
-      if (p < a.c.P) {
-        f32x4 v[NT];
+      const unsigned po = p < a.c.P ? (unsigned)p * yrow + (unsigned)(a.c.y_coffset + cb) * ES : OOB;
+      f32x4 v[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        v[t] = acc[t] + bias[t];
+        if (a.c.relu) {
+          v[t][0] = fmaxf(v[t][0], 0.f); v[t][1] = fmaxf(v[t][1], 0.f);
+          v[t][2] = fmaxf(v[t][2], 0.f); v[t][3] = fmaxf(v[t][3], 0.f);
+        }
+      }
+      if (wide) {
+#pragma unroll
+        for (int t = 0; t + 1 < NT; t += 2) {
+          const f16x8 h = {(f16)v[t][0], (f16)v[t][1], (f16)v[t][2], (f16)v[t][3],
+                           (f16)v[t + 1][0], (f16)v[t + 1][1], (f16)v[t + 1][2], (f16)v[t + 1][3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, h), ry, po != OOB ? po + (unsigned)(t * 4) * ES : OOB, 0, 0);
+        }
+      } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          v[t] = acc[t] + bias[t];
-          if (a.c.relu) {
-            v[t][0] = fmaxf(v[t][0], 0.f); v[t][1] = fmaxf(v[t][1], 0.f);
-            v[t][2] = fmaxf(v[t][2], 0.f); v[t][3] = fmaxf(v[t][3], 0.f);
+          const unsigned off = (po != OOB && t < nt_valid) ? po + (unsigned)(t * 4) * ES : OOB;
+          if constexpr (sizeof(T) == 2) {
+            const f16x4 h = {(f16)v[t][0], (f16)v[t][1], (f16)v[t][2], (f16)v[t][3]};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, h), ry, off, 0, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v[t]), ry, off, 0, 0);
           }
         }
-        store_couts<T, NT>(y + (size_t)p * a.c.y_cstride + a.c.y_coffset + cb, v, nt_valid);
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -118,9 +145,9 @@ __global__ __launch_bounds__(NWAVES * 64) void conv1x1_deepk(K1Args a) {
     cb_ = last ? cb_ + stride : cb_;
     cc_ = last ? 0 : cc_ + KB;
   };
+  // (a trip's second step past the wave's last block computes on zeros and stores nothing)
   while (cb_ < a.nblocks) {
     step(bfa);
-    if (cb_ >= a.nblocks) break;
     step(bfb);
   }
 }
@@ -187,8 +214,11 @@ int conv1x1_deepk_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStr
   //  below 60 k pixels, profiles/r04_conv1x1_shapes_ab.txt, inside the steps this kernel does: profiles/r05_conv1x1_threshold_ab.txt)
   const int min_pixels = tune(TUNE_DBG) == 53 ? 20000 : (tune(TUNE_DBG) == 54 ? 65536 : 8192);
   if (g.nchunk < 5 || g.nchunk > 48 || (size_t)g.nchunk * g.nt * 1024 > 152 * 1024 || c.P < min_pixels) return SQDET_OK;
+  const size_t xb = (size_t)c.P * c.Cin * esz, yb = (size_t)c.P * c.y_cstride * esz;
+  if (xb >= (1ull << 31) || yb >= (1ull << 31)) return SQDET_OK;   // 32-bit buffer offsets
   K1Args a;
   a.c = c;
+  a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb;
   a.nblocks = (c.P + 15) / 16;
   a.nchunk = g.nchunk;
   const bool ok = dtype == SQDET_F16 ? dispatch_k1<f16>(a, g.nt, g.ngroups, st) : dispatch_k1<float>(a, g.nt, g.ngroups, st);

@@ -23,11 +23,14 @@ __global__ __launch_bounds__(256) void rw(const i32x4* __restrict__ src, i32x4* 
     i32x4 v[R > 0 ? R : 1];
 #pragma unroll
     for (int r = 0; r < R; ++r) v[r] = src[(size_t)r * units + u];       // R planes of `units` vectors: each plane linear
+    i32x4 sum = {(int)u, 2, 3, 4};
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc += v[r];
+    for (int r = 0; r < R; ++r) sum += v[r];           // (every read feeds every write: none of them is dead)
+    acc += sum;
 #pragma unroll
     for (int w = 0; w < W; ++w) {
-      i32x4 o = R > 0 ? v[w % (R > 0 ? R : 1)] : i32x4{(int)u, w, 3, 4};
+      i32x4 o = sum;
+      o[1] += w;
       dst[(size_t)w * units + u] = o;
     }
   }
