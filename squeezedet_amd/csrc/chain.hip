@@ -70,7 +70,6 @@ struct ChainArgs {
   // RIDERS (chain.h): workgroups behind the `per_xcd` chain slots of every XCD that run filter_prediction's top-N branch
   // for images of the PREVIOUS batch instead of a tile
   int per_xcd;             // chain workgroups per XCD (grid = 8 * (per_xcd + riders per XCD))
-  int warm;                // 1: every workgroup touches a slice of the weight stream at entry (L2 warm-up, below)
   ChainRide ride;
 };
 
@@ -92,11 +91,6 @@ __device__ unsigned long long g_chain_tl[4096 * 8];
 #else
 #define CTL(k) do {} while (0)
 #endif
-
-// One dword per lane into LDS (the same addressing): used only to pull 64 cache lines through the XCD's L2 (see `warm`).
-__device__ __forceinline__ void glds4(unsigned voff, const unsigned char* sbase, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
-}
 
 template <int N>
 __device__ __forceinline__ void vm_wait() {
@@ -186,19 +180,6 @@ __global__ __launch_bounds__(512, 2) void fire_chain(ChainArgs a) {
       const unsigned off = ok ? (unsigned)((((n * a.H + iy) * a.W + ix) * a.S) * 2 + q * 16) : OOB;
       sv[it] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);   // out of range = the zero padding
     }
-  }
-
-  // ---------------------------------------------------------------- L2 warm-up of the weight stream
-  // Inside a forward the stream is cold: the XCD's 30 workgroups walk it in step, so every stage is ONE miss that all of them wait
-  // for, LOOK stages (1-2 us of MFMAs) ahead of its use -- about the latency of the miss.  At entry workgroup k of the XCD touches
-  // lines [512 k, 512 k + 512) of the stream (one dword per lane, 128 bytes apart): the whole stream is on its way into this L2
-  // within the first microsecond and the ring's own fetches hit.  The dwords land in the ring's LAST buffer, which takes its first
-  // stage two syncs from here; they are older than every ring fetch, so the first counted wait covers them.
-  if (a.warm) {
-    const unsigned stream_bytes = (unsigned)a.nstages * STAGE_B;
-    unsigned poff = (unsigned)(blockIdx.x >> 3) * 65536u + (unsigned)threadIdx.x * 128u;
-    if (poff >= stream_bytes) poff = 0;
-    glds4(poff, a.stream, ring_addr + (unsigned)((RING - 1) * STAGE_B + wave * 256));
   }
 
   // ---------------------------------------------------------------- the weight stream
@@ -960,7 +941,6 @@ int sqdet::fire_chain_launch_ride(const void* sq_in, const void* stream_buf, con
   a.out_bytes = (unsigned)(px * next_s1x1 * 2);
   a.y_bytes = (unsigned)(px * (e1x1 + e3x3) * 2);
   a.per_xcd = 0;
-  a.warm = tune(TUNE_DBG) != 90;      // ("dbg" 90: no L2 warm-up -- A/B)
   if (ride) a.ride = *ride; else { a.ride = ChainRide{}; a.ride.nimg = 0; a.ride.nriders = 0; a.ride.img0 = 0; }
   hipStream_t st = as_stream(stream);
   // large maps with a one-chunk squeeze: the persistent, weights-resident form ("dbg" 30 keeps the ring kernel for

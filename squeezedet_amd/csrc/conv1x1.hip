@@ -40,6 +40,15 @@ __global__ __launch_bounds__(256) void conv1x1_stream(C1Args a) {
   const int stream = gw / a.c.ngroups;
   if (stream >= a.nstreams) return;
   const int j = lane & 15, g = lane >> 4;
+  // LIN (float16, NT = 4, PERM: the expand1x1 convs of fire2 .. fire5 -- 64 couts = 128 bytes of a pixel's row per wave): the rounded
+  // tile goes through 2 KiB of LDS of the wave's own and leaves as LINEAR stores -- lane l writes bytes [16 (l & 7), +16) of pixel
+  // l >> 3, a store instruction covers 8 pixels x 128 contiguous bytes (1 KiB in one piece when the conv has 64 couts) -- instead of
+  // the MFMA D layout's 16 pixels x 64 bytes with ADJACENT LANES 128 BYTES APART.  Same bytes; with cold reads beside them the D-layout
+  // stores of this stream run at 3.9 TB/s, the linear ones at 4.8 (tools/microbench/store_shape.hip: 38.4 against 31.4 us for fire2's
+  // 150 MB).  No barrier: the wave reads back what it wrote itself (LDS executes a wave's instructions in order).
+  constexpr bool LIN = PERM && sizeof(T) == 2 && NT == 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lin_lds[LIN ? 4 * 2048 : 16];
+  unsigned char* const lin = lin_lds + (LIN ? (threadIdx.x >> 6) * 2048 : 0);
 
   // this wave's weights: [NCH][NT] fragments, resident in registers
   i32x4 af[NCH][NT];
@@ -92,6 +101,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream(C1Args a) {
 #pragma unroll
   for (int c = 0; c < NCH; ++c) kb[c] = c * KC + g * KG < a.c.Cin ? (unsigned)(c * KC + g * KG) * ES : OOB;
   const unsigned yb = (unsigned)(a.c.y_coffset + cb) * ES;
+  const unsigned ybl = (unsigned)(a.c.y_coffset + group * 16 * NT) * ES;   // (LIN: the group's segment of a row, no lane term)
 
   auto load_tile = [&](int tile, i32x4 (&bf)[MT][NCH]) {
 #pragma unroll
@@ -139,6 +149,25 @@ __global__ __launch_bounds__(256) void conv1x1_stream(C1Args a) {
             v[t][2] = fmaxf(v[t][2], 0.f); v[t][3] = fmaxf(v[t][3], 0.f);
           }
         }
+        if constexpr (LIN) {
+          // pair p = couts [32 p + 8 g, +8) of pixel j = piece 4 p + g of its 128-byte segment; slot = piece ^ (pixel & 7): the eight lanes
+          // a cycle serves write / read eight different 16-byte slots of 128-byte rows -- conflict-free both ways
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const f16x8 h = {(f16)v[2 * pr][0], (f16)v[2 * pr][1], (f16)v[2 * pr][2], (f16)v[2 * pr][3],
+                             (f16)v[2 * pr + 1][0], (f16)v[2 * pr + 1][1], (f16)v[2 * pr + 1][2], (f16)v[2 * pr + 1][3]};
+            *reinterpret_cast<f16x8*>(lin + j * 128 + (((4 * pr + g) ^ (j & 7)) << 4)) = h;
+          }
+          asm volatile("" ::: "memory");               // (the reads below are not hoisted above the writes)
+#pragma unroll
+          for (int sx = 0; sx < 2; ++sx) {
+            const int P = sx * 8 + (lane >> 3), q = lane & 7;
+            const i32x4 o = *reinterpret_cast<const i32x4*>(lin + P * 128 + ((q ^ (P & 7)) << 4));
+            const int pp = (tile * MT + m) * 16 + P;
+            __builtin_amdgcn_raw_buffer_store_b128(o, ry, pp < a.c.P ? (unsigned)pp * yrow + ybl + (unsigned)q * 16u : OOB, 0, 0);
+          }
+          asm volatile("" ::: "memory");               // (nor the next block's writes above these reads)
+        } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const bool pair = PERM && sizeof(T) == 2 && (t | 1) < NT;
@@ -158,6 +187,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream(C1Args a) {
           } else {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v[t]), ry, off, 0, 0);
           }
+        }
         }
       }
     };

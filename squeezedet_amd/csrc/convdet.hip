@@ -381,13 +381,8 @@ __device__ __forceinline__ void cd_dma16(unsigned voff, const i32x4& rsrc, unsig
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_dst) : "memory", "m0");
 }
 
-// One dword per lane into LDS: pulls 64 cache lines through the XCD's L2 (the weight warm-up below).
-__device__ __forceinline__ void cd_warm4(unsigned voff, const void* sbase, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
-}
-
 template <bool SCORE>
-__global__ __launch_bounds__(256) void convdet_dma_kernel(TileArgs a, int ntiles, int per_xcd, int warm) {
+__global__ __launch_bounds__(256) void convdet_dma_kernel(TileArgs a, int ntiles, int per_xcd) {
   using T = f16;
   constexpr int MT = 8, NTW = 5;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -416,20 +411,6 @@ __global__ __launch_bounds__(256) void convdet_dma_kernel(TileArgs a, int ntiles
       for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
   zero_acc();
-
-  // ---- L2 warm-up of the packed weights (1.1 MB, streamed by every workgroup of the XCD in step, two steps ahead of their use: inside
-  // a forward every step of the FIRST tile is a miss all of them wait for).  Workgroup k of the XCD touches lines [512 k, 512 k + 512)
-  // -- one dword per lane, 128 bytes apart, twice -- before anything else: the whole kernel is on its way into this L2 at once and the
-  // weight steps hit.  The dwords land in the (idle) reduction area; they are the oldest entries of the vmcnt queue.
-  if (warm) {
-    const unsigned wbytes = (unsigned)a.nchunk * 9u * NTW * 1024u;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      unsigned poff = (unsigned)(blockIdx.x >> 3) * 65536u + (unsigned)k * 32768u + (unsigned)threadIdx.x * 128u;
-      if (poff >= wbytes) poff = 0;
-      cd_warm4(poff, a.c.wp, lds_addr + (unsigned)(CDD_RED + k * 1024 + wave * 256));
-    }
-  }
 
   // ---- input staging by DMA: this wave's pixel blocks 3w + i (i = 0..2), lane = (pixel 16*(3w+i) + l/4, slot l & 3)
   const unsigned long long xaddr = (unsigned long long)(uintptr_t)a.c.x;
@@ -495,11 +476,7 @@ __global__ __launch_bounds__(256) void convdet_dma_kernel(TileArgs a, int ntiles
     // when the stage loop is entered.  With an asm wait the loop header inherited those from the tile loop's back edge and the pass
     // put `s_waitcnt vmcnt(0)` behind every stage's barrier: each of a tile's six stages began by draining the weight stream (the
     // two steps requested at taps 7 and 8 of the stage before) -- the "stage hand-overs" of the file header.
-#ifdef SQDET_CD_ASMWAIT                                  // (A/B build only: the round-4 form)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
     __builtin_amdgcn_s_waitcnt(0x0f70);                 // vmcnt(0), expcnt / lgkmcnt untouched
-#endif
 #pragma unroll 1
     for (int stage = 0; stage < nstages; ++stage) {
       // everybody's blocks of this stage have landed (see the file header); everybody is done reading the other buffer
@@ -663,8 +640,7 @@ static void convdet_dma_launch(const TileArgs& a, hipStream_t st) {
   const int per_xcd = (ntiles + 7) / 8;
   const int cus8 = cu_count() / 8;                            // persistent: one workgroup per CU
   const int slots = per_xcd < cus8 ? per_xcd : cus8;
-  hipLaunchKernelGGL((convdet_dma_kernel<SCORE>), dim3((unsigned)(slots * 8)), dim3(256), CDD_LDS + (SCORE ? CD_SC_LDS : 0), st, a, ntiles, per_xcd,
-                     tune(TUNE_DBG) != 90 ? 1 : 0);            // ("dbg" 90: no L2 warm-up of the weights -- A/B)
+  hipLaunchKernelGGL((convdet_dma_kernel<SCORE>), dim3((unsigned)(slots * 8)), dim3(256), CDD_LDS + (SCORE ? CD_SC_LDS : 0), st, a, ntiles, per_xcd);
 }
 
 template <typename T, bool PERS, bool SCORE = false>

@@ -227,7 +227,10 @@ __global__ __launch_bounds__((4 * NG / NTW) * RS * 64, WPS) void fire_dma(FireXA
   // next-squeeze items of this wave: item = wave + NWAVES * i -> (16-pixel block, cout tile)
   const int nitems = wave < NIT - (IPW - 1) * NWAVES ? IPW : IPW - 1;   // wave-uniform
 
-  vm_wait_x<0>();                                     // the first tile has landed (and every set-up load)
+  // the first tile has landed (and every set-up load) -- as a wait the COMPILER sees: behind an asm wait hipcc's wait-count pass still
+  // believed the last expand-weight loads pending and put `s_waitcnt vmcnt(1)` / `vmcnt(0)` in front of their first MFMAs INSIDE the
+  // tile loop (the fire5 + pool5 form: every step then waited, in the middle of its MFMAs, for the next tile's DMA to land)
+  __builtin_amdgcn_s_waitcnt(0x0f70);                 // vmcnt(0)
   __syncthreads();
 
   int buf = 0;

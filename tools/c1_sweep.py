@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Stand-alone 1x1 convs of the early fire modules (conv1x1_stream: K <= 4 chunks) under the launcher's knobs -- waves in flight
 (`c1_waves`), pixel blocks per wave step (`c1_mt`) -- at batch 32 / 375x1242 / float16, inputs AND outputs rotating over more than the
-256 MiB Infinity Cache.  HIP events, 20 launches behind 3 warm-up ones.
+256 MiB Infinity Cache.  Launches captured in one hipGraph (no host time between them), best of 3 replays.
     python tools/c1_sweep.py"""
 import os
 import sys
@@ -11,6 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from squeezedet_amd import ops  # noqa: E402
+from tools.arena_ab import graph_time  # noqa: E402
 
 SHAPES = [("fire2/squeeze1x1", 94, 311, 64, 16), ("fire2/expand1x1", 94, 311, 16, 64), ("fire3/squeeze1x1", 94, 311, 128, 16),
           ("fire4/squeeze1x1", 47, 156, 128, 32), ("fire4/expand1x1", 47, 156, 32, 128), ("fire6/expand1x1", 24, 78, 48, 192),
@@ -33,7 +34,6 @@ def main():
         b = torch.zeros(cout, dtype=torch.float32, device=dev)
         pk = ops.pack_conv_weights(wk, torch.float16)
         alg = inb + outb + cin * cout * 2 + 4 * cout
-        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ref = None
         for waves in (0, 2048, 8192, 16384):
             for mt in (0, 2, 4):
@@ -41,16 +41,9 @@ def main():
                     continue
                 ops.set_option("c1_waves", waves)
                 ops.set_option("c1_mt", mt)
-                for i in range(WARM):
-                    ops.conv2d_nhwc(xs[i % nrot], pk, b, 1, "SAME", True, out=ys[i % nrot_y])
-                torch.cuda.synchronize()
-                st.record()
-                for i in range(ITERS):
-                    ops.conv2d_nhwc(xs[(WARM + i) % nrot], pk, b, 1, "SAME", True, out=ys[(WARM + i) % nrot_y])
-                en.record()
-                en.synchronize()
-                us = st.elapsed_time(en) / ITERS * 1e3
-                out = ys[(WARM + ITERS - 1) % nrot_y]
+                n = max(nrot, nrot_y)
+                us = graph_time([(lambda i=i: ops.conv2d_nhwc(xs[i % nrot], pk, b, 1, "SAME", True, out=ys[i % nrot_y])) for i in range(n)] * 2)
+                out = ys[(n - 1) % nrot_y]
                 if ref is None:
                     ref = out.clone()
                 else:

@@ -103,6 +103,12 @@ __global__ __launch_bounds__(256, WPS) void k(Args a) {
   }
 }
 
+// "split": x and y of a launch live in allocations of their OWN (12 inputs, 3 outputs, hipMalloc each -- what a framework's tensors are)
+// instead of 1-GiB regions of one 3-GiB allocation
+static bool g_split = false;
+static char* g_xs[12];
+static char* g_ys[3];
+
 template <int MT, int NSETS, int WPS, bool RELU16>
 void run(char* pool, int P, int Cin, int Cout) {
   const size_t region = 1ull << 30;
@@ -122,8 +128,10 @@ void run(char* pool, int P, int Cin, int Cout) {
   float best = 1e9f, sum = 0.f;
   const int reps = 9;
   for (int i = 0; i < reps + 2; ++i) {
-    a.x = pool + (size_t)(i % 3) * region;
-    a.y = pool + (size_t)((i + 1) % 3) * region + (i % 3 == 1 ? 0 : 0);
+    // (pool mode: inputs from three 512 MiB regions that are only ever read, outputs into three others -- an earlier version read what the
+    //  launch before had written, i.e. from the Infinity Cache, and flattered every variant by ~10 us)
+    a.x = g_split ? g_xs[i % 12] : pool + (size_t)(i % 3) * (region / 2);
+    a.y = g_split ? g_ys[i % 3] : pool + (3ull << 29) + (size_t)(i % 3) * (region / 2);
     CK(hipEventRecord(e0));
     hipLaunchKernelGGL((k<MT, NSETS, WPS, RELU16>), dim3((waves + 3) / 4), dim3(256), 0, 0, a);
     CK(hipEventRecord(e1));
@@ -143,27 +151,42 @@ void both(char* pool, int P, int Cin, int Cout) {
   run<MT, NSETS, WPS, true>(pool, P, Cin, Cout);
 }
 
-int main() {
+// float16 values in [0.5, 2) with random mantissas (argument "random"): activations that look like data, not like a memset
+__global__ void fill_random(unsigned* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long z = 0x9E3779B97F4A7C15ull * (i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    const unsigned r = (unsigned)(z >> 32);
+    p[i] = (0x3800u | (r & 0x07ffu)) | ((0x3800u | ((r >> 16) & 0x07ffu)) << 16);
+  }
+}
+
+int main(int argc, char** argv) {
   char* pool;
   CK(hipMalloc(&pool, 3ull << 30));
   CK(hipMemset(pool, 0, 3ull << 30));
+  const bool random = argc > 1 && argv[1][0] == 'r';
+  if (random) hipLaunchKernelGGL(fill_random, dim3(8192), dim3(256), 0, 0, reinterpret_cast<unsigned*>(pool), (3ull << 30) / 4);
+  g_split = argc > 2 && argv[2][0] == 's';
+  if (g_split) {
+    for (int i = 0; i < 12; ++i) {
+      CK(hipMalloc(&g_xs[i], 30u << 20));
+      if (random) hipLaunchKernelGGL(fill_random, dim3(2048), dim3(256), 0, 0, reinterpret_cast<unsigned*>(g_xs[i]), (size_t)(30u << 20) / 4);
+      else CK(hipMemset(g_xs[i], 0, 30u << 20));
+    }
+    for (int i = 0; i < 3; ++i) { CK(hipMalloc(&g_ys[i], 120u << 20)); CK(hipMemset(g_ys[i], 0, 120u << 20)); }
+  }
+  printf("pool contents: %s; %s\n", random ? "random float16 in [0.5, 2)" : "zeros", g_split ? "x / y in allocations of their own" : "x / y = regions of one 3 GiB allocation");
   CK(hipDeviceSynchronize());
   const int shapes[2][3] = {{32 * 94 * 311, 16, 64}, {32 * 47 * 156, 32, 128}};
   for (auto& s : shapes) {
     both<4, 2, 3>(pool, s[0], s[1], s[2]);
-    both<4, 2, 4>(pool, s[0], s[1], s[2]);
     both<4, 3, 3>(pool, s[0], s[1], s[2]);
-    both<4, 3, 2>(pool, s[0], s[1], s[2]);
     both<4, 4, 2>(pool, s[0], s[1], s[2]);
     both<2, 2, 4>(pool, s[0], s[1], s[2]);
-    both<2, 3, 4>(pool, s[0], s[1], s[2]);
     both<2, 4, 4>(pool, s[0], s[1], s[2]);
-    both<2, 4, 5>(pool, s[0], s[1], s[2]);
-    both<2, 3, 6>(pool, s[0], s[1], s[2]);
     both<8, 2, 2>(pool, s[0], s[1], s[2]);
-    both<8, 3, 2>(pool, s[0], s[1], s[2]);
-    both<1, 4, 8>(pool, s[0], s[1], s[2]);
-    both<1, 6, 8>(pool, s[0], s[1], s[2]);
     printf("\n");
   }
   return 0;

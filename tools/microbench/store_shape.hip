@@ -60,8 +60,8 @@ void run(char* pool, size_t npix, int nwaves) {
   float best = 1e9f, sum = 0.f;
   const int reps = 9;
   for (int i = 0; i < reps + 2; ++i) {
-    const char* s = pool + (size_t)(i % 3) * region;
-    char* d = pool + (size_t)((i + 1) % 3) * region;
+    const char* s = pool + (size_t)(i % 3) * (region / 2);            // sources: three 512 MiB regions that are only ever read
+    char* d = pool + (3ull << 29) + (size_t)(i % 3) * (region / 2);    // destinations: three others
     CK(hipEventRecord(a));
     hipLaunchKernelGGL((k<SHAPE, MT>), dim3((nwaves + 3) / 4), dim3(256), 0, 0, s, d, ntiles, nwaves);
     CK(hipEventRecord(b));
