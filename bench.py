@@ -254,6 +254,36 @@ def rocprof_launch_ms(traffic_profile, layer, stats_suffix="_kernel_stats.txt"):
         return None
 
 
+def dominant_kernel_from_stats(config_name):
+    """The kernel with the largest total time in the committed rocprofv3 --kernel-trace --stats summary of this config and THIS build
+    (profiles/*_kernel_stats_<config>.txt, fingerprint in its header), with its average launch and its share of the profiled time;
+    None when no summary of this build is committed.  (Training lines: `roofline` itself stays the whole step -- forward + loss +
+    backward + update are ~300 launches of ~40 kernels; this names the one to look at first.)"""
+    prof = os.path.join(ROOT, "profiles")
+    fp = build_fingerprint()
+    best = None
+    for f in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
+        if not f.endswith("_kernel_stats_%s.txt" % config_name):
+            continue
+        rows, fp_ok = [], False
+        try:
+            with open(os.path.join(prof, f)) as fh:
+                for line in fh:
+                    if line.startswith("# build_fingerprint:"):
+                        fp_ok = line.split(":", 1)[1].strip() == fp
+                    elif not line.startswith(("#", "kernel ")) and len(line) > 92:
+                        c = line[90:].split()
+                        rows.append((line[:88].rstrip(), int(c[0]), float(c[1]), float(c[2]), float(c[3])))
+        except (OSError, ValueError, IndexError):
+            continue
+        rows = [r for r in rows if "calib_" not in r[0] and "rocclr" not in r[0] and "at::native" not in r[0]]
+        if fp_ok and rows:
+            top = max(rows, key=lambda r: r[2])
+            best = {"kernel": top[0], "launches_profiled": top[1], "avg_launch_us": round(top[3], 2), "share_of_profiled_time": round(top[4] / 100.0, 4),
+                    "profile": f}
+    return best
+
+
 def rotation_count(batch_bytes):
     """distinct input batches to rotate through: at least 4, and more than the Infinity Cache holds"""
     return max(4, int(np.ceil(1.3 * MALL_BYTES / float(batch_bytes))))
@@ -805,6 +835,7 @@ def run_train(args, rank, local_rank, world, device):
     roof["kernel"] = "whole training step (forward + loss + backward + update; ~300 launches%s)" % (", replayed as one hipGraph" if use_graph else "")
     roof["avg_launch_ms"] = round(step_ms, 4)
     roof["algorithmic_flops_per_launch"] = flops
+    roof["dominant_kernel"] = dominant_kernel_from_stats(args.config)
     res = result_head(args, value, world, elapsed, ranks_seen, devices, clocks)
     res["config"] = {"workload": "%s %s training, batch=%d per GPU, synthetic %dx%d images + KITTI-like ground truth (%d distinct batches "
                                  "in rotation): GPU label build + forward + loss + backward + gradient all-reduce + clipped Momentum"

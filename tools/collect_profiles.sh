@@ -32,7 +32,7 @@ KS_CONFIGS="sqdetplus_infer sqdet_train_fp32 res50_train_fp16 sqdet_train_fp16"
 # 2b. kernel stats of the other configs (which kernels carry SqueezeDet+, ResNet50 inference and the two training steps)
 for c in $KS_CONFIGS; do
   rocprofv3 --kernel-trace --stats -d $OUT/ks_$c -o ks --output-format csv -- python $R/bench.py --config $c --no-cpu-baseline --no-graph > $OUT/kstats_$c.log 2>&1
-  python $R/profiles/summarize.py $(find $OUT/ks_$c -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$c.txt "rocprofv3 --kernel-trace --stats -- python bench.py --config $c --no-cpu-baseline --no-graph" >> $OUT/kstats_$c.log 2>&1
+  python $R/profiles/summarize.py $(find $OUT/ks_$c -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$c.txt "rocprofv3 --kernel-trace --stats -- python bench.py --config $c --no-cpu-baseline --no-graph" $FP >> $OUT/kstats_$c.log 2>&1
   rm -rf $OUT/ks_$c
 done
 if [ "${FAST:-0}" != "1" ]; then
