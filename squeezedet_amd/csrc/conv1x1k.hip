@@ -214,6 +214,11 @@ int conv1x1_deepk_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStr
   //  below 60 k pixels, profiles/r04_conv1x1_shapes_ab.txt, inside the steps this kernel does: profiles/r05_conv1x1_threshold_ab.txt)
   const int min_pixels = tune(TUNE_DBG) == 53 ? 20000 : (tune(TUNE_DBG) == 54 ? 65536 : 8192);
   if (g.nchunk < 5 || g.nchunk > 48 || (size_t)g.nchunk * g.nt * 1024 > 152 * 1024 || c.P < min_pixels) return SQDET_OK;
+  // REDUCING convs only (Cin >= 2 Cout: the fire modules' squeeze1x1, ResNet50's branch2a): every cout group's workgroups stream all
+  // the pixels, so an expanding conv re-reads its input once per group (256 -> 1024: 16 times).  Stand-alone the tile kernel wins every
+  // shape with Cout > Cin / 2 but one (profiles/r05_conv1x1_shapes_ab.txt: 1.06-1.20x), in-step SqueezeDet+ -- whose deep 1x1s all are
+  // such -- runs 3.3 % faster without this kernel (profiles/r05_conv1x1_threshold_ab.txt).  ("dbg" 56: the round-4 rule, any ratio)
+  if (2 * c.Cout > c.Cin && tune(TUNE_DBG) != 56) return SQDET_OK;
   const size_t xb = (size_t)c.P * c.Cin * esz, yb = (size_t)c.P * c.y_cstride * esz;
   if (xb >= (1ull << 31) || yb >= (1ull << 31)) return SQDET_OK;   // 32-bit buffer offsets
   K1Args a;
