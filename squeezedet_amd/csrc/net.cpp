@@ -453,9 +453,10 @@ int refresh_folds(sqdet_net* net, hipStream_t st) {
   return SQDET_OK;
 }
 
-// squeeze1x1 + expand1x1 + expand3x3 -> one L_FIRE launch (decided at plan creation).  Heuristic
-// (tools/kbench.py on MI355X): fusion pays on the small late feature maps, where the three
-// launches are latency-bound; "fire_fuse" = 1 forces it everywhere, 2 disables it.
+// squeeze1x1 + expand1x1 + expand3x3 -> one L_FIRE launch (decided at plan creation) wherever a fused kernel takes the
+// module.  (Rounds 1-4 fused maps of <= 100000 pixels only -- tuned on SqueezeDet, whose large maps run the streaming
+// kernels anyway; SqueezeDet+'s 227 k-pixel fire2-4 at batch 8 run 1.5-2 % faster fused, SqueezeDet is level:
+// profiles/r05_fire_fuse_ab.txt.)  "fire_fuse" = 2 disables the fusion, 10 restores the pixel rule.
 void fuse_fires(sqdet_net* net, size_t esz) {
   if (conv_algo() != 0 || tune(3) == 2) return;
   std::vector<Layer> out;
@@ -466,7 +467,7 @@ void fuse_fires(sqdet_net* net, size_t esz) {
                       in[i + 1].k == 1 && in[i + 2].k == 3 && in[i + 1].out_buf == in[i + 2].out_buf;
     const long pixels = (long)net->batch * in[i].h * in[i].w;
     const bool streams = trio && tune(3) != 3 && fire_stream_eligible(in[i].cin, in[i].cout, in[i + 1].cout, in[i + 2].cout, net->dtype);
-    if (!trio || !(tune(3) == 1 || pixels <= 100000 || streams) ||
+    if (!trio || !(tune(3) != 10 || pixels <= 100000 || streams) ||
         !fire_fused_eligible(in[i].cin, in[i].cout, in[i + 1].cout, in[i + 2].cout, net->dtype)) {
       out.push_back(in[i]);
       continue;
