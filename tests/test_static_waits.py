@@ -1,0 +1,82 @@
+"""Static regression guard (no GPU): the wait counts hipcc puts into the tile loops of the forward's kernels and of the streaming 1x1
+kernels.  Round 5 found `s_waitcnt vmcnt(0)` -- "wait for every outstanding load AND store" -- inside loops that were written as
+software-pipelined: conv1x1_stream waited for its own stores at the top of every step, conv1x1_deepk's two load groups in flight were
+one, fire_dma / ConvDet waited for register-resident weights in the middle of a tile (their set-up waits were inline asm, which the
+compiler's wait-count pass cannot see).  The kernels are compiled here with the build's own flags (`hipcc -S --cuda-device-only`, ~40 s
+in parallel) and scanned with tools/wait_scan.py: the loops that carry the MFMAs must hold COUNTED compiler waits only."""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from squeezedet_amd import build as B  # noqa: E402
+from tools import wait_scan as W  # noqa: E402
+
+FILES = ["conv1x1.hip", "conv1x1k.hip", "fire3.hip", "convdet.hip", "chain.hip"]
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    d = tmp_path_factory.mktemp("isa")
+    flags = {s: e for s, e in B.SOURCES}
+
+    def comp(f):
+        out = os.path.join(str(d), f.split(".")[0] + ".s")
+        cmd = [B._hipcc()] + [c for c in B.COMMON if c != "-fPIC"] + flags[f] + ["-x", "hip", "-S", "--cuda-device-only", os.path.join(B.CSRC, f), "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return f, out
+    with cf.ThreadPoolExecutor(len(FILES)) as ex:
+        return dict(ex.map(comp, FILES))
+
+
+def _mfma_loops(path, pattern, min_mfma):
+    loops = [(name, lp) for name, ls in W.scan_file(path, pattern) for lp in ls if lp[2] >= min_mfma]
+    assert loops, "no loop with >= %d MFMAs in kernels matching %s" % (min_mfma, pattern)
+    return loops
+
+
+def test_conv1x1_stream_steps_never_wait_for_everything(asm):
+    """float16 forms of the fire modules' stand-alone 1x1 convs: squeeze (<2,1,4>, <4,1,4>, <4,2,4>), expand (<1,4,4>): every compiler
+    wait inside the two-step loop leaves the younger loads / stores in flight (the smallest count seen is 5)."""
+    for name, (t, n, nm, cw, aw) in _mfma_loops(asm["conv1x1.hip"], r"conv1x1_streamIDF16_Li(1ELi4|2ELi1|4ELi1|4ELi2)ELi4ELb1", 8):
+        assert cw and min(cw) >= 4, (name, t, cw)
+
+
+def test_conv1x1_deepk_keeps_two_groups_in_flight(asm):
+    """every fragment's wait leaves the other group's eight loads outstanding: vmcnt >= 8 throughout the block loop"""
+    for name, (t, n, nm, cw, aw) in _mfma_loops(asm["conv1x1k.hip"], r"conv1x1_deepkIDF16_Li[1-6]ELi16E", 8):
+        if n < 300:      # (the per-group MFMA sub-loops of partial unrolling carry no waits of their own)
+            continue
+        assert cw and min(cw) >= 8, (name, t, cw)
+
+
+def test_fire_dma_tile_loops_hold_no_compiler_waits(asm):
+    """the three forms without spills: hand-counted asm waits only (the fire5 + pool5 form reloads two spilled registers on its
+    edge-tile path -- `scratch_load` + vmcnt(0) -- and is checked for nothing else)"""
+    forms = {"ILb1ELb0ELi1ELi2ELi4ELi8ELi1ELi4": 0, "ILb1ELb1ELi1ELi2ELi2ELi8ELi2ELi4": 0, "ILb0ELb0ELi2ELi2ELi2ELi4ELi2ELi4": 0,
+             "ILb0ELb1ELi2ELi1ELi1ELi8ELi3ELi4": 2}
+    for form, allowed in forms.items():
+        for name, (t, n, nm, cw, aw) in _mfma_loops(asm["fire3.hip"], "fire_dma" + form, 4):
+            assert len(cw) <= allowed and all(c == 0 for c in cw), (name, t, cw)
+
+
+def test_convdet_stage_loop_counts(asm):
+    """the stage loop (360 MFMAs per trip): the explicit vmcnt(10) in front of the barrier, then counted waits for the weight steps --
+    no vmcnt(0) behind the barrier (it was inherited from the tile loop's back edge while the tile's first wait was inline asm)"""
+    for form in ("ILb1E", "ILb0E"):
+        inner = [lp for _, lp in _mfma_loops(asm["convdet.hip"], "convdet_dma_kernel" + form, 300) if lp[1] < 2000]
+        assert inner, form
+        for t, n, nm, cw, aw in inner:
+            assert cw and min(cw) >= 7 and aw == [10], (form, t, cw, aw)
+
+
+def test_fire_chain_loops_are_hand_counted(asm):
+    """the forward's five chain forms: no compiler wait inside any loop that carries MFMAs (every load there is an LDS-DMA)"""
+    for form in ("ILi2ELi3ELb0ELi6ELi0", "ILi2ELi4ELb0ELi6ELi0", "ILi2ELi6ELb0ELi6ELi0", "ILi3ELi6ELb0ELi4ELi0", "ILi3ELi0ELb1ELi6ELi0"):
+        for name, (t, n, nm, cw, aw) in _mfma_loops(asm["chain.hip"], "fire_chain" + form, 8):
+            assert cw == [], (name, t, cw)

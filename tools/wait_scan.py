@@ -1,38 +1,81 @@
-import re,sys
-# compiler-generated vmcnt waits (outside #ASMSTART..#ASMEND) inside loops, per kernel
-path=sys.argv[1]; pat=sys.argv[2] if len(sys.argv)>2 else ''
-name=None; lines=[]
-def report(name, lines):
-    inasm=False; tagged=[]
-    for l in lines:
-        if '#ASMSTART' in l: inasm=True
-        tagged.append((l,inasm))
-        if '#ASMEND' in l: inasm=False
-    labels={}
-    for i,(l,_) in enumerate(tagged):
-        m=re.match(r'^(\.LBB\w+):',l)
-        if m: labels[m.group(1)]=i
-    loops=[]
-    for i,(l,_) in enumerate(tagged):
-        m=re.search(r's_cbranch_\w+\s+(\.LBB\w+)|s_branch\s+(\.LBB\w+)',l)
+#!/usr/bin/env python
+"""Static check of `hipcc -S --cuda-device-only` output: per kernel and per LOOP (a label reached again by a later branch), the
+`s_waitcnt vmcnt(N)` values the COMPILER inserted and the ones that come from inline asm (between #ASMSTART / #ASMEND).
+
+Why: hipcc's wait-count pass decides how much of a software prefetch is one.  A compiler `vmcnt(0)` inside a tile loop means every
+outstanding load AND store is awaited there (round 5: conv1x1_stream waited for its own stores at the top of every step; conv1x1_deepk's
+"two load groups in flight" were one; behind asm set-up waits -- invisible to the pass -- fire_dma and ConvDet got waits in front of
+register-resident weights inside their tile loops).
+
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Isqueezedet_amd/csrc [the file's flags in build.py] -x hip -S --cuda-device-only \
+          squeezedet_amd/csrc/conv1x1.hip -o /tmp/conv1x1.s
+    python tools/wait_scan.py /tmp/conv1x1.s [regex on the mangled kernel name]
+tests/test_static_waits.py runs the same scan on the forward's kernels (no GPU needed)."""
+import re
+import sys
+
+
+def scan_file(path, pattern=""):
+    """-> [(kernel, [(loop label, instructions, mfma count, [compiler vmcnt], [asm vmcnt]), ...]), ...] for kernels matching `pattern`;
+    only loops that contain MFMAs are listed."""
+    out = []
+    name, lines = None, []
+    for l in open(path):
+        m = re.match(r"^(\w+):\s+; @", l)
         if m:
-            t=m.group(1) or m.group(2)
-            if t in labels and labels[t]<i: loops.append((labels[t],i,t))
-    # innermost-ish: report loops with mfma
-    out=[]
-    for a,b,t in loops:
-        body=tagged[a:b]
-        nm=sum('v_mfma' in x for x,_ in body)
-        if nm==0: continue
-        cw=[re.search(r'vmcnt\((\d+)\)',x).group(1) for x,ia in body if 'vmcnt' in x and not ia]
-        aw=[re.search(r'vmcnt\((\d+)\)',x).group(1) for x,ia in body if 'vmcnt' in x and ia]
-        out.append('   loop %s len %d mfma %d | compiler vmcnt: %s | asm vmcnt: %s'%(t,b-a,nm,' '.join(cw) or '-',' '.join(aw[:12]) or '-'))
-    if out: print(name[:120]); print('\n'.join(out))
-for l in open(path):
-    m=re.match(r'^(\w+):\s+; @',l)
-    if m: name=m.group(1); lines=[]; continue
-    if name is None: continue
-    if l.strip().startswith('.Lfunc_end'):
-        if re.search(pat,name): report(name,lines)
-        name=None; continue
-    lines.append(l)
+            name, lines = m.group(1), []
+            continue
+        if name is None:
+            continue
+        if l.strip().startswith(".Lfunc_end"):
+            if re.search(pattern, name):
+                loops = _loops(lines)
+                if loops:
+                    out.append((name, loops))
+            name = None
+            continue
+        lines.append(l)
+    return out
+
+
+def _loops(lines):
+    inasm, tagged = False, []
+    for l in lines:
+        if "#ASMSTART" in l:
+            inasm = True
+        tagged.append((l, inasm))
+        if "#ASMEND" in l:
+            inasm = False
+    labels = {}
+    for i, (l, _) in enumerate(tagged):
+        m = re.match(r"^(\.LBB\w+):", l)
+        if m:
+            labels[m.group(1)] = i
+    res = []
+    for i, (l, _) in enumerate(tagged):
+        m = re.search(r"s_cbranch_\w+\s+(\.LBB\w+)|s_branch\s+(\.LBB\w+)", l)
+        if not m:
+            continue
+        t = m.group(1) or m.group(2)
+        if t in labels and labels[t] < i:
+            body = tagged[labels[t]:i]
+            nm = sum("v_mfma" in x for x, _ in body)
+            if nm == 0:
+                continue
+            cw = [int(re.search(r"vmcnt\((\d+)\)", x).group(1)) for x, ia in body if "vmcnt" in x and not ia]
+            aw = [int(re.search(r"vmcnt\((\d+)\)", x).group(1)) for x, ia in body if "vmcnt" in x and ia]
+            res.append((t, i - labels[t], nm, cw, aw))
+    return res
+
+
+def main():
+    path = sys.argv[1]
+    pat = sys.argv[2] if len(sys.argv) > 2 else ""
+    for name, loops in scan_file(path, pat):
+        print(name[:120])
+        for t, n, nm, cw, aw in loops:
+            print("   loop %s len %d mfma %d | compiler vmcnt: %s | asm vmcnt: %s" % (t, n, nm, " ".join(map(str, cw)) or "-", " ".join(map(str, aw[:12])) or "-"))
+
+
+if __name__ == "__main__":
+    main()
