@@ -12,8 +12,11 @@ from concurrent.futures import ThreadPoolExecutor
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
-OBJ = os.path.join(PKG, "csrc", "build")
-LIB = os.path.join(PKG, "libsqdet_hip.so")
+# SQDET_BUILD_SUFFIX=_tl (with SQDET_EXTRA_DEFINES): an experiment build beside the default one -- its own object directory and
+# libsqdet_hip_tl.so, loaded through SQDET_LIB (tools/ab_lib.sh, the timeline tools)
+_SUFFIX = os.environ.get("SQDET_BUILD_SUFFIX", "")
+OBJ = os.path.join(PKG, "csrc", "build" + _SUFFIX)
+LIB = os.path.join(PKG, "libsqdet_hip%s.so" % _SUFFIX)
 
 # (source, extra flags).  postproc.hip must not contract mul+add (bit-exact decode / IoU).
 SOURCES = [
