@@ -206,7 +206,7 @@ bool dispatch_k1(K1Args& a, int nt, int ngroups, hipStream_t st) {
 // that have enough pixels to stream (>= 8192).  *handled = false: conv1x1_tile / the generic kernel take it.  ("dbg" 51 / 57: never)
 int conv1x1_deepk_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStream_t st, bool* handled) {
   *handled = false;
-  if (conv_algo() != 0 || tune(TUNE_DBG) == 51 || tune(TUNE_DBG) == 57) return SQDET_OK;
+  if (conv_algo() != 0 || tune(TUNE_DBG) == 51 || tune(TUNE_DBG) == 57 || (tune(TUNE_DBG) >= 61 && tune(TUNE_DBG) <= 79)) return SQDET_OK;
   if (c.k != 1 || c.stride != 1 || c.pt != 0 || c.pl != 0 || g.gather || c.accum || c.relu_of) return SQDET_OK;
   const int esz = dtype == SQDET_F16 ? 2 : 4;
   if (c.x_coffset != 0 || c.x_cstride != c.Cin || (c.Cin * esz) % 16 != 0) return SQDET_OK;

@@ -214,7 +214,15 @@ bool dispatch_g1(const G1Args& a, int mbw, int wr, int ntw, size_t lds, hipStrea
 //     multiply zeros: K is walked in whole trips);
 //   * ONE counted wait + one bare barrier per chunk: `s_waitcnt vmcnt((NS - 2) * (Q + NTW))` leaves the two younger chunks' requests
 //     in flight (vmcnt is one in-order counter over the DMA pieces and the fragment loads), the barrier publishes the other waves'
-//     pieces of the slot and retires everybody's reads of the slot that is refilled behind it;
+//     pieces of the slot and retires everybody's reads of the slot that is refilled behind it.  For that count to be EXACT every
+//     memory instruction of the loop is inline asm: with compiler-issued fragment loads hipcc's wait-count pass -- which cannot see
+//     the DMA pieces queued between them -- put `vmcnt((NS - 2) NTW)` in front of a chunk's MFMAs, i.e. waited for most of chunk
+//     c + 1 as well (first version of this kernel: 720 cycles per 16-MFMA chunk where a launch has one workgroup per CU).  The wait
+//     takes the chunk's fragment registers as in/out operands, so nothing that reads them can be scheduled above it;
+//     tests/test_static_waits.py checks that no other instruction touches a fragment register inside the loop;
+//   * the epilogue has no memory round trip: the bias is loaded before the loop, and the residual (`y +=`: ResNet50's branch2c,
+//     the backward-data sums) and the ReLU mask (`relu_of`) of the wave's tile come in by LDS-DMA before the first chunk is
+//     requested -- wave-private LDS, no registers, oldest in the queue (EPI form);
 //   * <= 256 registers: two workgroups per CU where the launch has them, so one's ramp and epilogue run under the other's MFMAs.
 // Accumulation order = ascending K chunks (+ 0 for the padding chunks): bitwise conv1x1_tile's and conv_direct's results.
 struct P1Args {
@@ -222,10 +230,15 @@ struct P1Args {
   int nt_pack, slices, grid_y, ptiles, pieces;
   int nchunk_pad;      // K chunks rounded up to whole NS-chunk trips
   unsigned x_bytes;    // extent of x (buffer resource: offsets beyond it read zeros)
+  unsigned y_bytes;    // extent of y / relu_of
+  int res_off, mask_off;   // EPI: LDS byte offsets of the residual / mask areas (-1: not staged)
+  int dbg;                 // -DSQDET_G1_EXP builds only: "dbg" 61 no activation traffic, 62 one weight chunk, 69 both, 63 K walked from a
+                           // per-tile start (what bounds the K loop: G1_DBG=.. tools/g1_kslope.py); -DSQDET_G1_TIMELINE: 71 = cycles per
+                           // step region (tools/g1_timeline.py)
 };
 
-// -DSQDET_G1_TIMELINE (experiments only, tools/g1_timeline.py): six s_memrealtime (100 MHz) stamps per workgroup -- entry, first NS - 1
-// chunks requested, chunk 0 landed, K loop done, queue drained, last store issued -- written once at the very end
+// -DSQDET_G1_TIMELINE (experiments only, tools/g1_timeline.py): seven s_memrealtime (100 MHz) stamps per workgroup -- entry, first NS - 1
+// chunks requested, chunk 0 landed, K loop done, queue drained, last store issued, stores retired -- written once at the very end
 #ifdef SQDET_G1_TIMELINE
 __device__ unsigned long long g_g1_tl[8192 * 8];
 #define GTL(k) do { gtl[k] = wall_clock64(); } while (0)
@@ -236,8 +249,33 @@ __device__ unsigned long long g_g1_tl[8192 * 8];
 __device__ __forceinline__ void g1_dma16(unsigned voff, const i32x4& rsrc, unsigned lds_dst) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_dst) : "memory", "m0");
 }
+// a weight fragment (wave-uniform base + lane offset + immediate), hidden from hipcc's wait-count pass like the DMA pieces (see the
+// header): the register is valid behind g1_wait
+template <int IMM>
+__device__ __forceinline__ void g1_wload(i32x4& dst, unsigned voff, const unsigned char* sbase) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
+// `s_waitcnt vmcnt(N)` + barrier; the chunk's fragment registers pass THROUGH it (nothing that reads them moves above the wait)
+template <int N, int NTW>
+__device__ __forceinline__ void g1_wait(i32x4 (&w)[NTW]) {
+  static_assert(N < 64 && NTW >= 2 && NTW <= 5, "");
+  if constexpr (NTW == 2)
+    asm volatile("s_waitcnt vmcnt(%2)\n\ts_barrier" : "+v"(w[0]), "+v"(w[1]) : "n"(N) : "memory");
+  else if constexpr (NTW == 3)
+    asm volatile("s_waitcnt vmcnt(%3)\n\ts_barrier" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]) : "n"(N) : "memory");
+  else if constexpr (NTW == 4)
+    asm volatile("s_waitcnt vmcnt(%4)\n\ts_barrier" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N) : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(%5)\n\ts_barrier" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]) : "n"(N) : "memory");
+}
 
-template <typename T, int MBW, int NTW, int WR, int NS>
+// how far ahead the activation pieces are requested (chunks), by tile size: the ring has DX + 2 slots of TP * 64 bytes
+template <int TP, int NS>
+struct P1Ring {
+  static constexpr int DX = TP <= 64 ? 6 : TP <= 128 ? 4 : NS - 1;
+};
+
+template <typename T, int MBW, int NTW, int WR, int NS, bool EPI>
 __global__ __launch_bounds__(256, 2) void conv1x1_pipe(P1Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int MB = MBW * WR;           // pixel blocks per tile
@@ -245,6 +283,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pipe(P1Args a) {
   constexpr int TP = 16 * MB;            // pixels per tile
   constexpr int CH = TP * 64;            // bytes of one K-chunk of the tile = one ring slot
   constexpr int Q = MB / 4;              // DMA pieces (16 pixels x 64 B) per wave per chunk
+  constexpr int DX = P1Ring<TP, NS>::DX, R = DX + 2;   // the activation ring: R slots, chunk c + DX requested while chunk c computes
+  static_assert(DX >= NS - 1, "a chunk's pieces are older in the queue than its weight fragments");
+  constexpr int RPM = sizeof(T) == 2 ? (NTW + 1) / 2 : NTW;   // EPI: 16-byte pieces per lane and pixel block (4 NTW couts)
   static_assert(MB % 4 == 0, "every wave fetches the same number of pieces (one wait count for all)");
   constexpr unsigned OOB = 0x80000000u;
   const unsigned lds_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
@@ -255,6 +296,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pipe(P1Args a) {
   unsigned long long gtl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   GTL(0);
+  // Every kernel argument the prologue needs is fetched HERE, in one batch behind one wait: left alone hipcc requests them where
+  // they are first used -- seven dependent scalar-load round trips (0.2-0.5 us each on a busy chip) in front of the first request.
+  asm volatile("" ::"s"(a.ptiles), "s"(a.grid_y), "s"(a.slices), "s"(a.nt_pack), "s"(a.pieces), "s"(a.nchunk_pad), "s"(a.x_bytes),
+               "s"(a.y_bytes), "s"(a.res_off), "s"(a.mask_off), "s"(a.c.nchunk), "s"(a.c.steps), "s"(a.c.P), "s"(a.c.Cout),
+               "s"(a.c.stride), "s"(a.c.x_cstride), "s"(a.c.x_coffset), "s"(a.c.y_cstride), "s"(a.c.y_coffset));
+  asm volatile("" ::"s"(a.c.x), "s"(a.c.wp), "s"(a.c.bias), "s"(a.c.y), "s"(a.c.relu_of), "s"(a.c.relu));
+#ifdef SQDET_G1_TIMELINE
+  const unsigned long long clk0 = clock64();   // shader cycles: gtl[7] = cycles between here and the last stamp (effective clock)
+#endif
   // XCD-aware order (as conv1x1_tile): workgroup L runs on XCD L % 8; an XCD owns a contiguous band of pixel tiles, the grid_y
   // workgroups of one pixel tile are neighbours on the same XCD
   const int per_xcd = (a.ptiles + 7) / 8;
@@ -272,11 +322,44 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pipe(P1Args a) {
   const int group = slice / spg;
   const int n0 = (slice - group * spg) * NTW;
   const int nchunk = a.c.nchunk;
+  const int esz = (int)sizeof(T);
+  const int cb = group * 16 * a.nt_pack + g * 4 * a.nt_pack + n0 * 4;   // this lane's 4 NTW consecutive couts
+
+  // ---- epilogue operands first (oldest in the queue): the tile's residual / mask -> wave-private LDS, lane-linear
+  const unsigned yrow = (unsigned)(a.c.y_cstride * esz);
+  const unsigned ycol = (unsigned)((a.c.y_coffset + cb) * esz);
+  const int pe0 = p0 + wr * MBW * 16 + j;                        // this lane's pixel of block m: pe0 + 16 m
+  if constexpr (EPI) {
+    const unsigned long long yaddr = (unsigned long long)(uintptr_t)a.c.y, maddr = (unsigned long long)(uintptr_t)a.c.relu_of;
+    const i32x4 ry = {(int)(unsigned)yaddr, (int)(unsigned)((yaddr >> 32) & 0xffffu), (int)a.y_bytes, 0x00020000};
+    const i32x4 rm = {(int)(unsigned)maddr, (int)(unsigned)((maddr >> 32) & 0xffffu), (int)a.y_bytes, 0x00020000};
+#pragma unroll
+    for (int m = 0; m < MBW; ++m) {
+      const int p = pe0 + 16 * m;
+      const unsigned yo = p < a.c.P && active ? (unsigned)p * yrow + ycol : OOB;
+#pragma unroll
+      for (int r = 0; r < RPM; ++r) {
+        // (pieces past Cout read the neighbour's couts or zeros: never used)
+        if (a.res_off >= 0) g1_dma16(yo + (unsigned)(r * 16), ry, lds_addr + (unsigned)(a.res_off + ((wave * MBW + m) * RPM + r) * 1024));
+        if (a.mask_off >= 0) g1_dma16(yo + (unsigned)(r * 16), rm, lds_addr + (unsigned)(a.mask_off + ((wave * MBW + m) * RPM + r) * 1024));
+      }
+    }
+  }
+  // the bias as raw buffer loads (no bias / couts past Cout: out of range, zeros) -- nothing here waits for them
+  f32x4 bias[NTW];
+  int nt_valid = 0;   // Cout is a multiple of 4: whole 4-cout pieces beyond Cout are skipped
+  {
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.c.bias), 0, a.c.bias ? a.c.Cout * 4 : 0, 0x00020000);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      bias[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)(cb + t * 4) * 4u, 0, 0));
+      nt_valid += cb + t * 4 < a.c.Cout ? 1 : 0;
+    }
+  }
 
   // ---- this lane's DMA sources: piece i = pixel block wave + 4 i of the tile; lane = (pixel l >> 2, LDS slot l & 3)
   const unsigned long long xaddr = (unsigned long long)(uintptr_t)a.c.x;
   const i32x4 rx = {(int)(unsigned)xaddr, (int)(unsigned)((xaddr >> 32) & 0xffffu), (int)a.x_bytes, 0x00020000};
-  const int esz = (int)sizeof(T);
   const int row_bytes = a.c.x_cstride * esz;
   const int piece = (lane & 3) ^ ((lane >> 3) & 3);              // the slot's XOR swizzle: (P >> 1) & 3 == (l >> 3) & 3
   const int nvalid = (a.pieces - piece + 3) >> 2;                // chunks c < nvalid hold this lane's piece
@@ -293,21 +376,56 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pipe(P1Args a) {
     }
     xoff[i] = p < a.c.P ? sp * (unsigned)row_bytes + (unsigned)(a.c.x_coffset * esz + piece * 16) : OOB;
   }
-  const i32x4* wbase = reinterpret_cast<const i32x4*>(a.c.wp) + ((size_t)group * a.c.steps * a.nt_pack + n0) * 64 + lane;
+  // weight fragment t of chunk c: wave-uniform base + lane * 16 (+ 4096 for the fifth tile: the immediate ends at 4095)
+  const unsigned char* wgrp = reinterpret_cast<const unsigned char*>(a.c.wp) + ((size_t)group * a.c.steps * a.nt_pack + n0) * 1024;
+  const unsigned wlane = (unsigned)lane * 16u, wlane4 = wlane + 4096u;
+  const unsigned wstep = (unsigned)a.nt_pack * 1024u;
 
   i32x4 wf[NS][NTW];
-  // requests chunk c: the tile's pieces into ring slot `slot`, the weight fragments into register set `set` (both static)
-  auto request = [&](int c, int set, int slot) {
+  // the tile's pieces of chunk c into ring slot `slot` (wave-uniform)
+  auto request_x = [&](int c, int slot) {
+#ifdef SQDET_G1_EXP
+    if (a.dbg == 63 && c < nchunk) { c += (tile * 5) % nchunk; c = c >= nchunk ? c - nchunk : c; }
+    if (a.dbg == 61 || a.dbg == 69) c = 1 << 20;
+#endif
 #pragma unroll
     for (int i = 0; i < Q; ++i)
       g1_dma16(c < nvalid ? xoff[i] + (unsigned)(c * 64) : OOB, rx, lds_addr + (unsigned)(slot * CH + (wave + 4 * i) * 1024));
-    const int cw = c < nchunk ? c : nchunk - 1;
-    const i32x4* wp = wbase + (size_t)cw * a.nt_pack * 64;
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) wf[set][t] = wp[t * 64];
   };
+  // the weight fragments of chunk c into register set `set` (static)
+  auto request_w = [&](int c, int set) {
+#ifdef SQDET_G1_EXP
+    if (a.dbg == 63 && c < nchunk) { c += (tile * 5) % nchunk; c = c >= nchunk ? c - nchunk : c; }
+    if (a.dbg == 62 || a.dbg == 69) c = 0;
+#endif
+    const int cw = c < nchunk ? c : nchunk - 1;
+    const unsigned char* sb = wgrp + (size_t)cw * wstep;
+    g1_wload<0>(wf[set][0], wlane, sb);
+    g1_wload<1024>(wf[set][1], wlane, sb);
+    if constexpr (NTW > 2) g1_wload<2048>(wf[set][2], wlane, sb);
+    if constexpr (NTW > 3) g1_wload<3072>(wf[set][3], wlane, sb);
+    if constexpr (NTW > 4) g1_wload<0>(wf[set][4], wlane4, sb);
+  };
+  // One step of the pipeline computes chunk c while chunk c + 1 is made available:
+  //     LDS reads of chunk c's LATER pixel blocks (m >= H)
+  //     MFMAs of the chunk's first H pixel blocks  +  the fragment loads of chunk c - 1 + NS (into the set chunk c - 1 has left)
+  //     wait + barrier for chunk c + 1             (covered by the MFMAs just issued)
+  //     LDS reads of chunk c + 1's first H pixel blocks (their latency runs under the MFMAs that follow)
+  //     MFMAs of the later pixel blocks            +  the DMA pieces of chunk c + 1 + DX (into the slot chunk c - 1 has left)
+  // i.e. every LDS read is issued half a chunk of MFMAs before its use, with MBW + H fragments live.
+  // (first version: wait, requests, LDS reads, MFMAs per chunk -- hipcc kept two B fragments live and exposed the LDS latency twice
+  //  per chunk: 720 cycles per 16-MFMA chunk with or without any memory traffic, tools/g1_timeline.py "dbg" 61 / 62.)
+  // The queue in front of the loop is the steady state's: per step [fragments x NTW][wait][pieces x Q], the wait for chunk k leaves
+  // the (NS - 2) younger steps' requests in flight.
+  constexpr int NWAIT = (NS - 2) * (Q + NTW);
+  constexpr int H = (MBW + 1) / 2;
 #pragma unroll
-  for (int u = 0; u < NS - 1; ++u) request(u, u, u);
+  for (int c = 0; c < DX + 2 - NS; ++c) request_x(c, c);
+#pragma unroll
+  for (int u = 0; u < NS - 1; ++u) {
+    request_w(u, u);
+    if (u < NS - 2) request_x(DX + 2 - NS + u, DX + 2 - NS + u);
+  }
   GTL(1);
 
   f32x4 acc[MBW][NTW];
@@ -317,23 +435,53 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pipe(P1Args a) {
     for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const unsigned char* lrd = lds + (wr * MBW * 16 + j) * 64 + ((g ^ ((j >> 1) & 3)) << 4);
+  g1_wait<NWAIT, NTW>(wf[0]);            // chunk 0 has landed
+  GTL(2);
+  request_x(DX, DX);
+  i32x4 bfa[H];                          // B fragments of the computing chunk's first H pixel blocks
+#pragma unroll
+  for (int m = 0; m < H; ++m) bfa[m] = *reinterpret_cast<const i32x4*>(lrd + m * 16 * 64);
+  int slot = 0;                          // ring slot of the chunk that computes (wave-uniform)
+#ifdef SQDET_G1_TIMELINE
+  unsigned long long rg[3] = {0, 0, 0}, slast = clock64();   // "dbg" 71: shader cycles per step region (A first half, B wait, C rest)
+#endif
 #pragma unroll 1
   for (int c0 = 0; c0 < a.nchunk_pad; c0 += NS) {
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-      // chunk c0 + u has landed (mine: the wait; everybody's: the barrier); everybody is done with slot (u - 1) % NS
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NS - 2) * (Q + NTW)) : "memory");
+      const int c = c0 + u;
+      __builtin_amdgcn_sched_barrier(0);
 #ifdef SQDET_G1_TIMELINE
-      if (c0 == 0 && u == 0) GTL(2);
+      unsigned long long s0 = 0, s1 = 0, s2 = 0;
+      if (a.dbg == 71) { s0 = clock64(); rg[2] += s0 - slast; }
 #endif
-      request(c0 + u + NS - 1, (u + NS - 1) % NS, (u + NS - 1) % NS);
-      i32x4 bf[MBW];
+      i32x4 bfb[MBW - H];
 #pragma unroll
-      for (int m = 0; m < MBW; ++m) bf[m] = *reinterpret_cast<const i32x4*>(lrd + u * CH + m * 16 * 64);
+      for (int m = H; m < MBW; ++m) bfb[m - H] = *reinterpret_cast<const i32x4*>(lrd + slot * CH + m * 16 * 64);
+      request_w(c - 1 + NS, (u + NS - 1) % NS);
 #pragma unroll
-      for (int m = 0; m < MBW; ++m)
+      for (int m = 0; m < H; ++m)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], wf[u][t], bf[m]);
+        for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], wf[u][t], bfa[m]);
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef SQDET_G1_TIMELINE
+      if (a.dbg == 71) s1 = clock64();
+#endif
+      g1_wait<NWAIT, NTW>(wf[(u + 1) % NS]);       // chunk c + 1: mine by the wait, everybody's by the barrier
+#ifdef SQDET_G1_TIMELINE
+      if (a.dbg == 71) { s2 = clock64(); rg[0] += s1 - s0; rg[1] += s2 - s1; slast = s2; }
+#endif
+      const int snext = slot + 1 == R ? 0 : slot + 1;
+#pragma unroll
+      for (int m = 0; m < H; ++m) bfa[m] = *reinterpret_cast<const i32x4*>(lrd + snext * CH + m * 16 * 64);
+      __builtin_amdgcn_sched_barrier(0);
+      // slot of chunk c - 1: every wave has issued chunk c's first MFMAs, i.e. retired its reads of chunks < c
+      request_x(c + 1 + DX, slot == 0 ? R - 1 : slot - 1);
+#pragma unroll
+      for (int m = H; m < MBW; ++m)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], wf[u][t], bfb[m - H]);
+      slot = snext;
     }
   }
   GTL(3);
@@ -342,45 +490,79 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pipe(P1Args a) {
   GTL(4);
   if (!active) return;
 
-  T* y = reinterpret_cast<T*>(a.c.y);
-  const int cb = group * 16 * a.nt_pack + g * 4 * a.nt_pack + n0 * 4;
-  f32x4 bias[NTW];
-  int nt_valid = 0;
-#pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    const bool ok = cb + t * 4 < a.c.Cout;
-    bias[t] = ok && a.c.bias ? *reinterpret_cast<const f32x4*>(a.c.bias + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    nt_valid += ok ? 1 : 0;
-  }
+  // ---- epilogue: lane = pixel (block m, column j), 4 NTW consecutive couts; raw buffer stores (pixels past the end: dropped)
+  const __amdgpu_buffer_rsrc_t ryb = __builtin_amdgcn_make_buffer_rsrc(a.c.y, 0, a.y_bytes, 0x00020000);
+  constexpr unsigned DROP = 0xfffffff0u;
+  // 16-byte stores of float16 tile pairs need whole tile pairs and 16-byte aligned row segments (wave-uniform)
+  const bool wide = sizeof(T) == 2 && (NTW & 1) == 0 && nt_valid == NTW &&
+                    ((reinterpret_cast<uintptr_t>(a.c.y) + (size_t)(a.c.y_coffset + group * 16 * a.nt_pack + n0 * 4) * esz) & 15) == 0 &&
+                    (yrow & 15) == 0 && ((4 * a.nt_pack * esz) & 15) == 0;
+  const unsigned char* lres = lds + (a.res_off >= 0 ? a.res_off : 0) + wave * MBW * RPM * 1024 + lane * 16;
+  const unsigned char* lmask = lds + (a.mask_off >= 0 ? a.mask_off : 0) + wave * MBW * RPM * 1024 + lane * 16;
 #pragma unroll
   for (int m = 0; m < MBW; ++m) {
-    const int p = p0 + (wr * MBW + m) * 16 + j;
-    if (p >= a.c.P) continue;
-    T* dst = y + (size_t)p * a.c.y_cstride + a.c.y_coffset + cb;
+    const int p = pe0 + 16 * m;
+    const unsigned yo = p < a.c.P ? (unsigned)p * yrow + ycol : DROP;
     f32x4 v[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
       v[t] = acc[m][t] + bias[t];
-      if (a.c.accum && t < nt_valid) {
-        v[t][0] += (float)dst[t * 4 + 0]; v[t][1] += (float)dst[t * 4 + 1];
-        v[t][2] += (float)dst[t * 4 + 2]; v[t][3] += (float)dst[t * 4 + 3];
+      if constexpr (EPI) {
+        if (a.res_off >= 0) {
+          f32x4 r;
+          if constexpr (sizeof(T) == 2) {
+            const f16x8 h = *reinterpret_cast<const f16x8*>(lres + (m * RPM + (t >> 1)) * 1024);
+            r = f32x4{(float)h[(t & 1) * 4 + 0], (float)h[(t & 1) * 4 + 1], (float)h[(t & 1) * 4 + 2], (float)h[(t & 1) * 4 + 3]};
+          } else {
+            r = *reinterpret_cast<const f32x4*>(lres + (m * RPM + t) * 1024);
+          }
+          v[t][0] += r[0]; v[t][1] += r[1]; v[t][2] += r[2]; v[t][3] += r[3];
+        }
       }
       if (a.c.relu) {
         v[t][0] = fmaxf(v[t][0], 0.f); v[t][1] = fmaxf(v[t][1], 0.f);
         v[t][2] = fmaxf(v[t][2], 0.f); v[t][3] = fmaxf(v[t][3], 0.f);
       }
-      if (a.c.relu_of && t < nt_valid) {
-        const T* r = reinterpret_cast<const T*>(a.c.relu_of) + (dst - y) + t * 4;
-        v[t][0] = (float)r[0] > 0.f ? v[t][0] : 0.f; v[t][1] = (float)r[1] > 0.f ? v[t][1] : 0.f;
-        v[t][2] = (float)r[2] > 0.f ? v[t][2] : 0.f; v[t][3] = (float)r[3] > 0.f ? v[t][3] : 0.f;
+      if constexpr (EPI) {
+        if (a.mask_off >= 0) {             // ReLU backward of the layer below (see ConvArgs)
+          f32x4 r;
+          if constexpr (sizeof(T) == 2) {
+            const f16x8 h = *reinterpret_cast<const f16x8*>(lmask + (m * RPM + (t >> 1)) * 1024);
+            r = f32x4{(float)h[(t & 1) * 4 + 0], (float)h[(t & 1) * 4 + 1], (float)h[(t & 1) * 4 + 2], (float)h[(t & 1) * 4 + 3]};
+          } else {
+            r = *reinterpret_cast<const f32x4*>(lmask + (m * RPM + t) * 1024);
+          }
+          v[t][0] = r[0] > 0.f ? v[t][0] : 0.f; v[t][1] = r[1] > 0.f ? v[t][1] : 0.f;
+          v[t][2] = r[2] > 0.f ? v[t][2] : 0.f; v[t][3] = r[3] > 0.f ? v[t][3] : 0.f;
+        }
       }
     }
-    store_couts<T, NTW>(dst, v, nt_valid);
+    if (wide) {
+#pragma unroll
+      for (int t = 0; t + 1 < NTW; t += 2) {
+        const f16x8 h = {(f16)v[t][0], (f16)v[t][1], (f16)v[t][2], (f16)v[t][3],
+                         (f16)v[t + 1][0], (f16)v[t + 1][1], (f16)v[t + 1][2], (f16)v[t + 1][3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, h), ryb, yo != DROP ? yo + (unsigned)(t * 4 * esz) : DROP, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const unsigned off = (yo != DROP && t < nt_valid) ? yo + (unsigned)(t * 4 * esz) : DROP;
+        if constexpr (sizeof(T) == 2) {
+          const f16x4 h = {(f16)v[t][0], (f16)v[t][1], (f16)v[t][2], (f16)v[t][3]};
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, h), ryb, off, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v[t]), ryb, off, 0, 0);
+        }
+      }
+    }
   }
 #ifdef SQDET_G1_TIMELINE
   GTL(5);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   GTL(6);
+  gtl[7] = clock64() - clk0;
+  if (a.dbg == 71) { gtl[1] = rg[0]; gtl[2] = rg[1]; gtl[3] = rg[2]; }
   if (threadIdx.x == 0 && blockIdx.x < 8192) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) g_g1_tl[(size_t)blockIdx.x * 8 + k] = gtl[k];
@@ -388,29 +570,49 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pipe(P1Args a) {
 #endif
 }
 
-template <typename T, int MBW, int NTW, int WR, int NS>
-void launch_p1(const P1Args& a, hipStream_t st) {
+template <typename T, int MBW, int NTW, int WR, int NS, bool EPI>
+void launch_p1(P1Args& a, hipStream_t st) {
   const int per_xcd = (a.ptiles + 7) / 8;
   const dim3 grid((unsigned)(per_xcd * a.grid_y * 8));
-  const size_t lds = (size_t)NS * 16 * MBW * WR * 64;
-  hipLaunchKernelGGL((conv1x1_pipe<T, MBW, NTW, WR, NS>), grid, dim3(256), lds, st, a);
+  constexpr int RPM = sizeof(T) == 2 ? (NTW + 1) / 2 : NTW;
+  size_t lds = (size_t)(P1Ring<16 * MBW * WR, NS>::DX + 2) * 16 * MBW * WR * 64;
+  const bool want_res = a.res_off >= 0, want_mask = a.mask_off >= 0;
+  a.res_off = a.mask_off = -1;
+  if (EPI && want_res) { a.res_off = (int)lds; lds += (size_t)4 * MBW * RPM * 1024; }
+  if (EPI && want_mask) { a.mask_off = (int)lds; lds += (size_t)4 * MBW * RPM * 1024; }
+  auto kern = &conv1x1_pipe<T, MBW, NTW, WR, NS, EPI>;
+  if (lds > 64 * 1024) {
+    static PerDevice once;
+    (void)once.run([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
 }
 
-template <typename T, int MBW, int WR, int NS>
-bool dispatch_p1_ntw(const P1Args& a, int ntw, hipStream_t st) {
+template <typename T, int MBW, int WR, int NS, bool EPI>
+bool dispatch_p1_ntw(P1Args& a, int ntw, hipStream_t st) {
   switch (ntw) {
-    case 3: launch_p1<T, MBW, 3, WR, NS>(a, st); return true;
-    case 4: launch_p1<T, MBW, 4, WR, NS>(a, st); return true;
-    case 5: if constexpr (MBW <= 4) { launch_p1<T, MBW, 5, WR, NS>(a, st); return true; } return false;
+    case 2: launch_p1<T, MBW, 2, WR, NS, EPI>(a, st); return true;
+    case 3: launch_p1<T, MBW, 3, WR, NS, EPI>(a, st); return true;
+    case 4: launch_p1<T, MBW, 4, WR, NS, EPI>(a, st); return true;
+    case 5: if constexpr (MBW <= 4) { launch_p1<T, MBW, 5, WR, NS, EPI>(a, st); return true; } return false;
     default: return false;
   }
 }
 
-template <typename T, int NS>
-bool dispatch_p1(const P1Args& a, int mbw, int wr, int ntw, hipStream_t st) {
-  if (wr == 1) return mbw == 8 ? dispatch_p1_ntw<T, 8, 1, NS>(a, ntw, st) : dispatch_p1_ntw<T, 4, 1, NS>(a, ntw, st);
-  if (wr == 2) return mbw == 4 ? dispatch_p1_ntw<T, 4, 2, NS>(a, ntw, st) : dispatch_p1_ntw<T, 2, 2, NS>(a, ntw, st);
-  return mbw == 4 ? dispatch_p1_ntw<T, 4, 4, NS>(a, ntw, st) : dispatch_p1_ntw<T, 2, 4, NS>(a, ntw, st);
+template <typename T, int NS, bool EPI>
+bool dispatch_p1_geo(P1Args& a, int mbw, int wr, int ntw, hipStream_t st) {
+  if (wr == 1) {
+    if constexpr (!EPI) { if (mbw == 8) return dispatch_p1_ntw<T, 8, 1, NS, EPI>(a, ntw, st); }
+    return dispatch_p1_ntw<T, 4, 1, NS, EPI>(a, ntw, st);
+  }
+  if (wr == 2) return mbw == 4 ? dispatch_p1_ntw<T, 4, 2, NS, EPI>(a, ntw, st) : dispatch_p1_ntw<T, 2, 2, NS, EPI>(a, ntw, st);
+  return mbw == 4 ? dispatch_p1_ntw<T, 4, 4, NS, EPI>(a, ntw, st) : dispatch_p1_ntw<T, 2, 4, NS, EPI>(a, ntw, st);
+}
+
+template <typename T>
+bool dispatch_p1(P1Args& a, int mbw, int wr, int ntw, int ns, bool epi, hipStream_t st) {
+  if (epi) return ns == 4 ? dispatch_p1_geo<T, 4, true>(a, mbw, wr, ntw, st) : dispatch_p1_geo<T, 3, true>(a, mbw, wr, ntw, st);
+  return ns == 4 ? dispatch_p1_geo<T, 4, false>(a, mbw, wr, ntw, st) : dispatch_p1_geo<T, 3, false>(a, mbw, wr, ntw, st);
 }
 
 }  // namespace
@@ -440,17 +642,29 @@ int conv1x1_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
   a.ptiles = (c.P + 16 * mbw * wr - 1) / (16 * mbw * wr);
   // the pipelined form (conv1x1_pipe) for 3..5 cout tiles per wave; "dbg" 57: conv1x1_tile for everything (A/B)
   {
-    const size_t xb = (size_t)c.N * c.H * c.W * c.x_cstride * esz;
-    if (ntw >= 3 && xb < (1ull << 31) && tune(TUNE_DBG) != 57) {
+    const size_t xb = (size_t)c.N * c.H * c.W * c.x_cstride * esz, yb = (size_t)c.P * c.y_cstride * esz;
+    if ((ntw >= 3 || tune(TUNE_G1_NTW) == 2) && xb < (1ull << 31) && yb < (1ull << 31) && tune(TUNE_DBG) != 57) {
+      const bool epi = c.accum || c.relu_of;
+      int pm = mbw, pw = wr, pn = ntw;
+      if (tune(TUNE_G1_NTW) > 0 && g.nt % tune(TUNE_G1_NTW) == 0) pn = tune(TUNE_G1_NTW);
+      const int pslices = g.ngroups * (g.nt / pn);
+      if (tune(TUNE_G1_WR) > 0) pw = tune(TUNE_G1_WR);
+      if (tune(TUNE_G1_MBW) > 0) pm = tune(TUNE_G1_MBW);
+      if (pw == 1 && pm == 2) pm = 4;
+      if (pw != 1 && pm == 8) pm = 4;
+      if (epi && pw == 1 && pm == 8) pm = 4;      // the EPI form stages MBW x NTW KiB per wave and tensor: 64-pixel tiles
       P1Args p;
-      p.c = c; p.nt_pack = a.nt_pack; p.slices = a.slices; p.grid_y = a.grid_y; p.ptiles = a.ptiles; p.pieces = a.pieces;
-      p.x_bytes = (unsigned)xb;
+      p.c = c; p.nt_pack = a.nt_pack; p.slices = pslices; p.pieces = a.pieces;
+      p.grid_y = (pslices + 4 / pw - 1) / (4 / pw);
+      p.ptiles = (c.P + 16 * pm * pw - 1) / (16 * pm * pw);
+      p.x_bytes = (unsigned)xb; p.y_bytes = (unsigned)yb;
+      p.dbg = tune(TUNE_DBG);
+      p.res_off = c.accum ? 0 : -1; p.mask_off = c.relu_of ? 0 : -1;     // (launch_p1 turns the requests into LDS offsets)
       // ring depth = register sets = chunks per unrolled trip: the one that walks K in whole trips (4 when both do)
       const int pad4 = (g.nchunk + 3) / 4 * 4, pad3 = (g.nchunk + 2) / 3 * 3;
       const int ns = pad4 <= pad3 ? 4 : 3;
       p.nchunk_pad = ns == 4 ? pad4 : pad3;
-      const bool okp = dtype == SQDET_F16 ? (ns == 4 ? dispatch_p1<f16, 4>(p, mbw, wr, ntw, st) : dispatch_p1<f16, 3>(p, mbw, wr, ntw, st))
-                                          : (ns == 4 ? dispatch_p1<float, 4>(p, mbw, wr, ntw, st) : dispatch_p1<float, 3>(p, mbw, wr, ntw, st));
+      const bool okp = dtype == SQDET_F16 ? dispatch_p1<f16>(p, pm, pw, pn, ns, epi, st) : dispatch_p1<float>(p, pm, pw, pn, ns, epi, st);
       if (okp) {
         SQDET_CHECK_HIP(hipGetLastError());
         *handled = true;

@@ -25,7 +25,7 @@ SHAPES = [("res4 2a fwd / 2c dgrad", 8, 24, 78, 1024, 256, 0), ("res4 2c fwd / 2
           ("plus fire6 squeeze", 8, 45, 153, 256, 288, 0), ("plus fire6 e1", 8, 45, 153, 288, 192, 0),
           ("plus fire2 squeeze", 8, 92, 309, 96, 96, 0), ("plus fire3 e1", 8, 92, 309, 96, 128, 0),
           ("sqdet fire6 squeeze b32", 32, 24, 78, 256, 48, 0), ("sqdet fire11 squeeze b32", 32, 24, 78, 768, 96, 0)]
-WARM, ITERS = 3, 30
+WARM, ITERS = 2000, 200      # WARM: ~50-100 ms of launches first -- the clocks ramp; a cold burst reads 2x the in-step time
 
 
 def time_shape(n, h, w, cin, cout, add):
