@@ -407,9 +407,9 @@ int conv_algo() {
 void set_conv_algo(int v) { g_conv_algo = v; }
 
 // Experiment knobs (0 = built-in heuristic): see tune() call sites.
-static const char* const kTuneNames[] = {"c1_waves", "c1_mt", "c1_min_tiles", "fire_fuse", "stem_algo", "dbg", "g1_wr", "g1_mbw", "g1_ntw"};
-constexpr int kNumTune = 9;
-static int g_tune[kNumTune] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+static const char* const kTuneNames[] = {"c1_waves", "c1_mt", "c1_min_tiles", "fire_fuse", "stem_algo", "dbg", "g1_wr", "g1_mbw", "g1_ntw", "g1_ns"};
+constexpr int kNumTune = 10;
+static int g_tune[kNumTune] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 int tune(int which) { return g_tune[which]; }
 
 }  // namespace sqdet

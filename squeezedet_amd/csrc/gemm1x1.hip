@@ -269,12 +269,6 @@ __device__ __forceinline__ void g1_wait(i32x4 (&w)[NTW]) {
     asm volatile("s_waitcnt vmcnt(%5)\n\ts_barrier" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]) : "n"(N) : "memory");
 }
 
-// how far ahead the activation pieces are requested (chunks), by tile size: the ring has DX + 2 slots of TP * 64 bytes
-template <int TP, int NS>
-struct P1Ring {
-  static constexpr int DX = TP <= 64 ? 6 : TP <= 128 ? 4 : NS - 1;
-};
-
 template <typename T, int MBW, int NTW, int WR, int NS, bool EPI>
 __global__ __launch_bounds__(256, 2) void conv1x1_pipe(P1Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -283,8 +277,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pipe(P1Args a) {
   constexpr int TP = 16 * MB;            // pixels per tile
   constexpr int CH = TP * 64;            // bytes of one K-chunk of the tile = one ring slot
   constexpr int Q = MB / 4;              // DMA pieces (16 pixels x 64 B) per wave per chunk
-  constexpr int DX = P1Ring<TP, NS>::DX, R = DX + 2;   // the activation ring: R slots, chunk c + DX requested while chunk c computes
-  static_assert(DX >= NS - 1, "a chunk's pieces are older in the queue than its weight fragments");
   constexpr int RPM = sizeof(T) == 2 ? (NTW + 1) / 2 : NTW;   // EPI: 16-byte pieces per lane and pixel block (4 NTW couts)
   static_assert(MB % 4 == 0, "every wave fetches the same number of pieces (one wait count for all)");
   constexpr unsigned OOB = 0x80000000u;
@@ -382,49 +374,60 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pipe(P1Args a) {
   const unsigned wstep = (unsigned)a.nt_pack * 1024u;
 
   i32x4 wf[NS][NTW];
-  // the tile's pieces of chunk c into ring slot `slot` (wave-uniform)
-  auto request_x = [&](int c, int slot) {
+  // Requests walk the chunks in order, one chunk per step: running scalars instead of per-request address arithmetic (the K loop of a
+  // lone workgroup is ISSUE-bound: a dozen extra scalar instructions per step cost it 300 cycles, tools/g1_kslope.py on an -DSQDET_G1_EXP
+  // build).  wnext = the fragments of the next chunk to request (it stays on the last chunk: chunks past it multiply zeros),
+  // xk / xkb = index and byte offset of the next chunk's pieces.
+  const unsigned char* wnext = wgrp;
+  int wk = 0, xk = 0;
+  unsigned xkb = 0;
+  // the tile's pieces of the next chunk into ring slot `slot` (static)
+  auto request_x = [&](int slot) {
 #ifdef SQDET_G1_EXP
-    if (a.dbg == 63 && c < nchunk) { c += (tile * 5) % nchunk; c = c >= nchunk ? c - nchunk : c; }
-    if (a.dbg == 61 || a.dbg == 69) c = 1 << 20;
+    const bool off = a.dbg == 61 || a.dbg == 69;
+#else
+    constexpr bool off = false;
 #endif
 #pragma unroll
     for (int i = 0; i < Q; ++i)
-      g1_dma16(c < nvalid ? xoff[i] + (unsigned)(c * 64) : OOB, rx, lds_addr + (unsigned)(slot * CH + (wave + 4 * i) * 1024));
+      g1_dma16(xk < nvalid && !off ? xoff[i] + xkb : OOB, rx, lds_addr + (unsigned)(slot * CH + (wave + 4 * i) * 1024));
+    xk += 1;
+    xkb += 64u;
   };
-  // the weight fragments of chunk c into register set `set` (static)
-  auto request_w = [&](int c, int set) {
-#ifdef SQDET_G1_EXP
-    if (a.dbg == 63 && c < nchunk) { c += (tile * 5) % nchunk; c = c >= nchunk ? c - nchunk : c; }
-    if (a.dbg == 62 || a.dbg == 69) c = 0;
-#endif
-    const int cw = c < nchunk ? c : nchunk - 1;
-    const unsigned char* sb = wgrp + (size_t)cw * wstep;
+  // the weight fragments of the next chunk into register set `set` (static)
+  auto request_w = [&](int set) {
+    const unsigned char* sb = wnext;
     g1_wload<0>(wf[set][0], wlane, sb);
     g1_wload<1024>(wf[set][1], wlane, sb);
     if constexpr (NTW > 2) g1_wload<2048>(wf[set][2], wlane, sb);
     if constexpr (NTW > 3) g1_wload<3072>(wf[set][3], wlane, sb);
     if constexpr (NTW > 4) g1_wload<0>(wf[set][4], wlane4, sb);
+    wk += 1;
+#ifdef SQDET_G1_EXP
+    if (a.dbg == 62 || a.dbg == 69) return;
+#endif
+    wnext = wk < nchunk ? wnext + wstep : wnext;
   };
-  // One step of the pipeline computes chunk c while chunk c + 1 is made available:
+  // One step of the pipeline computes chunk c while chunk c + 1 is made available and chunk c + NS - 1 is requested:
   //     LDS reads of chunk c's LATER pixel blocks (m >= H)
-  //     MFMAs of the chunk's first H pixel blocks  +  the fragment loads of chunk c - 1 + NS (into the set chunk c - 1 has left)
+  //     MFMAs of the chunk's first H pixel blocks  +  the fragment loads of chunk c + NS - 1 (into the set chunk c - 1 has left)
   //     wait + barrier for chunk c + 1             (covered by the MFMAs just issued)
   //     LDS reads of chunk c + 1's first H pixel blocks (their latency runs under the MFMAs that follow)
-  //     MFMAs of the later pixel blocks            +  the DMA pieces of chunk c + 1 + DX (into the slot chunk c - 1 has left)
-  // i.e. every LDS read is issued half a chunk of MFMAs before its use, with MBW + H fragments live.
-  // (first version: wait, requests, LDS reads, MFMAs per chunk -- hipcc kept two B fragments live and exposed the LDS latency twice
-  //  per chunk: 720 cycles per 16-MFMA chunk with or without any memory traffic, tools/g1_timeline.py "dbg" 61 / 62.)
-  // The queue in front of the loop is the steady state's: per step [fragments x NTW][wait][pieces x Q], the wait for chunk k leaves
-  // the (NS - 2) younger steps' requests in flight.
-  constexpr int NWAIT = (NS - 2) * (Q + NTW);
+  //     MFMAs of the later pixel blocks            +  the DMA pieces of chunk c + NS - 1 (into the slot chunk c - 1 has left: every wave
+  //                                                   has issued chunk c's first MFMAs, i.e. retired its reads of chunks < c)
+  // i.e. every LDS read is issued half a chunk of MFMAs before its use (MBW + H fragments live), and a chunk's requests are in flight
+  // for NS - 2 steps.  vmcnt retires in order, so the pieces cannot usefully run further ahead than the fragments: a wait for chunk
+  // k + 1's fragments is a wait for every piece requested before them.  Depth is bought with register sets (3 / 4 / 6; 8 measured level stand-alone and - 2 % inside the steps).
+  // (first version: wait, requests, LDS reads, MFMAs per chunk -- hipcc kept two B fragments live and exposed the LDS latency twice per
+  //  chunk.)
+  // The queue in front of the loop is the steady state's: per step [fragments x NTW][wait][pieces x Q], the wait for chunk k + 1 leaves
+  // the NS - 3 younger chunks' requests and the fragments just requested in flight.
+  constexpr int NWAIT = (NS - 3) * (Q + NTW) + NTW;
   constexpr int H = (MBW + 1) / 2;
 #pragma unroll
-  for (int c = 0; c < DX + 2 - NS; ++c) request_x(c, c);
-#pragma unroll
   for (int u = 0; u < NS - 1; ++u) {
-    request_w(u, u);
-    if (u < NS - 2) request_x(DX + 2 - NS + u, DX + 2 - NS + u);
+    request_w(u);
+    request_x(u);
   }
   GTL(1);
 
@@ -435,53 +438,34 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pipe(P1Args a) {
     for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const unsigned char* lrd = lds + (wr * MBW * 16 + j) * 64 + ((g ^ ((j >> 1) & 3)) << 4);
-  g1_wait<NWAIT, NTW>(wf[0]);            // chunk 0 has landed
+  g1_wait<(NS - 2) * (Q + NTW), NTW>(wf[0]);            // chunk 0 has landed
   GTL(2);
-  request_x(DX, DX);
   i32x4 bfa[H];                          // B fragments of the computing chunk's first H pixel blocks
 #pragma unroll
   for (int m = 0; m < H; ++m) bfa[m] = *reinterpret_cast<const i32x4*>(lrd + m * 16 * 64);
-  int slot = 0;                          // ring slot of the chunk that computes (wave-uniform)
-#ifdef SQDET_G1_TIMELINE
-  unsigned long long rg[3] = {0, 0, 0}, slast = clock64();   // "dbg" 71: shader cycles per step region (A first half, B wait, C rest)
-#endif
 #pragma unroll 1
   for (int c0 = 0; c0 < a.nchunk_pad; c0 += NS) {
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-      const int c = c0 + u;
       __builtin_amdgcn_sched_barrier(0);
-#ifdef SQDET_G1_TIMELINE
-      unsigned long long s0 = 0, s1 = 0, s2 = 0;
-      if (a.dbg == 71) { s0 = clock64(); rg[2] += s0 - slast; }
-#endif
       i32x4 bfb[MBW - H];
 #pragma unroll
-      for (int m = H; m < MBW; ++m) bfb[m - H] = *reinterpret_cast<const i32x4*>(lrd + slot * CH + m * 16 * 64);
-      request_w(c - 1 + NS, (u + NS - 1) % NS);
+      for (int m = H; m < MBW; ++m) bfb[m - H] = *reinterpret_cast<const i32x4*>(lrd + u * CH + m * 16 * 64);
+      request_w((u + NS - 1) % NS);
 #pragma unroll
       for (int m = 0; m < H; ++m)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], wf[u][t], bfa[m]);
       __builtin_amdgcn_sched_barrier(0);
-#ifdef SQDET_G1_TIMELINE
-      if (a.dbg == 71) s1 = clock64();
-#endif
       g1_wait<NWAIT, NTW>(wf[(u + 1) % NS]);       // chunk c + 1: mine by the wait, everybody's by the barrier
-#ifdef SQDET_G1_TIMELINE
-      if (a.dbg == 71) { s2 = clock64(); rg[0] += s1 - s0; rg[1] += s2 - s1; slast = s2; }
-#endif
-      const int snext = slot + 1 == R ? 0 : slot + 1;
 #pragma unroll
-      for (int m = 0; m < H; ++m) bfa[m] = *reinterpret_cast<const i32x4*>(lrd + snext * CH + m * 16 * 64);
+      for (int m = 0; m < H; ++m) bfa[m] = *reinterpret_cast<const i32x4*>(lrd + ((u + 1) % NS) * CH + m * 16 * 64);
       __builtin_amdgcn_sched_barrier(0);
-      // slot of chunk c - 1: every wave has issued chunk c's first MFMAs, i.e. retired its reads of chunks < c
-      request_x(c + 1 + DX, slot == 0 ? R - 1 : slot - 1);
+      request_x((u + NS - 1) % NS);
 #pragma unroll
       for (int m = H; m < MBW; ++m)
 #pragma unroll
         for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], wf[u][t], bfb[m - H]);
-      slot = snext;
     }
   }
   GTL(3);
@@ -575,7 +559,7 @@ void launch_p1(P1Args& a, hipStream_t st) {
   const int per_xcd = (a.ptiles + 7) / 8;
   const dim3 grid((unsigned)(per_xcd * a.grid_y * 8));
   constexpr int RPM = sizeof(T) == 2 ? (NTW + 1) / 2 : NTW;
-  size_t lds = (size_t)(P1Ring<16 * MBW * WR, NS>::DX + 2) * 16 * MBW * WR * 64;
+  size_t lds = (size_t)NS * 16 * MBW * WR * 64;
   const bool want_res = a.res_off >= 0, want_mask = a.mask_off >= 0;
   a.res_off = a.mask_off = -1;
   if (EPI && want_res) { a.res_off = (int)lds; lds += (size_t)4 * MBW * RPM * 1024; }
@@ -588,31 +572,43 @@ void launch_p1(P1Args& a, hipStream_t st) {
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
 }
 
+// (the six-set form exists for 64- and 128-pixel tiles with <= 4 pixel blocks and <= 4 cout tiles per wave: <= 256 registers,
+//  <= 48 KiB of ring)
 template <typename T, int MBW, int WR, int NS, bool EPI>
 bool dispatch_p1_ntw(P1Args& a, int ntw, hipStream_t st) {
-  switch (ntw) {
-    case 2: launch_p1<T, MBW, 2, WR, NS, EPI>(a, st); return true;
-    case 3: launch_p1<T, MBW, 3, WR, NS, EPI>(a, st); return true;
-    case 4: launch_p1<T, MBW, 4, WR, NS, EPI>(a, st); return true;
-    case 5: if constexpr (MBW <= 4) { launch_p1<T, MBW, 5, WR, NS, EPI>(a, st); return true; } return false;
-    default: return false;
+  constexpr bool deep = NS > 4;
+  if constexpr (deep && (MBW > 4 || MBW * WR > 8)) return false;
+  else {
+    switch (ntw) {
+      case 2: launch_p1<T, MBW, 2, WR, NS, EPI>(a, st); return true;
+      case 3: launch_p1<T, MBW, 3, WR, NS, EPI>(a, st); return true;
+      case 4: launch_p1<T, MBW, 4, WR, NS, EPI>(a, st); return true;
+      case 5: if constexpr (MBW <= 4 && !deep) { launch_p1<T, MBW, 5, WR, NS, EPI>(a, st); return true; } return false;
+      default: return false;
+    }
   }
 }
 
 template <typename T, int NS, bool EPI>
 bool dispatch_p1_geo(P1Args& a, int mbw, int wr, int ntw, hipStream_t st) {
-  if (wr == 1) {
-    if constexpr (!EPI) { if (mbw == 8) return dispatch_p1_ntw<T, 8, 1, NS, EPI>(a, ntw, st); }
-    return dispatch_p1_ntw<T, 4, 1, NS, EPI>(a, ntw, st);
-  }
+  if (wr == 1) return mbw == 8 ? dispatch_p1_ntw<T, 8, 1, NS, EPI>(a, ntw, st) : dispatch_p1_ntw<T, 4, 1, NS, EPI>(a, ntw, st);
   if (wr == 2) return mbw == 4 ? dispatch_p1_ntw<T, 4, 2, NS, EPI>(a, ntw, st) : dispatch_p1_ntw<T, 2, 2, NS, EPI>(a, ntw, st);
   return mbw == 4 ? dispatch_p1_ntw<T, 4, 4, NS, EPI>(a, ntw, st) : dispatch_p1_ntw<T, 2, 4, NS, EPI>(a, ntw, st);
 }
 
+template <typename T, bool EPI>
+bool dispatch_p1_ns(P1Args& a, int mbw, int wr, int ntw, int ns, hipStream_t st) {
+  switch (ns) {
+    case 3: return dispatch_p1_geo<T, 3, EPI>(a, mbw, wr, ntw, st);
+    case 4: return dispatch_p1_geo<T, 4, EPI>(a, mbw, wr, ntw, st);
+    case 6: return dispatch_p1_geo<T, 6, EPI>(a, mbw, wr, ntw, st);
+    default: return false;
+  }
+}
+
 template <typename T>
 bool dispatch_p1(P1Args& a, int mbw, int wr, int ntw, int ns, bool epi, hipStream_t st) {
-  if (epi) return ns == 4 ? dispatch_p1_geo<T, 4, true>(a, mbw, wr, ntw, st) : dispatch_p1_geo<T, 3, true>(a, mbw, wr, ntw, st);
-  return ns == 4 ? dispatch_p1_geo<T, 4, false>(a, mbw, wr, ntw, st) : dispatch_p1_geo<T, 3, false>(a, mbw, wr, ntw, st);
+  return epi ? dispatch_p1_ns<T, true>(a, mbw, wr, ntw, ns, st) : dispatch_p1_ns<T, false>(a, mbw, wr, ntw, ns, st);
 }
 
 }  // namespace
@@ -640,35 +636,50 @@ int conv1x1_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
   auto wgs = [&](int m) { return (long)((c.P + 16 * m * wr - 1) / (16 * m * wr)) * a.grid_y; };
   if (wgs(mbw) < 768 || (wr == 1 && ntw == 5)) mbw /= 2;
   a.ptiles = (c.P + 16 * mbw * wr - 1) / (16 * mbw * wr);
-  // the pipelined form (conv1x1_pipe) for 3..5 cout tiles per wave; "dbg" 57: conv1x1_tile for everything (A/B)
+  // The pipelined form (conv1x1_pipe) unless "dbg" 57 (conv1x1_tile for everything: A/B) or a tensor is beyond the 2 GiB of a buffer
+  // offset.  Its layout -- measured inside the ResNet50 training step and the SqueezeDet+ serving step (profiles/r06_ab_g1_layout.txt),
+  // where the inputs come from the Infinity Cache, not on cold stand-alone launches:
+  //   * TWO cout tiles per wave wherever the packed group splits evenly (twice the workgroups, lighter waves: + 2-3 % per step);
+  //   * 128-pixel tiles (8 pixel blocks per wave) in the four-slice layout while that leaves >= 200 workgroups (half the weight
+  //     traffic per MFMA: + 3 % on SqueezeDet+), 64-pixel tiles otherwise and in the residual / mask forms beyond 64 KiB of LDS;
+  //   * four register sets where K is a multiple of four chunks, else six, else three (eight were level stand-alone, - 2 % in-step).
   {
     const size_t xb = (size_t)c.N * c.H * c.W * c.x_cstride * esz, yb = (size_t)c.P * c.y_cstride * esz;
-    if ((ntw >= 3 || tune(TUNE_G1_NTW) == 2) && xb < (1ull << 31) && yb < (1ull << 31) && tune(TUNE_DBG) != 57) {
+    if (xb < (1ull << 31) && yb < (1ull << 31) && tune(TUNE_DBG) != 57) {
       const bool epi = c.accum || c.relu_of;
-      int pm = mbw, pw = wr, pn = ntw;
+      int pn = g.nt % 2 == 0 ? 2 : g.nt;
       if (tune(TUNE_G1_NTW) > 0 && g.nt % tune(TUNE_G1_NTW) == 0) pn = tune(TUNE_G1_NTW);
       const int pslices = g.ngroups * (g.nt / pn);
+      int pw = pslices >= 4 ? 1 : pslices >= 2 ? 2 : 4;
       if (tune(TUNE_G1_WR) > 0) pw = tune(TUNE_G1_WR);
+      const int pgy = (pslices + 4 / pw - 1) / (4 / pw);
+      auto pwgs = [&](int m) { return (long)((c.P + 16 * m * pw - 1) / (16 * m * pw)) * pgy; };
+      int pm = pw == 1 ? (pwgs(8) >= 200 && pn <= 4 ? 8 : 4) : (pwgs(4) >= 768 ? 4 : 2);
       if (tune(TUNE_G1_MBW) > 0) pm = tune(TUNE_G1_MBW);
       if (pw == 1 && pm == 2) pm = 4;
-      if (pw != 1 && pm == 8) pm = 4;
-      if (epi && pw == 1 && pm == 8) pm = 4;      // the EPI form stages MBW x NTW KiB per wave and tensor: 64-pixel tiles
-      P1Args p;
-      p.c = c; p.nt_pack = a.nt_pack; p.slices = pslices; p.pieces = a.pieces;
-      p.grid_y = (pslices + 4 / pw - 1) / (4 / pw);
-      p.ptiles = (c.P + 16 * pm * pw - 1) / (16 * pm * pw);
-      p.x_bytes = (unsigned)xb; p.y_bytes = (unsigned)yb;
-      p.dbg = tune(TUNE_DBG);
-      p.res_off = c.accum ? 0 : -1; p.mask_off = c.relu_of ? 0 : -1;     // (launch_p1 turns the requests into LDS offsets)
-      // ring depth = register sets = chunks per unrolled trip: the one that walks K in whole trips (4 when both do)
-      const int pad4 = (g.nchunk + 3) / 4 * 4, pad3 = (g.nchunk + 2) / 3 * 3;
-      const int ns = pad4 <= pad3 ? 4 : 3;
-      p.nchunk_pad = ns == 4 ? pad4 : pad3;
-      const bool okp = dtype == SQDET_F16 ? dispatch_p1<f16>(p, pm, pw, pn, ns, epi, st) : dispatch_p1<float>(p, pm, pw, pn, ns, epi, st);
-      if (okp) {
-        SQDET_CHECK_HIP(hipGetLastError());
-        *handled = true;
-        return SQDET_OK;
+      if ((pw != 1 || pn > 4) && pm == 8) pm = 4;
+      int ns = g.nchunk % 4 == 0 ? 4 : g.nchunk % 6 == 0 ? 6 : g.nchunk % 3 == 0 ? 3 : ((g.nchunk + 3) / 4 * 4 <= (g.nchunk + 2) / 3 * 3 ? 4 : 3);
+      if (tune(TUNE_G1_NS) > 0) ns = tune(TUNE_G1_NS);
+      if (ns != 3 && ns != 4 && ns != 6) ns = 4;
+      if (ns == 6 && (pm > 4 || pm * pw > 8 || pn > 4)) ns = 3;                      // (the six-set form: <= 256 registers, <= 48 KiB of ring)
+      const int rpm = esz == 2 ? (pn + 1) / 2 : pn;
+      auto lds_need = [&](int m) { return (size_t)ns * 16 * m * pw * 64 + (size_t)((c.accum ? 1 : 0) + (c.relu_of ? 1 : 0)) * 4 * m * rpm * 1024; };
+      if (epi && pm == 8 && lds_need(8) > 64 * 1024) pm = 4;
+      if (lds_need(pm) <= 160 * 1024) {
+        P1Args p;
+        p.c = c; p.nt_pack = g.nt; p.slices = pslices; p.pieces = a.pieces;
+        p.grid_y = pgy;
+        p.ptiles = (c.P + 16 * pm * pw - 1) / (16 * pm * pw);
+        p.x_bytes = (unsigned)xb; p.y_bytes = (unsigned)yb;
+        p.dbg = tune(TUNE_DBG);
+        p.res_off = c.accum ? 0 : -1; p.mask_off = c.relu_of ? 0 : -1;     // (launch_p1 turns the requests into LDS offsets)
+        p.nchunk_pad = (g.nchunk + ns - 1) / ns * ns;
+        const bool okp = dtype == SQDET_F16 ? dispatch_p1<f16>(p, pm, pw, pn, ns, epi, st) : dispatch_p1<float>(p, pm, pw, pn, ns, epi, st);
+        if (okp) {
+          SQDET_CHECK_HIP(hipGetLastError());
+          *handled = true;
+          return SQDET_OK;
+        }
       }
     }
   }
