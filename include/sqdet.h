@@ -88,6 +88,14 @@ int sqdet_convdet_scores_supported(int cin, int anchors_per_grid, int classes, i
 int sqdet_conv2d_add_nhwc_fwd(const void* x, const void* w_packed, const float* bias, void* y_inout,
                               int n, int h, int w, int cin, int cout, int k, int stride, int pad_mode, int relu,
                               int dtype, int y_cstride, int y_coffset, sqdet_stream_t stream);
+/* The same with the shortcut in a tensor of its own (rows of y_cstride channels, like y), left untouched:
+ *   y = relu?(conv2d(x, W) + b + residual)
+ * -- the training forward keeps every block input for the backward pass (nn_skeleton.py:329-361 differentiates through
+ * resnet50_convDet.py:55), so the sum must not overwrite the shortcut.  1x1 convs read the residual tile in their epilogue
+ * (conv1x1_pipe); other shapes copy it into y first. */
+int sqdet_conv2d_res_nhwc_fwd(const void* x, const void* w_packed, const float* bias, const void* residual, void* y,
+                              int n, int h, int w, int cin, int cout, int k, int stride, int pad_mode, int relu,
+                              int dtype, int y_cstride, int y_coffset, sqdet_stream_t stream);
 
 /* ------------------------------------------------------------- batch norm --
  * Replaces the frozen-statistics batch norm of ModelSkeleton._conv_bn_layer (nn_skeleton.py:374-468:

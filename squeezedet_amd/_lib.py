@@ -27,6 +27,7 @@ SIGNATURES = {
     "sqdet_conv_pack_weights": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "sqdet_conv2d_nhwc_fwd": (ci, [vp, vp, vp, vp] + [ci] * 12 + [vp]),
     "sqdet_conv2d_add_nhwc_fwd": (ci, [vp, vp, vp, vp] + [ci] * 12 + [vp]),
+    "sqdet_conv2d_res_nhwc_fwd": (ci, [vp, vp, vp, vp, vp] + [ci] * 12 + [vp]),
     "sqdet_fold_batchnorm": (ci, [vp] * 6 + [cf, vp, vp, ci, ci, ci, vp]),
     "sqdet_fold_batchnorm_bwd_workspace_bytes": (sz, [ci] * 3),
     "sqdet_fold_batchnorm_bwd": (ci, [vp] * 7 + [cf, vp, vp, vp, vp, ci, ci, ci, vp]),

@@ -287,6 +287,9 @@ int conv2d_launch_ex(const void* x, const void* w_packed, const float* bias, voi
 int conv2d_launch_masked(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
                          int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
                          int x_cstride, int x_coffset, int accum, const void* relu_of, hipStream_t st);
+int conv2d_launch_res(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
+                      int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
+                      int x_cstride, int x_coffset, int accum, const void* relu_of, const void* res, hipStream_t st);
 
 int conv2d_launch(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
                   int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
@@ -309,7 +312,16 @@ int conv2d_launch_ex(const void* x, const void* w_packed, const float* bias, voi
 int conv2d_launch_masked(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
                          int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
                          int x_cstride, int x_coffset, int accum, const void* relu_of, hipStream_t st) {
+  return conv2d_launch_res(x, w_packed, bias, y, n, h, w, cin, cout, k, stride, pad_mode, relu, dtype, y_cstride, y_coffset, x_cstride,
+                           x_coffset, accum, relu_of, nullptr, st);
+}
+
+// res != NULL (with accum): y = conv(x) + res instead of y += conv(x); res has y's layout (whole rows of y_cstride channels)
+int conv2d_launch_res(const void* x, const void* w_packed, const float* bias, void* y, int n, int h, int w, int cin,
+                      int cout, int k, int stride, int pad_mode, int relu, int dtype, int y_cstride, int y_coffset,
+                      int x_cstride, int x_coffset, int accum, const void* relu_of, const void* res, hipStream_t st) {
   SQDET_REQUIRE(x && w_packed && y, "conv2d: null pointer");  // bias == NULL means no bias (generic kernel)
+  SQDET_REQUIRE(!res || accum, "conv2d: a residual tensor needs the accumulate form");
   const int kg_ = dtype == SQDET_F16 ? 8 : 4;
   SQDET_UNSUPPORTED((x_cstride != cin || x_coffset != 0) &&
                         (x_cstride % kg_ != 0 || x_coffset % kg_ != 0 || x_coffset < 0 || x_coffset + cin > x_cstride),
@@ -339,11 +351,20 @@ int conv2d_launch_masked(const void* x, const void* w_packed, const float* bias,
   a.y_cstride = y_cstride; a.y_coffset = y_coffset; a.relu = relu;
   a.x_cstride = x_cstride; a.x_coffset = x_coffset; a.accum = accum;
   a.relu_of = relu_of;
+  a.res = res == y ? nullptr : res;
   a.scores = nullptr; a.score_apg = 0; a.score_classes = 0;
   const bool plain = x_cstride == cin && x_coffset == 0 && !accum && bias != nullptr && !relu_of;
   SQDET_UNSUPPORTED(!plain && g.gather, "conv2d: channel-sliced / accumulating convs need Cin %% %d == 0", kg_);
   bool handled = false;
   int rc = SQDET_OK;
+  if (a.res) {                // only conv1x1_pipe reads the residual from a tensor of its own: everybody else adds into a copy of it
+    if (!g.gather) {
+      rc = conv1x1_tile_launch(a, g, dtype, st, &handled);
+      if (rc != SQDET_OK || handled) return rc;
+    }
+    SQDET_CHECK_HIP(hipMemcpyAsync(y, a.res, (size_t)P * y_cstride * dtype_size(dtype), hipMemcpyDeviceToDevice, st));
+    a.res = nullptr;
+  }
   if (plain || !g.gather) {   // (the tile kernels also take channel-sliced inputs, no bias and y += : the backward-data convs)
     rc = conv3x3_tile_launch(a, g, dtype, st, &handled);
     if (rc != SQDET_OK || handled) return rc;
@@ -387,7 +408,7 @@ int convdet_scored_launch(const void* x, const void* w_packed, const float* bias
   a.P = (int)P; a.ntiles = 0;
   a.nchunk = g.nchunk; a.steps = g.steps; a.ngroups = g.ngroups;
   a.y_cstride = cout; a.y_coffset = 0; a.relu = 0;
-  a.x_cstride = cin; a.x_coffset = 0; a.accum = 0; a.relu_of = nullptr;
+  a.x_cstride = cin; a.x_coffset = 0; a.accum = 0; a.relu_of = nullptr; a.res = nullptr;
   a.scores = scores; a.score_apg = apg; a.score_classes = classes;
   bool handled = false;
   const int rc = conv3x3_tile_launch(a, g, dtype, st, &handled);
@@ -474,6 +495,14 @@ extern "C" int sqdet_convdet_scores_supported(int cin, int anchors_per_grid, int
   if (conv_algo() != 0 || !convdet_score_supported(cout, anchors_per_grid, classes, dtype)) return 0;
   const ConvGeom g = conv_geom(3, cin, cout, dtype);
   return (!g.gather && g.nt == 5 && g.ngroups == 1 && g.nchunk >= 8 && g.nchunk % 4 == 0) ? 1 : 0;
+}
+
+extern "C" int sqdet_conv2d_res_nhwc_fwd(const void* x, const void* w_packed, const float* bias, const void* residual, void* y, int n,
+                                         int h, int w, int cin, int cout, int k, int stride, int pad_mode, int relu, int dtype,
+                                         int y_cstride, int y_coffset, sqdet_stream_t stream) {
+  SQDET_REQUIRE(residual, "conv2d_res: null residual");
+  return conv2d_launch_res(x, w_packed, bias, y, n, h, w, cin, cout, k, stride, pad_mode, relu, dtype, y_cstride, y_coffset, cin, 0, 1,
+                           nullptr, residual, as_stream(stream));
 }
 
 extern "C" int sqdet_conv2d_add_nhwc_fwd(const void* x, const void* w_packed, const float* bias, void* y_inout, int n,

@@ -37,6 +37,10 @@ struct ConvArgs {
   // x_cstride channels wide, and the result may be ADDED to y (backward-data of a fire module:
   // d(squeeze) = dgrad_1x1(dY[:, :e1]) + dgrad_3x3(dY[:, e1:])).
   int x_cstride, x_coffset, accum;
+  // accum only: the tensor the result is added to when it is NOT y itself (same layout as y; NULL = y).  ResNet50's training forward
+  // keeps the shortcut for the backward pass: y = relu(conv(x) + b + res) without a copy of the shortcut first.  Honoured by
+  // conv1x1_pipe; every other kernel gets a copy res -> y in front (conv2d_launch_res).
+  const void* res;
   // backward-data only: the result is the gradient w.r.t. a ReLU OUTPUT r (same layout as y); it is zeroed where r <= 0 --
   // the ReLU backward of the layer below, taken in this conv's epilogue instead of a separate pass over the tensor
   const void* relu_of;

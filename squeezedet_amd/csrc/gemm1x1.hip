@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pipe(P1Args a) {
   asm volatile("" ::"s"(a.ptiles), "s"(a.grid_y), "s"(a.slices), "s"(a.nt_pack), "s"(a.pieces), "s"(a.nchunk_pad), "s"(a.x_bytes),
                "s"(a.y_bytes), "s"(a.res_off), "s"(a.mask_off), "s"(a.c.nchunk), "s"(a.c.steps), "s"(a.c.P), "s"(a.c.Cout),
                "s"(a.c.stride), "s"(a.c.x_cstride), "s"(a.c.x_coffset), "s"(a.c.y_cstride), "s"(a.c.y_coffset));
-  asm volatile("" ::"s"(a.c.x), "s"(a.c.wp), "s"(a.c.bias), "s"(a.c.y), "s"(a.c.relu_of), "s"(a.c.relu));
+  asm volatile("" ::"s"(a.c.x), "s"(a.c.wp), "s"(a.c.bias), "s"(a.c.y), "s"(a.c.relu_of), "s"(a.c.relu), "s"(a.c.res));
 #ifdef SQDET_G1_TIMELINE
   const unsigned long long clk0 = clock64();   // shader cycles: gtl[7] = cycles between here and the last stamp (effective clock)
 #endif
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pipe(P1Args a) {
   const unsigned ycol = (unsigned)((a.c.y_coffset + cb) * esz);
   const int pe0 = p0 + wr * MBW * 16 + j;                        // this lane's pixel of block m: pe0 + 16 m
   if constexpr (EPI) {
-    const unsigned long long yaddr = (unsigned long long)(uintptr_t)a.c.y, maddr = (unsigned long long)(uintptr_t)a.c.relu_of;
+    const unsigned long long yaddr = (unsigned long long)(uintptr_t)(a.c.res ? a.c.res : a.c.y), maddr = (unsigned long long)(uintptr_t)a.c.relu_of;
     const i32x4 ry = {(int)(unsigned)yaddr, (int)(unsigned)((yaddr >> 32) & 0xffffu), (int)a.y_bytes, 0x00020000};
     const i32x4 rm = {(int)(unsigned)maddr, (int)(unsigned)((maddr >> 32) & 0xffffu), (int)a.y_bytes, 0x00020000};
 #pragma unroll
@@ -683,6 +683,7 @@ int conv1x1_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
       }
     }
   }
+  if (c.res) return SQDET_OK;            // (conv1x1_tile adds into y itself: the caller copies the residual first)
   a.stage_chunks = g.nchunk < 4 ? g.nchunk : 4;
   const size_t lds = (size_t)a.stage_chunks * 16 * mbw * wr * 64;   // <= 64 KiB
   const bool ok = dtype == SQDET_F16 ? dispatch_g1<f16>(a, mbw, wr, ntw, lds, st) : dispatch_g1<float>(a, mbw, wr, ntw, lds, st);

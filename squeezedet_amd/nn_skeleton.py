@@ -361,9 +361,11 @@ class ModelSkeleton:
                 sv = self._eval(shortcut, env, use_plan)
                 in_place = (shortcut not in self._fetching and shortcut.op != "placeholder" and
                             all(r in env for r in shortcut.readers if r is not node))
-                out = sv if in_place else sv.clone()
                 pk, bf = self._folded_conv(branch.name, branch.attrs["with_bias"])
-                v = ops.conv2d_nhwc(bx, pk, bf, branch.attrs["stride"], branch.attrs["padding"], True, out=out, accumulate=True)
+                if in_place:
+                    v = ops.conv2d_nhwc(bx, pk, bf, branch.attrs["stride"], branch.attrs["padding"], True, out=sv, accumulate=True)
+                else:       # the shortcut has other readers: read as a residual tensor, not copied
+                    v = ops.conv2d_nhwc(bx, pk, bf, branch.attrs["stride"], branch.attrs["padding"], True, residual=sv)
             else:
                 a = self._eval(shortcut, env, use_plan)
                 b = self._eval(branch, env, use_plan)

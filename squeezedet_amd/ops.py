@@ -64,12 +64,27 @@ def fold_batchnorm(w_hwio, conv_bias, gamma, beta, mean, var, eps):
     return wf, bf
 
 
-def conv2d_nhwc(x, packed, bias, stride=1, padding="SAME", relu=True, out=None, out_coffset=0, accumulate=False):
+def conv2d_nhwc(x, packed, bias, stride=1, padding="SAME", relu=True, out=None, out_coffset=0, accumulate=False, residual=None):
     """relu?(conv2d(x, W) + b) with TF SAME/VALID semantics (nn_skeleton.py:471-563).
     x: [N,H,W,Cin] f16/f32 NHWC; packed: PackedConv; bias: f32 [Cout].  ``out`` (optional)
     is a [N,Ho,Wo,Ctot] tensor whose channels [out_coffset, out_coffset+Cout) are written
     (fire-module concat without a concat pass).  accumulate=True: out = relu?(conv + b + out), the
-    residual add of a ResNet bottleneck (resnet50_convDet.py:55) done in the conv epilogue."""
+    residual add of a ResNet bottleneck (resnet50_convDet.py:55) done in the conv epilogue;
+    residual=<tensor shaped like out>: out = relu?(conv + b + residual), the shortcut left untouched."""
+    if residual is not None:
+        n, h, w, cin = [int(v) for v in x.shape]
+        ho, wo = _out_size(h, packed.k, stride, padding), _out_size(w, packed.k, stride, padding)
+        if cin != packed.cin or x.dtype != packed.dtype:
+            raise _lib.SqdetError("conv2d_nhwc: input does not match the packed kernel")
+        if out is None:
+            out = torch.empty((n, ho, wo, packed.cout), dtype=x.dtype, device=x.device)
+            out_coffset = 0
+        if tuple(out.shape[:3]) != (n, ho, wo) or out.dtype != x.dtype or tuple(residual.shape) != tuple(out.shape) or residual.dtype != out.dtype:
+            raise _lib.SqdetError("conv2d_nhwc: `residual` must have the shape and dtype of `out`")
+        check(lib().sqdet_conv2d_res_nhwc_fwd(_dev(x, "x"), _dev(packed.data, "packed"), _dev(bias, "bias", torch.float32), _dev(residual, "residual"),
+                                              _dev(out, "out"), n, h, w, cin, packed.cout, packed.k, int(stride), pad_code(padding), int(bool(relu)),
+                                              dtype_code(x.dtype), int(out.shape[3]), int(out_coffset), stream_ptr()), "sqdet_conv2d_res_nhwc_fwd")
+        return out
     n, h, w, cin = [int(v) for v in x.shape]
     if cin != packed.cin or x.dtype != packed.dtype:
         raise _lib.SqdetError("conv2d_nhwc: input [%d ch, %s] does not match packed kernel [%d ch, %s]"

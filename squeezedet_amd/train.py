@@ -642,9 +642,10 @@ class ResNet50ConvDetTrainer(_TrainerBase):
                 if br in val:
                     val[n] = ops.add_relu(val[sc], val[br])
                 else:
-                    out = val[sc].clone()         # the shortcut is branch2a's input: its value is needed by the backward
+                    # (the shortcut is branch2a's input: its value is needed by the backward -- the conv reads it as a residual tensor
+                    #  of its own instead of adding into a copy)
                     val[n] = ops.conv2d_nhwc(val[br.inputs[0]], pk[br.name], pbias[br.name], br.attrs["stride"],
-                                             br.attrs["padding"], True, out=out, accumulate=True)
+                                             br.attrs["padding"], True, residual=val[sc])
             elif n.op == "dropout":
                 x = val[n.inputs[0]]
                 keep = n.attrs["keep_prob"]

@@ -59,6 +59,14 @@ def test_conv_residual_add_epilogue(dtype, shape):
                         accumulate=True)
     assert y.data_ptr() == out.data_ptr()
     _close(y, ref, dtype, "conv+add+relu")
+    # sqdet_conv2d_res_nhwc_fwd: the shortcut in a tensor of its own, left untouched -- bitwise the in-place form's result (1x1: the
+    # pipelined GEMM tile reads the residual tile by LDS-DMA; 3x3: copy + add)
+    res = sc.to(DEV, dtype).contiguous()
+    keep = res.clone()
+    y2 = ops.conv2d_nhwc(x.to(DEV, dtype), ops.pack_conv_weights(wt.to(DEV), dtype), b.to(DEV), 1, "SAME", True, residual=res)
+    torch.cuda.synchronize()
+    assert y2.data_ptr() != res.data_ptr() and torch.equal(res, keep), "the residual tensor was modified"
+    assert torch.equal(y2, y), "residual form differs from the in-place form"
 
 
 def _model(dtype, batch, size, seed=0):
