@@ -106,12 +106,24 @@ def _dist_on():
     return dist.is_available() and dist.is_initialized()
 
 
-def max_over_ranks(value, world, device):
-    """Timing rule of the bench contract: the job's time is the MAX over ranks."""
+_RANK_SECONDS = None     # every rank's elapsed seconds of the last timed region (rank order), for the line's "rank_ms_per_step"
+
+
+def max_over_ranks(value, world, device, own=None):
+    """Timing rule of the bench contract: the job's time is the MAX over ranks.  `own` = this rank's seconds up to its own device
+    synchronisation, BEFORE the closing barrier: kept for every rank (all-gather) -- the line reports their min / max, so a straggling
+    rank or GPU shows up in the record instead of hiding inside the maximum."""
+    global _RANK_SECONDS
+    own = value if own is None else own
     if not _dist_on():
+        _RANK_SECONDS = [float(own)]
         return value
     import torch.distributed as dist
     t = torch.tensor([value], dtype=torch.float64, device=device)
+    o = torch.tensor([own], dtype=torch.float64, device=device)
+    every = [torch.zeros_like(o) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, o)
+    _RANK_SECONDS = [float(e.item()) for e in every]
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -562,10 +574,11 @@ def run_infer(args, rank, local_rank, world, device):
     model.flush_pipeline()                   # the last step's decode + filter + row copy
     t_issued = time.perf_counter() - t0      # host side done enqueueing (diagnostic: host-bound if ~ elapsed)
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0           # this rank's own time (before the barrier): the line's rank_ms_per_step
     barrier(world, device)
     elapsed = time.perf_counter() - t0
     clocks["after"] = gpu_state(local_rank)
-    elapsed = max_over_ranks(elapsed, world, device)
+    elapsed = max_over_ranks(elapsed, world, device, own)
     ranks_seen, devices = rank_census(rank, local_rank, world, device)
 
     probe_ms = plan.read_probe(args.steps)
@@ -574,18 +587,25 @@ def run_infer(args, rank, local_rank, world, device):
     if lanes >= 2 and os.environ.get("SQDET_BENCH_NO_PROBE") != "1":
         # the SAME dominant launch with ONE forward in flight (untimed second pass of the same K steps): under two lanes a launch
         # shares the chip with the other lane's launches, so its wall-clock duration above is not the time the kernel needs
+        # (two sub-passes: the step time WITHOUT the probe's event pair in the stream -- the one-lane serving loop itself, each call's
+        #  decode + filter riding in the next forward -- then the probed launch; round-5 review: the probed, flushed pass read 0.54 ms
+        #  where SQDET_SERVE_LANES=1 runs 0.44)
         model.serve_lanes = 1
-        for i in range(4):
+        for i in range(8):
             step(i)
         model.flush_pipeline()
         torch.cuda.synchronize()
-        plan.set_probe(dom, args.steps)
         t1 = time.perf_counter()
         for i in range(args.steps):
             step(i)
         model.flush_pipeline()
         torch.cuda.synchronize()
         single_step_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        plan.set_probe(dom, args.steps)
+        for i in range(args.steps):
+            step(i)
+        model.flush_pipeline()
+        torch.cuda.synchronize()
         sp = plan.read_probe(args.steps)
         plan.set_probe(-1, 0)
         model.serve_lanes = lanes
@@ -817,10 +837,11 @@ def run_train(args, rank, local_rank, world, device):
     t_issued = time.perf_counter() - t0
     torch.cuda.synchronize()
     tr.flush()
+    own = time.perf_counter() - t0
     barrier(world, device)
     elapsed = time.perf_counter() - t0
     clocks["after"] = gpu_state(local_rank)
-    elapsed = max_over_ranks(elapsed, world, device)
+    elapsed = max_over_ranks(elapsed, world, device, own)
     ranks_seen, devices = rank_census(rank, local_rank, world, device)
     if rank != 0:
         return None
@@ -869,6 +890,10 @@ def result_head(args, value, world, elapsed, ranks_seen=1, devices=None, clocks=
         "vs_baseline": None,
         "dtype": "f16" if args.dtype == "fp16" else "f32",
         "data": "reference data/sample.png (tests/golden/sample.png), random-init weights" if getattr(args, "sample", False) else "synthetic",
+        # per-rank step time (the timed region of every rank / K): ms_per_step above is the max; a wide min..max = a straggler
+        "rank_ms_per_step": None if not _RANK_SECONDS else {"min": round(min(_RANK_SECONDS) / args.steps * 1e3, 4),
+                                                            "max": round(max(_RANK_SECONDS) / args.steps * 1e3, 4),
+                                                            "per_rank": [round(v / args.steps * 1e3, 4) for v in _RANK_SECONDS]},
         "ranks_seen": ranks_seen,          # dist.get_world_size() as the process group reports it (== n_gpus or the run is void)
         "devices": devices,                # one entry per rank: device index, name, uuid / PCI id
         "clocks": clocks,                  # rank 0's GPU right before / after the timed region (amdsmi)
@@ -926,9 +951,10 @@ def run_dry(args, rank, local_rank, world, device):
     for i in range(args.steps):
         step(i)
     time.sleep(0.01 * (1 + rank))                      # ranks finish at different times: the MAX must win
+    own = time.perf_counter() - t0
     barrier(world, device)
     elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, world, device)
+    elapsed = max_over_ranks(elapsed, world, device, own)
     ranks_seen, devices = rank_census(rank, local_rank, world, device)
     if rank != 0:
         return None

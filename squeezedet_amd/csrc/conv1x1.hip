@@ -220,17 +220,19 @@ __global__ __launch_bounds__(256) void conv1x1_stream(C1Args a) {
 // resident 256-thread workgroups per CU of one instantiation (registers decide), asked once per device
 template <typename T, int NCH, int NT, int MT, bool PERM>
 static int c1_blocks_per_cu() {
-  static int cached[64] = {};
+  static std::atomic<int> cached[64];      // (relaxed: racing first launches of two host threads both ask and store the same number)
   const int d = current_device() & 63;
-  if (cached[d] == 0) {
+  int v = cached[d].load(std::memory_order_relaxed);
+  if (v == 0) {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&conv1x1_stream<T, NCH, NT, MT, PERM>), 256, 0) != hipSuccess || n < 1) {
       (void)hipGetLastError();
       n = 4;
     }
-    cached[d] = n > 8 ? 8 : n;
+    v = n > 8 ? 8 : n;
+    cached[d].store(v, std::memory_order_relaxed);
   }
-  return cached[d];
+  return v;
 }
 
 template <typename T, int NCH, int NT, int MT>

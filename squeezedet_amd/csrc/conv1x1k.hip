@@ -164,19 +164,26 @@ bool launch_k1(K1Args& a, int ngroups, hipStream_t st) {
   // cout groups
   // (asked once per LDS size and instantiation: the query costs tens of microseconds of host time)
   // (keyed by LDS size and device: slot key = lds * 64 + device + 1)
-  static size_t cached_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  static int cached_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const size_t lds_key = lds * 64 + (size_t)(current_device() & 63) + 1;
+  // (one 64-bit word per slot = key << 8 | answer, relaxed atomics: host threads may launch concurrently; a full table evicts round-robin)
+  static std::atomic<uint64_t> slots[8];
+  static std::atomic<unsigned> victim{0};
+  const uint64_t lds_key = (uint64_t)lds * 64 + (uint64_t)(current_device() & 63) + 1;
   int per_cu = 0;
-  for (int i = 0; i < 8; ++i)
-    if (cached_n[i] > 0 && cached_lds[i] == lds_key) per_cu = cached_n[i];
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t v = slots[i].load(std::memory_order_relaxed);
+    if ((v >> 8) == lds_key) per_cu = (int)(v & 0xff);
+  }
   if (per_cu == 0) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NWAVES * 64, lds) != hipSuccess || per_cu < 1) {
       (void)hipGetLastError();
       return false;
     }
-    for (int i = 0; i < 8; ++i)
-      if (cached_n[i] == 0) { cached_lds[i] = lds_key; cached_n[i] = per_cu; break; }
+    if (per_cu > 255) per_cu = 255;
+    int slot = -1;
+    for (int i = 0; i < 8 && slot < 0; ++i)
+      if (slots[i].load(std::memory_order_relaxed) == 0) slot = i;
+    if (slot < 0) slot = (int)(victim.fetch_add(1, std::memory_order_relaxed) & 7);
+    slots[slot].store(lds_key << 8 | (uint64_t)per_cu, std::memory_order_relaxed);
   }
   int wgs = cu_count() * per_cu / ngroups;
   const int need = (a.nblocks + NWAVES - 1) / NWAVES;
@@ -202,8 +209,9 @@ bool dispatch_k1(K1Args& a, int nt, int ngroups, hipStream_t st) {
 
 }  // namespace
 
-// Plain (no channel slice, no accumulate) 1x1 / stride-1 convs with 5..48 K chunks whose cout group's weights fit 152 KiB of LDS and
-// that have enough pixels to stream (>= 8192).  *handled = false: conv1x1_tile / the generic kernel take it.  ("dbg" 51 / 57: never)
+// Plain (no channel slice, no accumulate, no mask) REDUCING (Cin >= 2 Cout) 1x1 / stride-1 convs with 5..48 K chunks whose cout group's
+// weights fit 152 KiB of LDS and that have enough pixels to stream (>= 8192).  *handled = false: conv1x1_pipe / conv1x1_tile / the
+// generic kernel take it.  ("dbg" 51 / 57 / 61..79: never)
 int conv1x1_deepk_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStream_t st, bool* handled) {
   *handled = false;
   if (conv_algo() != 0 || tune(TUNE_DBG) == 51 || tune(TUNE_DBG) == 57 || (tune(TUNE_DBG) >= 61 && tune(TUNE_DBG) <= 79)) return SQDET_OK;

@@ -92,7 +92,8 @@ __device__ __forceinline__ void store_couts(T* dst, const f32x4 (&v)[NT], int nt
 // 1 = generic only (conv_direct / conv_gather).  Set from SQDET_CONV_ALGO=generic (tests, A/B).
 int conv_algo();
 // experiment knobs set through sqdet_set_option (0 = built-in heuristic)
-// fire_fuse: 0 heuristic, 1 always, 2 never; stem_algo: 0 phase kernel (stem4.hip), else persistent strip-lane kernel (stem3.hip), else strip kernel (in-register pool), whichever is eligible first; 3 skips the phase kernel; 2 strip kernel only
+// fire_fuse: 0 / 1 = a fire module is one fused launch wherever a fused kernel takes it (the default since round 5), 2 = never,
+// 10 = the round-1..4 rule (only maps of <= 100 k pixels); stem_algo: 0 phase kernel (stem4.hip), else persistent strip-lane kernel (stem3.hip), else strip kernel (in-register pool), whichever is eligible first; 3 skips the phase kernel; 2 strip kernel only
 // g1_wr / g1_mbw / g1_ntw: conv1x1_pipe's wave layout (waves along the pixel blocks: 1, 2, 4), pixel blocks per wave (2, 4, 8) and cout tiles per wave -- tools/g1_sweep.py
 enum { TUNE_C1_WAVES = 0, TUNE_C1_MT = 1, TUNE_C1_MIN_TILES = 2, TUNE_FIRE_FUSE = 3, TUNE_STEM_ALGO = 4, TUNE_DBG = 5, TUNE_G1_WR = 6, TUNE_G1_MBW = 7, TUNE_G1_NTW = 8, TUNE_G1_NS = 9 };
 int tune(int which);

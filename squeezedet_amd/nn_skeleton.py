@@ -598,8 +598,11 @@ class ModelSkeleton:
         if n < 1:
             raise SqdetError("detect_filter_pipelined: lanes must be >= 1, got %r" % (n,))
         if not defer or self.NATIVE_ARCH is None or n < 2:
-            if self._lanes is not None and defer:
-                self.flush_pipeline()                     # (the lane set may hold pending rows: carried out ahead of the single-lane call; the set is kept)
+            if self._lanes is not None and defer and any(l["pipe"] is not None and l["pipe"].get("pending") is not None for l in self._lanes):
+                # the lane set holds pending rows of earlier multi-lane calls: carried out ONCE, ahead of the first single-lane call (the
+                # set is kept).  The single-lane pipe's own pending job is left alone -- it rides in this call's forward as ever.
+                with torch.cuda.device(self.device):
+                    self._flush_lane_set(torch.cuda.current_stream())
             return None
         if self._lanes is None or len(self._lanes) != n:
             if self._lanes is not None:
@@ -618,16 +621,21 @@ class ModelSkeleton:
         read every returned row, device or pinned host."""
         with torch.cuda.device(self.device):
             cur = torch.cuda.current_stream()
-            if self._lanes is not None:
-                for lane in self._lanes:
-                    with torch.cuda.stream(lane["stream"]), self._lane_state(lane):
-                        self._flush_pipe(self._pipe)
-                    cur.wait_stream(lane["stream"])
-                    if lane["post_stream"] is not None:
-                        cur.wait_stream(lane["post_stream"])
+            self._flush_lane_set(cur)
             self._flush_pipe(getattr(self, "_pipe", None))
             if getattr(self, "post_stream", None) is not None:
                 cur.wait_stream(self.post_stream)
+
+    def _flush_lane_set(self, cur):
+        """The serving lanes' half of flush_pipeline: every lane's pending side work enqueued on its own stream, `cur` waits for it."""
+        if self._lanes is None:
+            return
+        for lane in self._lanes:
+            with torch.cuda.stream(lane["stream"]), self._lane_state(lane):
+                self._flush_pipe(self._pipe)
+            cur.wait_stream(lane["stream"])
+            if lane["post_stream"] is not None:
+                cur.wait_stream(lane["post_stream"])
 
     def _flush_pipe(self, pipe):
         if pipe is not None and pipe.get("pending") is not None:

@@ -895,7 +895,8 @@ def calib_mfma_variant(device, shape, waves_per_simd, zero_operands, iters=None,
     nacc = 8 if shape == 0 else 4
     if iters is None:
         iters = (8192 * 2 // waves_per_simd) if shape == 0 else (8192 // waves_per_simd)       # ~2 ms at the guide's rate
-    cap = 256 * 8 * 8
+    # (the kernel's grid is cu_count() x waves_per_simd workgroups: sized from THIS device's compute units, not an MI355X's 256)
+    cap = max(256, int(torch.cuda.get_device_properties(device).multi_processor_count)) * 8 * 8
     scratch = torch.empty(cap * 256 // 8, dtype=torch.float32, device=device)
     ticks = torch.zeros(cap * 2 // 8 * 8, dtype=torch.int64, device=device)
     flops, wgs = C.c_double(0.0), C.c_int(0)

@@ -210,6 +210,21 @@ def test_bench_self_launches_n_ranks_dry_run():
     assert rc == 0 and res["dry_run"] is True and res["value"] is None
     assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["config"]["global_batch"] == 64
     assert sorted(d["rank"] for d in res["devices"]) == [0, 1] and len({d["pid"] for d in res["devices"]}) == 2
+    # per-rank step times beside the max-reduce: rank 1 sleeps longer than rank 0 in the dry run, and the line's time is the maximum
+    rk = res["rank_ms_per_step"]
+    assert len(rk["per_rank"]) == 2 and rk["min"] == min(rk["per_rank"]) and rk["max"] == max(rk["per_rank"]) and rk["per_rank"][1] > rk["per_rank"][0]
+
+
+def test_bench_self_launches_eight_ranks_dry_run():
+    """The driver's largest launch -- `--gpus 8`, one process per GPU of a node -- through the same self-launch path: eight distinct
+    processes rendezvous on 127.0.0.1, every rank is seen, global batch = 8 x the per-GPU batch (weak scaling), the per-rank times
+    arrive in rank order and the maximum is the slowest rank's."""
+    rc, res = _bench(["--gpus", "8", "--dry-run", "--steps", "3", "--warmup", "1"])
+    assert rc == 0 and res["dry_run"] is True and res["n_gpus"] == 8 and res["ranks_seen"] == 8
+    assert res["config"]["global_batch"] == 8 * 32 and res["config"]["parallelism"] == "dp8" and res["scaling"] == "weak"
+    assert sorted(d["rank"] for d in res["devices"]) == list(range(8)) and len({d["pid"] for d in res["devices"]}) == 8
+    rk = res["rank_ms_per_step"]["per_rank"]
+    assert len(rk) == 8 and rk[7] == max(rk) and rk[7] > rk[0]
 
 
 def test_bench_failures_are_one_json_line():

@@ -16,11 +16,29 @@ sys.path.insert(0, ROOT)
 from squeezedet_amd import build as B  # noqa: E402
 from tools import wait_scan as W  # noqa: E402
 
-FILES = ["conv1x1.hip", "conv1x1k.hip", "fire3.hip", "convdet.hip", "chain.hip"]
+FILES = ["conv1x1.hip", "conv1x1k.hip", "fire3.hip", "convdet.hip", "chain.hip", "gemm1x1.hip"]
+# the thresholds below were taken with this compiler; another version may schedule differently without anything being wrong
+HIPCC_SEEN = "7.2"
+
+
+def _hipcc_version():
+    import shutil
+    exe = B._hipcc()
+    if not (os.path.isabs(exe) and os.path.exists(exe)) and shutil.which(exe) is None:
+        return None
+    r = subprocess.run([exe, "--version"], capture_output=True, text=True)
+    import re
+    m = re.search(r"HIP version:\s*(\d+\.\d+)", r.stdout)
+    return m.group(1) if m else ""
 
 
 @pytest.fixture(scope="module")
 def asm(tmp_path_factory):
+    ver = _hipcc_version()
+    if ver is None:
+        pytest.skip("no hipcc on this machine (the static wait-count guard needs the ROCm compiler)")
+    if not ver.startswith(HIPCC_SEEN):
+        pytest.skip("hipcc %s: the wait counts asserted here were taken with %s" % (ver, HIPCC_SEEN))
     d = tmp_path_factory.mktemp("isa")
     flags = {s: e for s, e in B.SOURCES}
 
@@ -80,3 +98,20 @@ def test_fire_chain_loops_are_hand_counted(asm):
     for form in ("ILi2ELi3ELb0ELi6ELi0", "ILi2ELi4ELb0ELi6ELi0", "ILi2ELi6ELb0ELi6ELi0", "ILi3ELi6ELb0ELi4ELi0", "ILi3ELi0ELb1ELi6ELi0"):
         for name, (t, n, nm, cw, aw) in _mfma_loops(asm["chain.hip"], "fire_chain" + form, 8):
             assert cw == [], (name, t, cw)
+
+
+def test_conv1x1_pipe_loop_is_hand_counted_and_fragments_stay_untouched(asm):
+    """conv1x1_pipe (gemm1x1.hip): every memory instruction of the K loop is inline asm, so (i) no compiler vmcnt wait may appear in a
+    loop that carries MFMAs, (ii) the hand-counted waits are the ones the launcher's arithmetic expects -- (NS - 3)(Q + NTW) + NTW --
+    and (iii) no instruction mentions a weight-fragment register between its asm load and the first MFMA that reads it (a register
+    allocator copy at the loop edge would read data that has not arrived; the compiler cannot know)."""
+    forms = {"IDF16_Li4ELi2ELi1ELi4ELb0E": (4, 1, 2), "IDF16_Li8ELi2ELi1ELi4ELb0E": (4, 2, 2), "IDF16_Li4ELi2ELi1ELi4ELb1E": (4, 1, 2),
+             "IDF16_Li4ELi3ELi1ELi3ELb0E": (3, 1, 3), "IDF16_Li4ELi2ELi2ELi6ELb0E": (6, 2, 2), "IfLi4ELi2ELi1ELi4ELb1E": (4, 1, 2),
+             "IDF16_Li4ELi5ELi1ELi4ELb0E": (4, 1, 5)}
+    for form, (ns, q, ntw) in forms.items():
+        loops = _mfma_loops(asm["gemm1x1.hip"], "conv1x1_pipe" + form, 8)
+        for name, (t, n, nm, cw, aw) in loops:
+            assert cw == [], (name, t, cw)
+            assert aw and set(aw) == {(ns - 3) * (q + ntw) + ntw}, (name, t, aw)
+    bad = W.asm_load_violations(asm["gemm1x1.hip"], "conv1x1_pipe")
+    assert not bad, bad[:5]

@@ -68,6 +68,92 @@ def _loops(lines):
     return res
 
 
+def _regs(tok):
+    """'v[82:85]' -> {82..85}, 'v82' -> {82}; anything else -> empty"""
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def asm_load_violations(path, pattern=""):
+    """Registers written by INLINE-ASM `global_load_dwordx4` (loads the compiler's wait-count pass cannot see: conv1x1_pipe's weight
+    fragments) must not be mentioned by ANY instruction between the load and the first MFMA that reads them -- that MFMA sits behind
+    the hand-counted wait (the wait's asm statement passes the registers through), anything earlier would read or clobber a register
+    whose data is still in flight (a register-allocator copy at a loop edge, a spill).  -> [(kernel, loop label, instruction), ...];
+    only loops that contain MFMAs are scanned, the body is walked twice (a load at the bottom is consumed at the top)."""
+    bad = []
+    name, lines = None, []
+    for l in open(path):
+        m = re.match(r"^(\w+):\s+; @", l)
+        if m:
+            name, lines = m.group(1), []
+            continue
+        if name is None:
+            continue
+        if l.strip().startswith(".Lfunc_end"):
+            if re.search(pattern, name):
+                bad += [(name, t, i) for t, i in _asm_load_check(lines)]
+            name = None
+            continue
+        lines.append(l)
+    return bad
+
+
+def _asm_load_check(lines):
+    inasm, tagged = False, []
+    for l in lines:
+        if "#ASMSTART" in l:
+            inasm = True
+        tagged.append((l, inasm))
+        if "#ASMEND" in l:
+            inasm = False
+    labels = {}
+    for i, (l, _) in enumerate(tagged):
+        m = re.match(r"^(\.LBB\w+):", l)
+        if m:
+            labels[m.group(1)] = i
+    out = []
+    for i, (l, _) in enumerate(tagged):
+        m = re.search(r"s_cbranch_\w+\s+(\.LBB\w+)|s_branch\s+(\.LBB\w+)", l)
+        if not m:
+            continue
+        t = m.group(1) or m.group(2)
+        if t not in labels or labels[t] >= i:
+            continue
+        body = tagged[labels[t]:i]
+        if not any("v_mfma" in x for x, _ in body):
+            continue
+        flight = set()
+        for x, ia in body + body:
+            ins = x.split(";")[0].strip()
+            if not ins or ins.startswith((".", "#")) or ins.endswith(":"):
+                continue
+            toks = [tk.strip() for tk in re.split(r"[\s,]+", ins) if tk.strip()]
+            op, args = toks[0], toks[1:]
+            mentioned = set()
+            for a in args:
+                mentioned |= _regs(a)
+            if ia and op == "global_load_dwordx4":
+                dst = _regs(args[0])
+                if (mentioned - dst) & flight or dst & flight:
+                    out.append((t, ins))
+                flight |= dst
+                continue
+            if op.startswith("v_mfma"):
+                srcs = set()
+                for a in args[1:3]:
+                    srcs |= _regs(a)
+                if _regs(args[0]) & flight or (_regs(args[3]) if len(args) > 3 else set()) & flight:
+                    out.append((t, ins))
+                flight -= srcs
+                continue
+            if mentioned & flight:
+                out.append((t, ins))
+    return out
+
+
 def main():
     path = sys.argv[1]
     pat = sys.argv[2] if len(sys.argv) > 2 else ""
