@@ -37,6 +37,7 @@ SOURCES = [
     # (-fno-honor-nans: without it every two-operand fmaxf on an MFMA result is preceded by a canonicalising v_max x, x, x:
     # 148 instead of 84 max instructions per pooled row)
     ("stem4.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-honor-nans"]),
+    ("stem5.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-honor-nans"]),
     ("fire.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("fire2.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("fire3.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),

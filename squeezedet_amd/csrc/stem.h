@@ -28,6 +28,7 @@ struct StemArgs {
 int stem_strip_launch(StemArgs a, int k, int dtype, hipStream_t st, bool* handled);
 int stem_pers_launch(StemArgs a, int k, int dtype, hipStream_t st, bool* handled);   // stem3.hip: fp16, 3x3, 64 couts
 int stem_phase_launch(StemArgs a, int k, int dtype, hipStream_t st, bool* handled);  // stem4.hip: the same shapes, images >= 523 wide
+int stem_k7_launch(StemArgs a, int k, int dtype, hipStream_t st, bool* handled);     // stem5.hip: fp16 7x7 stems (SqueezeDet+, ResNet50)
 bool stem_squeeze_eligible(int h, int w, int cout, int k, int conv_pad, int pool_pad, int s2, int dtype, int n);
 
 }  // namespace sqdet

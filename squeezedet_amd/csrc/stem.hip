@@ -5,7 +5,8 @@
 // (fp16); fused, the conv activations never leave the CU.  Kernels: stem4.hip (persistent, lane-local pooling over three column
 // phases; fp16 3x3 on images >= 523 wide: the default there since the end of round 3 -- the 32-image step 0.5254 against
 // 0.5305 ms, six alternating runs on two boxes), stem3.hip (persistent, strip lanes + DPP pooling; fp16 3x3 otherwise, or
-// "stem_algo" 3) and stem2.hip (strip kernel with the pool in registers; every other shape / dtype, or "stem_algo" 2).  (The round-1 LDS-conv-tile kernel that lived here -- conv
+// "stem_algo" 3), stem5.hip (the float16 7x7 stems: 4-channel LDS rows, one K chunk per kernel row, no gather; round 6) and
+// stem2.hip (strip kernel with the pool in registers; every other shape / dtype, or "stem_algo" 2).  (The round-1 LDS-conv-tile kernel that lived here -- conv
 // tile written to LDS, pooled from LDS -- was superseded by both and is gone.)
 #include "stem.h"
 
@@ -38,6 +39,10 @@ int stem_launch(const void* x, const void* w_packed, const float* bias, void* y,
   if (tune(TUNE_STEM_ALGO) == 0 || tune(TUNE_STEM_ALGO) >= 3) {  // default for the fp16 3x3 stem: the persistent kernel (stem3.hip)
     const int rc3 = stem_pers_launch(a, k, dtype, st, handled);
     if (rc3 != SQDET_OK || *handled) return rc3;
+  }
+  if (tune(TUNE_STEM_ALGO) == 0) {                               // the float16 7x7 stems: one K chunk per kernel row (stem5.hip)
+    const int rc5 = stem_k7_launch(a, k, dtype, st, handled);
+    if (rc5 != SQDET_OK || *handled) return rc5;
   }
   // otherwise the in-register-pool strip kernel (stem2.hip); channel strides it cannot store with 16-byte vectors: not
   // handled (the caller runs conv and pool apart)
