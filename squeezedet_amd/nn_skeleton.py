@@ -371,8 +371,27 @@ class ModelSkeleton:
                 b = self._eval(branch, env, use_plan)
                 v = ops.add_relu(a, b)
         elif node.op == "pool":
-            x = self._eval(node.inputs[0], env, use_plan)
-            v = ops.maxpool_nhwc(x, node.attrs["size"], node.attrs["stride"], node.attrs["padding"])
+            src = node.inputs[0]
+            fused = None
+            if (node.attrs["size"] == 3 and node.attrs["stride"] == 2 and src.op in ("conv", "conv_bn") and src.consumers == 1 and src not in env
+                    and src not in self._fetching and src.attrs["stride"] == 2 and src.attrs["relu"] and int(src.inputs[0].shape[3]) == 3
+                    and ops.stem_supported(int(src.shape[3]), src.attrs["size"])):
+                # conv1 + pool1 of the node-by-node evaluation (the frozen prefix of the trainers, fetches of inner tensors) as the fused
+                # stem launch, like the native plan's (conv activations never reach HBM); shapes no stem kernel takes: conv, then pool
+                xin = self._eval(src.inputs[0], env, use_plan)
+                if src.op == "conv":
+                    pk, bf = self._packed_conv(src.name), self.params[src.name + "/biases"]
+                else:
+                    pk, bf = self._folded_conv(src.name, src.attrs["with_bias"])
+                try:
+                    fused = ops.stem_conv_pool(xin, pk, bf, src.attrs["padding"], node.attrs["padding"])
+                except SqdetError:
+                    fused = None
+            if fused is not None:
+                v = fused
+            else:
+                x = self._eval(src, env, use_plan)
+                v = ops.maxpool_nhwc(x, node.attrs["size"], node.attrs["stride"], node.attrs["padding"])
         elif node.op == "concat":
             if all(i.op == "conv" and i.consumers == 1 for i in node.inputs):
                 # the producing convs write their channel range of the concat tensor directly
