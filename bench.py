@@ -296,6 +296,54 @@ def dominant_kernel_from_stats(config_name):
     return best
 
 
+def pmc_kernels(config_name):
+    """The committed per-kernel PMC summary of this config ON THIS BUILD (profiles/*_pmc_kernels_<config>.json, profiles/pmc_kernels.py), or
+    None."""
+    prof = os.path.join(ROOT, "profiles")
+    fp = build_fingerprint()
+    best = None
+    for f in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
+        if not f.endswith("_pmc_kernels_%s.json" % config_name):
+            continue
+        try:
+            with open(os.path.join(prof, f)) as fh:
+                d = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if d.get("build_fingerprint") == fp and d.get("config") == config_name:
+            d["profile"] = f
+            best = d
+    return best
+
+
+def kernel_roofline(dom, pk, dtype):
+    """A kernel's OWN roofline position from the committed profiles of this build: its average launch (kernel trace) against its fabric
+    bytes per launch (PMC FETCH_SIZE / WRITE_SIZE) and the matrix instructions it issued (PMC SQ_INSTS_MFMA x the flops of one
+    instruction of the config's dtype: 16x16x32 f16 = 16384, 16x16x4 f32 = 2048 -- issued flops, padding lanes included)."""
+    if not dom or not pk:
+        return dom
+    e = next((v for k, v in pk["kernels"].items() if k[:88].rstrip() == dom["kernel"][:88].rstrip()), None)
+    if e is None:
+        return dom
+    sec = dom["avg_launch_us"] * 1e-6
+    out = dict(dom)
+    out["pmc_profile"] = pk["profile"]
+    if e.get("hbm_bytes_per_launch_corrected") is not None:
+        out["traffic_bytes_per_launch"] = e["hbm_bytes_per_launch_corrected"]
+        out["hbm_gbs"] = round(e["hbm_bytes_per_launch_corrected"] / sec / 1e9, 1)
+        out["hbm_frac"] = round(out["hbm_gbs"] / HBM_PEAK_GBS, 4)
+    if e.get("SQ_INSTS_MFMA") is not None:
+        per = 16384.0 if dtype == "fp16" else 2048.0
+        peak = MFMA_F16_PEAK_TFLOPS if dtype == "fp16" else MFMA_F32_PEAK_TFLOPS
+        out["mfma_issued_flops_per_launch"] = e["SQ_INSTS_MFMA"] * per
+        out["mfma_tflops"] = round(e["SQ_INSTS_MFMA"] * per / sec / 1e12, 1)
+        out["mfma_frac"] = round(out["mfma_tflops"] / peak, 4)
+    if "hbm_frac" in out and "mfma_frac" in out:
+        out["bound"] = "hbm" if out["hbm_frac"] >= out["mfma_frac"] else "mfma"
+        out["frac"] = max(out["hbm_frac"], out["mfma_frac"])
+    return out
+
+
 def rotation_count(batch_bytes):
     """distinct input batches to rotate through: at least 4, and more than the Infinity Cache holds"""
     return max(4, int(np.ceil(1.3 * MALL_BYTES / float(batch_bytes))))
@@ -852,11 +900,14 @@ def run_train(args, rank, local_rank, world, device):
     flops = (fwd + bwd) * args.batch
     roof = {"bound": "mfma", "achieved": round(flops / (step_ms * 1e-3) / 1e12, 3), "peak": peak, "unit": "TFLOP/s"}
     roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-    roof["traffic"] = None
+    pk = pmc_kernels(args.config)
+    roof["traffic"] = pk["hbm_bytes_per_step"] if pk else None      # fabric bytes of ONE step: every kernel's PMC bytes x its launches / steps
+    if pk:
+        roof["traffic_profile"] = pk["profile"]
     roof["kernel"] = "whole training step (forward + loss + backward + update; ~300 launches%s)" % (", replayed as one hipGraph" if use_graph else "")
     roof["avg_launch_ms"] = round(step_ms, 4)
     roof["algorithmic_flops_per_launch"] = flops
-    roof["dominant_kernel"] = dominant_kernel_from_stats(args.config)
+    roof["dominant_kernel"] = kernel_roofline(dominant_kernel_from_stats(args.config), pk, args.dtype)
     res = result_head(args, value, world, elapsed, ranks_seen, devices, clocks)
     res["config"] = {"workload": "%s %s training, batch=%d per GPU, synthetic %dx%d images + KITTI-like ground truth (%d distinct batches "
                                  "in rotation): GPU label build + forward + loss + backward + gradient all-reduce + clipped Momentum"

@@ -1,7 +1,7 @@
 """Builds the HBM-traffic summary bench.py attaches to its roofline object from two rocprofv3 PMC passes
 (FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs of tools/pmc_forward.py, as MI355X_MICROARCH.md prescribes):
 
-    python profiles/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> <layer names, comma separated>
+    python profiles/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> <layer names, comma separated> [config]
 
 tools/pmc_forward.py runs 5 forwards of the plan and nothing else after the parameters are packed, so the LAST
 5 x L dispatches of the trace are the L launches of each forward, in plan order: launch i of a forward is layer i
@@ -44,7 +44,9 @@ def main():
             "forwards, KiB as reported.  gfx950 correction: bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (FETCH_SIZE tallies 128-B requests "
             "at 64 B).  Counters sit on the L2's memory side: hits in the 256 MiB Infinity Cache are included, so 'traffic' is fabric "
             "traffic, an upper bound on DRAM traffic.")
-    json.dump({"note": note, "config": "sqdet_infer", "build_fingerprint": bench.build_fingerprint(), "kernels": kernels, "by_layer": by_layer},
+    config = sys.argv[5] if len(sys.argv) > 5 else "sqdet_infer"
+    note = note.replace("`python tools/pmc_forward.py`", "`PMC_CONFIG=%s python tools/pmc_forward.py`" % config)
+    json.dump({"note": note, "config": config, "build_fingerprint": bench.build_fingerprint(), "kernels": kernels, "by_layer": by_layer},
               open(sys.argv[3], "w"), indent=1)
     for k in kernels:
         print("%-44s %10.1f MB  %s" % (k["layer"], k["hbm_bytes_per_launch_corrected"] / 1e6, k["kernel"][:60]))

@@ -17,6 +17,8 @@
 //   * a WAVE is the unit of work: a strip of 16 conv columns (7 pooled ones) x 16 conv rows (7 pooled rows) in four steps of 4 conv rows
 //     x all cout tiles (96 / 64 accumulators); its input rows sit in a 16-row ring of its own, the rows of the next step are requested a
 //     step ahead (registers) and written behind the step's fragment reads -- no barrier anywhere after the weight conversion;
+//     (stand-alone, batch 8: 55 us for SqueezeDet+'s stem -- of which the MFMA loop is ~40 and the pooled epilogue ~18, measured by
+//     leaving each out -- against 91 for the strip kernel; 40 against 98 us for ResNet50's)
 //   * pooling in registers as in the strip kernel: vertical v_max3 over the step's rows (+ the carry of the last two rows), horizontal
 //     3-tap / stride-2 max by two DPP row shifts, then bias + ReLU + rounding ONCE on the pooled value (all three commute with max).
 // K is 7 x 32 = 224 instead of 147 (1.52x the MFMAs), which is what the alignment costs; the matrix pipe has the room.
@@ -32,6 +34,10 @@ constexpr int S5_PITCH = 304;               // bytes per ring row: 38 pixels x 8
 constexpr int S5_PAIRS = 19;                // 16-byte pixel pairs per ring row
 constexpr int S5_STEPS = 4;                 // steps per item: 16 conv rows -> 7 pooled rows
 constexpr int S5_PROWS = 2 * S5_STEPS - 1;
+constexpr int S5_WAVES = 4;                 // waves per workgroup (two workgroups per CU: 8-wave workgroups whose second four waves start half a
+                                            // step late -- one wave's pooled epilogue under its SIMD partner's MFMAs -- measured 58.8 against 55.2 us)
+// LDS behind the converted weights: the four rings (or, first, the packed weights as they arrive: 5 NT KiB), then the bias
+template <int NT> constexpr int S5_BIAS_OFF = (S5_WAVES * S5_RING * S5_PITCH > 5 * NT * 1024 ? S5_WAVES * S5_RING * S5_PITCH : 5 * NT * 1024);
 
 struct S5Args {
   StemArgs s;
@@ -40,7 +46,7 @@ struct S5Args {
 };
 
 template <int NT>
-__global__ __launch_bounds__(256, 2) void stem_k7(S5Args a) {
+__global__ __launch_bounds__(S5_WAVES * 64, 2) void stem_k7(S5Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int WL = 7 * NT * 1024;         // [kernel row][cout tile][64 lanes][16 B]
   unsigned char* const wl = lds;
@@ -52,10 +58,10 @@ __global__ __launch_bounds__(256, 2) void stem_k7(S5Args a) {
   // ---- weights: gather order (K' = (row * 7 + col) * 3 + ch, 5 chunks) -> one chunk per kernel row (K'' = col * 4 + ch)
   {
     const i32x4* src = reinterpret_cast<const i32x4*>(a.s.wp);
-    for (int i = threadIdx.x; i < 5 * NT * 64; i += 256) reinterpret_cast<i32x4*>(rings)[i] = src[i];
+    for (int i = threadIdx.x; i < 5 * NT * 64; i += S5_WAVES * 64) reinterpret_cast<i32x4*>(rings)[i] = src[i];
     __syncthreads();
     const unsigned short* tmp = reinterpret_cast<const unsigned short*>(rings);
-    for (int u = threadIdx.x; u < 7 * NT * 64; u += 256) {
+    for (int u = threadIdx.x; u < 7 * NT * 64; u += S5_WAVES * 64) {
       const int L = u & 63, rt = u >> 6;
       const int r = rt / NT, t = rt - r * NT;
       const int gg = L >> 4, ii = L & 15;
@@ -78,9 +84,10 @@ __global__ __launch_bounds__(256, 2) void stem_k7(S5Args a) {
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.s.y, 0, a.y_bytes, 0x00020000);
   constexpr unsigned OOB = 0xfffffff0u;
   const int cb = g * 4 * NT;                               // this lane's 4 NT consecutive couts
-  f32x4 bias[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) bias[t] = *reinterpret_cast<const f32x4*>(a.s.bias + cb + t * 4);
+  // (the bias lives in LDS behind the rings: 16 NT floats, read in the epilogue -- 4 NT registers the step loop needs elsewhere)
+  float* const biasl = reinterpret_cast<float*>(rings + S5_BIAS_OFF<NT>);
+  if (threadIdx.x < 16 * NT) biasl[threadIdx.x] = a.s.bias[threadIdx.x];
+  __syncthreads();
   const unsigned char* const wlane = wl + lane * 16;
   const unsigned char* const rlane = ring + 16 * j + 16 * g;
   const float NEG = -__builtin_inff();
@@ -94,44 +101,58 @@ __global__ __launch_bounds__(256, 2) void stem_k7(S5Args a) {
     tpair[q] = id - trow[q] * S5_PAIRS;
   }
 
-  const int wid = (int)blockIdx.x * 4 + wave, nw = (int)gridDim.x * 4;
-#pragma unroll 1
-  for (int item = wid; item < a.nitems; item += nw) {
+  const int wid = (int)blockIdx.x * S5_WAVES + wave, nw = (int)gridDim.x * S5_WAVES;
+  // (geometry of an item: image, first pooled row / column, first input row / column)
+  auto decode = [&](int item, int& n, int& py0, int& px0, int& iy0, int& ix0) {
     const int sx = item % a.nsx;
     const int it2 = item / a.nsx;
-    const int seg = it2 % a.nseg, n = it2 / a.nseg;
-    const int py0 = seg * S5_PROWS, px0 = sx * 7;
-    const int iy0 = 4 * py0 - a.s.ptc, ix0 = 4 * px0 - a.s.plc;       // conv (2 py0, 2 px0) -> input (4 py0 - pad, ..)
-
-    // requests the pixel pairs of input rows [rho0, rho0 + nrows) (relative to iy0): 12 bytes each, zeros outside the image
-    auto request = [&](int rho0, int nrows, int ntask, i32x4 (&v)[4]) {
+    const int seg = it2 % a.nseg;
+    n = it2 / a.nseg;
+    py0 = seg * S5_PROWS; px0 = sx * 7;
+    iy0 = 4 * py0 - a.s.ptc; ix0 = 4 * px0 - a.s.plc;         // conv (2 py0, 2 px0) -> input (4 py0 - pad, ..)
+  };
+  // requests the pixel pairs of input rows [rho0, rho0 + nrows) of an item (relative to its iy0): 12 bytes each, zeros outside the image
+  auto request = [&](int n, int iy0, int ix0, int rho0, int nrows, int ntask, unsigned (&v)[4][3]) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q >= ntask) continue;
-        const int iy = iy0 + rho0 + trow[q], ix = ix0 + 2 * tpair[q];
-        const bool ok = trow[q] < nrows && (unsigned)iy < (unsigned)a.s.H && (unsigned)ix < (unsigned)a.s.W;
-        const unsigned off = ok ? (unsigned)(((n * a.s.H + iy) * a.s.W + ix) * 6) : OOB;
-        const auto d = __builtin_amdgcn_raw_buffer_load_b96(rx, off, 0, 0);
-        v[q] = i32x4{(int)d[0], (int)d[1], (int)d[2], 0};
-      }
-    };
-    // writes them: two 3-channel pixels -> two 4-channel pixels (16 bytes) at ring row (rho0 + row) % 16
-    auto commit = [&](int rho0, int nrows, int ntask, const i32x4 (&v)[4]) {
+    for (int q = 0; q < 4; ++q) {
+      if (q >= ntask) continue;
+      const int iy = iy0 + rho0 + trow[q], ix = ix0 + 2 * tpair[q];
+      const bool ok = trow[q] < nrows && (unsigned)iy < (unsigned)a.s.H && (unsigned)ix < (unsigned)a.s.W;
+      const unsigned off = ok ? (unsigned)(((n * a.s.H + iy) * a.s.W + ix) * 6) : OOB;
+      const auto d = __builtin_amdgcn_raw_buffer_load_b96(rx, off, 0, 0);
+      v[q][0] = d[0]; v[q][1] = d[1]; v[q][2] = d[2];
+    }
+  };
+  // writes them: two 3-channel pixels -> two 4-channel pixels (16 bytes) at ring row (rho0 + row) % 16
+  auto commit = [&](int rho0, int nrows, int ntask, const unsigned (&v)[4][3]) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q >= ntask) continue;
-        if (trow[q] < nrows) {
-          const unsigned d0 = (unsigned)v[q][0], d1 = (unsigned)v[q][1], d2 = (unsigned)v[q][2];
-          const i32x4 o = {(int)d0, (int)(d1 & 0xffffu), (int)((d1 >> 16) | (d2 << 16)), (int)(d2 >> 16)};
-          *reinterpret_cast<i32x4*>(ring + ((rho0 + trow[q]) & (S5_RING - 1)) * S5_PITCH + tpair[q] * 16) = o;
-        }
+    for (int q = 0; q < 4; ++q) {
+      if (q >= ntask) continue;
+      if (trow[q] < nrows) {
+        const unsigned d0 = v[q][0], d1 = v[q][1], d2 = v[q][2];
+        const i32x4 o = {(int)d0, (int)(d1 & 0xffffu), (int)((d1 >> 16) | (d2 << 16)), (int)(d2 >> 16)};
+        *reinterpret_cast<i32x4*>(ring + ((rho0 + trow[q]) & (S5_RING - 1)) * S5_PITCH + tpair[q] * 16) = o;
       }
-    };
+    }
+  };
 
-    i32x4 pre[4];
-    request(0, 13, 4, pre);
+  // Every request has a whole step of MFMAs to land: a step's rows are requested two steps ahead and written one step ahead, behind
+  // the step's own fragment reads (the LDS serves a wave in order); the first 13 rows of the NEXT item are requested in the third step
+  // of the current one (the registers are free by then) and written when the item starts.
+  unsigned pre[4][3];
+  {
+    int n, py0, px0, iy0, ix0;
+    if (wid < a.nitems) {
+      decode(wid, n, py0, px0, iy0, ix0);
+      request(n, iy0, ix0, 0, 13, 4, pre);
+    }
+  }
+#pragma unroll 1
+  for (int item = wid; item < a.nitems; item += nw) {
+    int n, py0, px0, iy0, ix0;
+    decode(item, n, py0, px0, iy0, ix0);
     commit(0, 13, 4, pre);
-    request(13, 8, 3, pre);
+    request(n, iy0, ix0, 13, 8, 3, pre);
 
     f32x4 carry[NT];
 #pragma unroll
@@ -148,11 +169,6 @@ __global__ __launch_bounds__(256, 2) void stem_k7(S5Args a) {
       for (int rho = 0; rho < 8; ++rho) bf[rho] = *reinterpret_cast<const i32x4*>(b0 + rho * S5_PITCH);
 #pragma unroll
       for (int rho = 8; rho < 13; ++rho) bf[rho] = *reinterpret_cast<const i32x4*>(b1 + (rho - 8) * S5_PITCH);
-      // ---- the next step's rows: written behind these reads (the LDS serves a wave in order), the step after that requested
-      if (step + 1 < S5_STEPS) {
-        commit(8 * step + 13, 8, 3, pre);
-        if (step + 2 < S5_STEPS) request(8 * step + 21, 8, 3, pre);
-      }
       // ---- 4 conv rows x NT cout tiles x 7 kernel rows
       f32x4 acc[4][NT];
 #pragma unroll
@@ -167,6 +183,18 @@ __global__ __launch_bounds__(256, 2) void stem_k7(S5Args a) {
 #pragma unroll
           for (int m = 0; m < 4; ++m) mma16<f16>(acc[m][t], af, bf[2 * m + r]);
         }
+      // ---- the next step's rows (requested a step ago) behind this step's fragment reads; then the rows of the step after that,
+      //      or -- in the third step -- the first rows of this wave's next item
+      if (step + 1 < S5_STEPS) {
+        commit(8 * step + 13, 8, 3, pre);
+        if (step + 2 < S5_STEPS) {
+          request(n, iy0, ix0, 8 * step + 21, 8, 3, pre);
+        } else if (item + nw < a.nitems) {
+          int n2, py2, px2, iy2, ix2;
+          decode(item + nw, n2, py2, px2, iy2, ix2);
+          request(n2, iy2, ix2, 0, 13, 4, pre);
+        }
+      }
       // ---- pooled rows 2 step - 1 (carry + row 0) and 2 step (rows 0..2); rows 2, 3 are carried
       const int pyA = py0 + 2 * step - 1, pyB = pyA + 1;
       const int px = px0 + (j >> 1);
@@ -183,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void stem_k7(S5Args a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) h[t >> 1][(t & 1) * 4 + e] = (f16)__builtin_fmaxf(hpool(v[t][e]) + bias[t][e], 0.f);
+          for (int e = 0; e < 4; ++e) h[t >> 1][(t & 1) * 4 + e] = (f16)__builtin_fmaxf(hpool(v[t][e]) + biasl[cb + t * 4 + e], 0.f);
 #pragma unroll
         for (int p = 0; p < NT / 2; ++p)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, h[p]), ry, row != OOB ? row + (unsigned)(p * 16) : OOB, 0, 0);
@@ -205,15 +233,14 @@ __global__ __launch_bounds__(256, 2) void stem_k7(S5Args a) {
 
 template <int NT>
 int launch_s5(S5Args& a, hipStream_t st) {
-  constexpr size_t ringb = (size_t)4 * S5_RING * S5_PITCH, tmpb = (size_t)5 * NT * 1024;
-  const size_t lds = (size_t)7 * NT * 1024 + (ringb > tmpb ? ringb : tmpb);
+  const size_t lds = (size_t)7 * NT * 1024 + S5_BIAS_OFF<NT> + 16 * NT * 4;
   auto kern = &stem_k7<NT>;
   static PerDevice once;
   SQDET_CHECK_HIP(once.run([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }));
-  int wgs = (a.nitems + 3) / 4;
-  const int cap = 2 * cu_count();
+  int wgs = (a.nitems + S5_WAVES - 1) / S5_WAVES;
+  const int cap = cu_count() * (S5_WAVES == 8 ? 1 : 2);
   if (wgs > cap) wgs = cap;
-  hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(S5_WAVES * 64), lds, st, a);
   SQDET_CHECK_HIP(hipGetLastError());
   return SQDET_OK;
 }

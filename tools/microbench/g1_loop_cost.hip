@@ -11,7 +11,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-enum { F_MFMA = 1, F_W = 2, F_DMA = 4, F_LDS = 8, F_BAR = 16, F_WAIT = 32 };
+enum { F_MFMA = 1, F_W = 2, F_DMA = 4, F_LDS = 8, F_BAR = 16, F_WAIT = 32, F_BR = 64, F_BRT = 128, F_SALU = 256 };
 
 template <int IMM>
 __device__ __forceinline__ void wload(i32x4& dst, unsigned voff, const unsigned char* sbase) {
@@ -56,6 +56,22 @@ __global__ __launch_bounds__(256, 2) void step_cost(const unsigned char* w, cons
       if (F & F_MFMA)
         for (int m = 0; m < 2; ++m) for (int t = 0; t < 4; ++t) mma(acc[m][t], wf[u][t], bfa[m]);
       __builtin_amdgcn_sched_barrier(0);
+      // F_BR: four wave-uniform branches per step that are never taken; F_BRT: four that always are (over one s_nop); F_SALU: sixteen
+      // dependent scalar adds per step -- what control flow and scalar arithmetic cost a loop that is otherwise bound by its MFMAs
+      if (F & F_BR) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (steps == 12345 + k + u) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+      }
+      if (F & F_BRT) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (steps != 12345 + k + u) asm volatile("s_nop 0" ::: "memory");
+      }
+      if (F & F_SALU) {
+        int sa = steps;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) asm volatile("s_add_i32 %0, %0, %1" : "+s"(sa) : "s"(c));
+        if (sa == 77) asm volatile("s_nop 1");
+      }
       constexpr int N = ((F & F_W) ? 8 : 0) + ((F & F_DMA) ? 2 : 0);
       if ((F & F_WAIT) && (F & F_BAR)) asm volatile("s_waitcnt vmcnt(%4)\n\ts_barrier" : "+v"(wf[(u + 1) & 3][0]), "+v"(wf[(u + 1) & 3][1]), "+v"(wf[(u + 1) & 3][2]), "+v"(wf[(u + 1) & 3][3]) : "n"(N) : "memory");
       else if (F & F_WAIT) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(wf[(u + 1) & 3][0]), "+v"(wf[(u + 1) & 3][1]), "+v"(wf[(u + 1) & 3][2]), "+v"(wf[(u + 1) & 3][3]) : "n"(N) : "memory");
@@ -108,6 +124,11 @@ int main(int argc, char**) {
     run<F_MFMA | F_W | F_DMA | F_WAIT>("16 MFMAs + 4 loads + 1 piece + wait", w, x, out, sink, wgs);
     run<F_MFMA | F_W | F_DMA | F_WAIT | F_BAR>("16 MFMAs + 4 loads + 1 piece + wait + barrier", w, x, out, sink, wgs);
     run<F_MFMA | F_W | F_DMA | F_WAIT | F_BAR | F_LDS>("the whole step", w, x, out, sink, wgs);
+    run<F_MFMA | F_W | F_DMA | F_WAIT | F_BAR | F_LDS | F_BR>("the whole step + 4 untaken branches", w, x, out, sink, wgs);
+    run<F_MFMA | F_W | F_DMA | F_WAIT | F_BAR | F_LDS | F_BRT>("the whole step + 4 taken branches", w, x, out, sink, wgs);
+    run<F_MFMA | F_W | F_DMA | F_WAIT | F_BAR | F_LDS | F_SALU>("the whole step + 16 scalar adds", w, x, out, sink, wgs);
+    run<F_MFMA | F_BR>("16 MFMAs + 4 untaken branches", w, x, out, sink, wgs);
+    run<F_MFMA | F_BRT>("16 MFMAs + 4 taken branches", w, x, out, sink, wgs);
     run<F_W | F_DMA | F_WAIT | F_BAR | F_LDS>("the whole step without MFMAs", w, x, out, sink, wgs);
     run<F_W | F_WAIT>("4 fragment loads + wait only", w, x, out, sink, wgs);
   }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""The command the PMC passes profile: the SqueezeDet configs[1] plan (batch 32, 375x1242, float16), 2 warm-up + 3 measured
-sqdet_net_forward calls on distinct input batches, nothing else.  Run under
+"""The command the PMC passes profile: an inference config's plan (default the SqueezeDet configs[1] plan: batch 32, 375x1242, float16;
+PMC_CONFIG=sqdetplus_infer: SqueezeDet+ at batch 8), 2 warm-up + 3 measured sqdet_net_forward calls on distinct input batches, nothing
+else.  Run under
     rocprofv3 --pmc FETCH_SIZE -d <dir> -o fetch --output-format csv -- python tools/pmc_forward.py
     rocprofv3 --pmc WRITE_SIZE -d <dir> -o write --output-format csv -- python tools/pmc_forward.py
 (separate passes, counters only) and feed the two counter_collection.csv files to profiles/pmc_traffic.py."""
@@ -12,7 +13,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
-args = bench.parse_args(["--config", "sqdet_infer"])
+args = bench.parse_args(["--config", os.environ.get("PMC_CONFIG", "sqdet_infer")])
 model, mc, xs = bench.build_infer_model(args, 0)
 plan = model._native_plan(args.batch)
 preds = None
