@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 FIRES = [("fire2", 64, 16, 64), ("fire3", 128, 16, 64), ("fire4", 128, 32, 128), ("fire5", 256, 32, 128),
          ("fire6", 256, 48, 192), ("fire7", 384, 48, 192), ("fire8", 384, 64, 256), ("fire9", 512, 64, 256),
          ("fire10", 512, 96, 384), ("fire11", 768, 96, 384)]
-WARM, ITERS = 3, 20
+WARM, ITERS = 100, 20      # (100: the clocks ramp over the first milliseconds of a burst)
 HBM_PEAK = 8000.0
 
 
