@@ -192,7 +192,11 @@ int sqdet_fire_maxpool_fwd(const void* x, const void* w_s, const float* b_s, con
  *   y = concat(relu(conv1x1(sq_in, W_e1) + b_e1), relu(conv3x3(sq_in, W_e3) + b_e3))     (nets/squeezeDet.py:92-106),
  * pool != 0: followed by max_pool 3x3 / stride 2 / SAME (fire3 -> pool3, fire5 -> pool5: nets/squeezeDet.py:49-57) taken
  * in registers -- y is then the pooled tensor [n, ceil(h/2), ceil(w/2), e1x1+e3x3] (float16 shapes of the streaming
- * kernel only).  w_e1 / w_e3: packed by sqdet_conv_pack_weights.  Bitwise sqdet_fire_fwd / sqdet_fire_maxpool_fwd. */
+ * kernel only).  w_e1 / w_e3: packed by sqdet_conv_pack_weights.  Bitwise sqdet_fire_fwd / sqdet_fire_maxpool_fwd.
+ * Deep squeezes (SqueezeDet+: 192 / 384 channels, nets/squeezeDetPlus.py:46-73), pool == 0: ONE launch of the 3x3 tile kernel that
+ * also runs the expand1x1 on the staged squeeze tile where sqdet_fire_expand_pair_supported says 1 (float16, e1x1 == e3x3 a multiple
+ * of 64 >= 128, the halo tile resident in LDS); two conv launches otherwise.  Bitwise the two convs either way. */
+int sqdet_fire_expand_pair_supported(int n, int h, int w, int s1x1, int e1x1, int e3x3, int dtype);
 int sqdet_fire_expand_fwd(const void* sq_in, const void* w_e1, const float* b_e1, const void* w_e3, const float* b_e3,
                           void* y, int n, int h, int w, int s1x1, int e1x1, int e3x3, int pool, int dtype,
                           sqdet_stream_t stream);

@@ -45,6 +45,7 @@ SIGNATURES = {
     "sqdet_fire_fwd_keep": (ci, [vp] * 9 + [ci] * 8 + [vp]),
     "sqdet_fire_maxpool_fwd": (ci, [vp] * 10 + [ci] * 8 + [vp]),
     "sqdet_fire_expand_fwd": (ci, [vp] * 6 + [ci] * 8 + [vp]),
+    "sqdet_fire_expand_pair_supported": (ci, [ci] * 7),
     "sqdet_fire_squeeze_next_supported": (ci, [ci] * 6),
     "sqdet_fire_squeeze_next_fwd": (ci, [vp] * 10 + [ci] * 9 + [vp]),
     "sqdet_fire_expand_squeeze_next_supported": (ci, [ci] * 6),

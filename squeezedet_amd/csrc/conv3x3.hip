@@ -53,6 +53,7 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
   a.nchunk = g.nchunk;
   a.pieces = c.Cin * esz / 16;
   a.stage_chunks = g.nchunk;
+  a.wp1 = nullptr; a.bias1 = nullptr; a.y_coffset1 = 0;
   if ((long)c.N * a.tiles_x * a.tiles_y > 0x7fffffffL) return SQDET_OK;
 
   int ntw = g.nt, mt = 2;
@@ -96,6 +97,54 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
   const bool ok = dtype == SQDET_F16 ? dispatch_tile<f16>(a, mt, ntw, splitk, grid_y, lds, st)
                                      : dispatch_tile<float>(a, mt, ntw, splitk, grid_y, lds, st);
   if (!ok) return SQDET_OK;
+  SQDET_CHECK_HIP(hipGetLastError());
+  *handled = true;
+  return SQDET_OK;
+}
+
+// ---- expand1x1 || expand3x3 of a fire module in ONE launch of the tile kernel's PAIR form (float16; SqueezeDet+'s squeeze depths
+// 192 / 384, nets/squeezeDetPlus.py:46-73,81-106) ----
+// Shapes: e1 == e3 = a multiple of 64 in two or more packed groups of 4 tiles (the <4, 4> wave layout), and the WHOLE halo tile
+// resident: up to 6 K chunks (S <= 192) anywhere -- two workgroups per CU as for the plain conv --, up to 12 (S <= 384: 135 KiB,
+// one workgroup per CU) only where the launch has at most one workgroup per CU anyway (the 22 x 76 maps at batch 8: 240).
+// ("dbg" 93: never; 94: the 12-chunk form at any size -- tests)
+bool conv3x3_pair_eligible(int n, int h, int w, int s, int e1, int e3, int dtype) {
+  if (conv_algo() != 0 || tune(TUNE_DBG) == 93 || dtype != SQDET_F16 || e1 != e3 || e1 % 64 != 0 || s % 8 != 0) return false;
+  const ConvGeom g1 = conv_geom(1, s, e1, dtype), g3 = conv_geom(3, s, e3, dtype);
+  if (g1.gather || g3.gather || g3.nt != 4 || g1.nt != 4 || g3.ngroups < 2 || g1.ngroups != g3.ngroups || g1.nchunk != g3.nchunk) return false;
+  if (g3.nchunk <= 6) return true;
+  if (g3.nchunk > 12) return false;
+  const long wgs = (long)n * ((w + TCOLS - 1) / TCOLS) * ((h + TROWS - 1) / TROWS) * ((g3.ngroups + 1) / 2);
+  return wgs <= cu_count() || tune(TUNE_DBG) == 94;
+}
+
+int conv3x3_pair_launch(const void* x, const void* w3, const float* b3, const void* w1, const float* b1, void* y, int n, int h, int w,
+                        int s, int e1, int e3, int dtype, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (!conv3x3_pair_eligible(n, h, w, s, e1, e3, dtype)) return SQDET_OK;
+  const ConvGeom g = conv_geom(3, s, e3, dtype);
+  const long px = (long)n * h * w;
+  if (px * (e1 + e3) * 2 >= (1L << 31) || px > (1L << 30)) return SQDET_OK;
+  TileArgs a;
+  ConvArgs& c = a.c;
+  c.x = x; c.wp = w3; c.bias = b3; c.y = y;
+  c.N = n; c.H = h; c.W = w; c.Cin = s; c.Cout = e3; c.k = 3; c.stride = 1; c.pt = 1; c.pl = 1; c.Ho = h; c.Wo = w;
+  c.P = (int)px; c.ntiles = 0;
+  c.nchunk = g.nchunk; c.steps = g.steps; c.ngroups = g.ngroups;
+  c.y_cstride = e1 + e3; c.y_coffset = e1; c.relu = 1;
+  c.x_cstride = s; c.x_coffset = 0; c.accum = 0; c.res = nullptr; c.relu_of = nullptr;
+  c.scores = nullptr; c.score_apg = 0; c.score_classes = 0;
+  a.tiles_x = (w + TCOLS - 1) / TCOLS;
+  a.tiles_y = (h + TROWS - 1) / TROWS;
+  a.nt_pack = g.nt;
+  a.total_tiles = g.nt * g.ngroups;
+  a.nchunk = g.nchunk;
+  a.pieces = s * 2 / 16;
+  a.stage_chunks = g.nchunk;                // resident
+  a.x_bytes = (unsigned)(px * s * 2);
+  a.wp1 = w1; a.bias1 = b1; a.y_coffset1 = 0;
+  const size_t lds = (size_t)g.nchunk * CHUNK_BYTES;
+  launch_tile<f16, 4, 4, true>(a, (g.ngroups + 1) / 2, lds, st);
   SQDET_CHECK_HIP(hipGetLastError());
   *handled = true;
   return SQDET_OK;

@@ -34,6 +34,11 @@ struct TileArgs {
   int pieces;       // 16-byte pieces per pixel actually present = Cin*sizeof(T)/16
   unsigned x_bytes; // size of the input tensor (split-K mode: 32-bit buffer offsets)
   int stage_chunks; // cout-split mode: K-chunks of the halo tile resident in LDS at a time (deep K is walked in stages)
+  // PAIR form (expand1x1 || expand3x3 of a fire module from ONE staged squeeze tile, nets/squeezeDetPlus.py:81-106): the packed 1x1
+  // kernel / bias of the same Cin -> Cout shape and the channel offset of its slice of y's rows; the whole tile is resident
+  const void* wp1;
+  const float* bias1;
+  int y_coffset1;
 };
 
 // Stage `nload` K-chunks starting at chunk c0 of the halo tile into LDS.
@@ -71,7 +76,12 @@ __device__ __forceinline__ void stage_tile(const TileArgs& a, unsigned char* lds
   }
 }
 
-template <typename T, int MT, int NTW>
+// PAIR (round 6): behind the 3x3 conv the workgroup runs the module's expand1x1 on the SAME resident tile -- the centre tap's B
+// fragments, nchunk steps instead of 9 nchunk, the accumulators and fragment registers the 3x3 pass has just left -- and writes it
+// into its slice of the concat rows: one read and one staging of the squeeze tile for both expands, one launch instead of two.
+// The 1x1 weights (6 chunks per group of loads) are requested before the 3x3 epilogue's stores.  Accumulation order = chunk
+// ascending, as every 1x1 kernel: bitwise the separate conv.
+template <typename T, int MT, int NTW, bool PAIR = false>
 __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int WR = TROWS / MT;   // waves along the tile rows
@@ -182,12 +192,13 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
   T* y = reinterpret_cast<T*>(a.c.y);
   const int ox = ox0 + j;
   const int cb = group * 16 * a.nt_pack + g * 4 * a.nt_pack + n0 * 4;
+  auto epilogue = [&](const float* bias_p, int y_coffset) {
   f32x4 bias[NTW];
   int nt_valid = 0;   // Cout is a multiple of 4: whole 4-cout pieces beyond Cout are skipped
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     const bool ok = cb + t * 4 < a.c.Cout;
-    bias[t] = ok && a.c.bias ? *reinterpret_cast<const f32x4*>(a.c.bias + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bias[t] = ok && bias_p ? *reinterpret_cast<const f32x4*>(bias_p + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     nt_valid += ok ? 1 : 0;
   }
 
@@ -198,7 +209,7 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
     for (int m = 0; m < MT; ++m) {
       const int oy = oy0 + m0 + m;
       if (oy >= a.c.H) break;
-      T* dst = y + (((size_t)n * a.c.H + oy) * a.c.W + ox) * a.c.y_cstride + a.c.y_coffset + cb;
+      T* dst = y + (((size_t)n * a.c.H + oy) * a.c.W + ox) * a.c.y_cstride + y_coffset + cb;
       f32x4 v[NTW];
 #pragma unroll
       for (int t = 0; t < NTW; ++t) {
@@ -220,16 +231,60 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
       store_couts<T, NTW>(dst, v, nt_valid);
     }
   }
+  };
+  if constexpr (!PAIR) {
+    epilogue(a.c.bias, a.c.y_coffset);
+  } else {
+    // ---- expand1x1 on the resident tile (a.stage_chunks == a.nchunk: one stage, the whole halo tile is still in LDS) ----
+    constexpr int CG = 6;                    // chunks per group of weight loads (6 x NTW fragments in flight)
+    const i32x4* w1base = reinterpret_cast<const i32x4*>(a.wp1) + ((size_t)group * a.nchunk * a.nt_pack + n0) * 64 + lane;
+    i32x4 w1[CG][NTW];
+    auto load_w1 = [&](int c0) {
+#pragma unroll
+      for (int u = 0; u < CG; ++u) {
+        const int ch = c0 + u < a.nchunk ? c0 + u : a.nchunk - 1;      // (past the last chunk: a harmless re-read, never multiplied)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) w1[u][t] = w1base[(size_t)(ch * a.nt_pack + t) * 64];
+      }
+    };
+    if (active) load_w1(0);                  // in flight under the 3x3 epilogue's stores
+    epilogue(a.c.bias, a.c.y_coffset);
+    if (!active) return;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int P0 = (1 + m0) * (TCOLS + 2) + j + 1;   // halo pixel of this wave's first row at the centre tap
+    const int h0 = P0 >> 1;
+    for (int c0 = 0; c0 < a.nchunk; c0 += CG) {
+      if (c0 > 0) load_w1(c0);
+#pragma unroll
+      for (int u = 0; u < CG; ++u) {
+        if (c0 + u < a.nchunk) {             // wave-uniform
+          const unsigned char* lchunk = lds + (c0 + u) * CHUNK_BYTES;
+          i32x4 bf[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            bf[m] = *reinterpret_cast<const i32x4*>(lchunk + (P0 + (TCOLS + 2) * m) * 64 + ((g ^ ((h0 + m) & 3)) << 4));
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], w1[u][t], bf[m]);
+        }
+      }
+    }
+    epilogue(a.bias1, a.y_coffset1);
+  }
 }
 
-template <typename T, int MT, int NTW>
+template <typename T, int MT, int NTW, bool PAIR = false>
 static void launch_tile(const TileArgs& a, int grid_y, size_t lds, hipStream_t st) {
   static PerDevice once;   // > 64 KiB of dynamic LDS has to be allowed once per kernel and device
   if (lds > 65536)
-    (void)once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_tile<T, MT, NTW>),
+    (void)once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_tile<T, MT, NTW, PAIR>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
   const dim3 grid((unsigned)((a.c.N * a.tiles_x * a.tiles_y + 7) / 8 * 8), (unsigned)grid_y);
-  hipLaunchKernelGGL((conv3x3_tile<T, MT, NTW>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_tile<T, MT, NTW, PAIR>), grid, dim3(256), lds, st, a);
 }
 
 // the split-K (ConvDet) kernel lives in convdet.hip: that file is compiled with the accumulators in AGPRs

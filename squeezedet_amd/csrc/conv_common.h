@@ -132,6 +132,10 @@ int fire_dma_launch(const void* sq_in, const void* w1, const float* b1, const vo
                     const float* bs2, void* s_out, int n, int h, int w, int s, int e1, int e3, int s2, int pool, int dtype,
                     hipStream_t st, bool* handled);
 int conv3x3_tile_launch(const ConvArgs& a, const ConvGeom& g, int dtype, hipStream_t st, bool* handled);
+// conv3x3.hip: both expands of a fire module from ONE staged squeeze tile (the tile kernel's PAIR form)
+bool conv3x3_pair_eligible(int n, int h, int w, int s, int e1, int e3, int dtype);
+int conv3x3_pair_launch(const void* sq_in, const void* w3, const float* b3, const void* w1, const float* b1, void* y, int n, int h, int w,
+                        int s, int e1, int e3, int dtype, hipStream_t st, bool* handled);
 // convdet.hip: the score epilogue's shapes; conv.hip: ConvDet + scores in one launch (sqdet_convdet_fwd)
 bool convdet_score_supported(int cout, int apg, int classes, int dtype);
 int convdet_scored_launch(const void* x, const void* w_packed, const float* bias, void* preds, float* scores, int n, int h, int w,

@@ -54,6 +54,9 @@ int fire_squeeze_next_launch(const void* x, const void* ws, const float* bs, con
                              int s, int e1, int e3, int s2, int dtype, hipStream_t st, bool* handled);
 int fire_expand_stream_launch(const void* sq_in, const void* w1, const float* b1, const void* w3, const float* b3, void* y,
                               int n, int h, int w, int s, int e1, int e3, int dtype, int pool, hipStream_t st, bool* handled);
+bool conv3x3_pair_eligible(int n, int h, int w, int s, int e1, int e3, int dtype);
+int conv3x3_pair_launch(const void* sq_in, const void* w3, const float* b3, const void* w1, const float* b1, void* y, int n, int h, int w,
+                        int s, int e1, int e3, int dtype, hipStream_t st, bool* handled);
 int conv_algo();
 int tune(int which);
 }  // namespace sqdet
@@ -664,6 +667,41 @@ void fuse_chains(sqdet_net* net, size_t esz) {
   net->layers.swap(out);
 }
 
+// expand1x1 + expand3x3 of a fire module that stayed three convs (SqueezeDet+'s squeeze depths 192 / 384: no fused fire kernel, no
+// chain) -> one L_EXPAND launch of the tile kernel's PAIR form where it covers the shape (conv3x3_pair_eligible): both expands from ONE
+// staged squeeze tile.  "fire_fuse" = 2 / 11: not.
+void fuse_expand_pairs(sqdet_net* net, size_t esz) {
+  if (conv_algo() != 0 || tune(3) == 2 || tune(3) == 11) return;
+  std::vector<Layer> out;
+  const std::vector<Layer>& in = net->layers;
+  for (size_t i = 0; i < in.size(); ++i) {
+    const bool pair = i + 1 < in.size() && in[i].type == L_CONV && in[i + 1].type == L_CONV && in[i].k == 1 && in[i + 1].k == 3 &&
+                      in[i].in_buf == BUF_S && in[i + 1].in_buf == BUF_S && in[i].out_buf == in[i + 1].out_buf && in[i].stride == 1 &&
+                      in[i + 1].stride == 1 && in[i].relu && in[i + 1].relu && in[i].cin == in[i + 1].cin && in[i].y_coffset == 0 &&
+                      in[i + 1].y_coffset == in[i].cout && in[i].y_cstride == in[i].cout + in[i + 1].cout &&
+                      in[i + 1].y_cstride == in[i].y_cstride && in[i].fold < 0 && in[i + 1].fold < 0 && !in[i].accum && !in[i + 1].accum &&
+                      in[i + 1].pad_mode == SQDET_PAD_SAME &&
+                      conv3x3_pair_eligible(net->batch, in[i].h, in[i].w, in[i].cin, in[i].cout, in[i + 1].cout, net->dtype);
+    if (!pair) { out.push_back(in[i]); continue; }
+    const Layer &e1 = in[i], &e3 = in[i + 1];
+    Layer f = e3;
+    f.type = L_EXPAND;
+    f.name = e1.name.substr(0, e1.name.find('/')) + "/expand";
+    f.fire_pool = 0;
+    f.fs = e1.cin; f.fe1 = e1.cout; f.fe3 = e3.cout;
+    f.kp_1 = e1.kparam; f.bp_1 = e1.bparam; f.kp_3 = e3.kparam; f.bp_3 = e3.bparam;
+    f.cout = e1.cout + e3.cout;
+    f.y_cstride = f.cout; f.y_coffset = 0;
+    f.flops = e1.flops + e3.flops;
+    // algorithmic bytes: squeeze tensor in (once) + concat tensor out + both weight sets
+    const double npix = (double)net->batch * e1.h * e1.w;
+    f.bytes = (npix * e1.cin + npix * f.cout + 10.0 * e1.cin * e1.cout) * (double)esz + 4.0 * f.cout;
+    out.push_back(f);
+    ++i;
+  }
+  net->layers.swap(out);
+}
+
 // L_STEM followed by the first chained module's squeeze1x1 (a plain 64 -> 16 conv emitted by fuse_chains) -> one L_STEMSQ
 // launch: pool1's tensor is never written.
 void fuse_stem_squeeze(sqdet_net* net, size_t esz) {
@@ -763,6 +801,7 @@ extern "C" int sqdet_net_create(sqdet_net_t** out, int arch, int dtype, int batc
   fuse_fires(net, b.esz);
   fuse_fire_pools(net, b.esz);
   fuse_chains(net, b.esz);
+  fuse_expand_pairs(net, b.esz);
   fuse_stem_squeeze(net, b.esz);
   net->fold_scratch_off = net->param_bytes;
   net->param_bytes = align_up(net->param_bytes + net->fold_scratch_bytes, 256);
@@ -1082,9 +1121,15 @@ extern "C" int sqdet_fire_expand_fwd(const void* sq_in, const void* w_e1, const 
   int rc = fire_expand_stream_launch(sq_in, w_e1, b_e1, w_e3, b_e3, y, n, h, w, s1x1, e1x1, e3x3, dtype, pool, st, &handled);
   if (rc != SQDET_OK || handled) return rc;
   SQDET_UNSUPPORTED(pool != 0, "fire_expand_fwd: the pooled form needs a shape the streaming kernel covers");
+  rc = conv3x3_pair_launch(sq_in, w_e3, b_e3, w_e1, b_e1, y, n, h, w, s1x1, e1x1, e3x3, dtype, st, &handled);   // deep squeezes: one tile launch
+  if (rc != SQDET_OK || handled) return rc;
   rc = conv2d_launch(sq_in, w_e1, b_e1, y, n, h, w, s1x1, e1x1, 1, 1, SQDET_PAD_SAME, 1, dtype, e1x1 + e3x3, 0, st);
   if (rc != SQDET_OK) return rc;
   return conv2d_launch(sq_in, w_e3, b_e3, y, n, h, w, s1x1, e3x3, 3, 1, SQDET_PAD_SAME, 1, dtype, e1x1 + e3x3, e1x1, st);
+}
+
+extern "C" int sqdet_fire_expand_pair_supported(int n, int h, int w, int s1x1, int e1x1, int e3x3, int dtype) {
+  return conv3x3_pair_eligible(n, h, w, s1x1, e1x1, e3x3, dtype) ? 1 : 0;
 }
 
 extern "C" int sqdet_fire_squeeze_next_fwd(const void* x, const void* w_s, const float* b_s, const void* w_e1, const float* b_e1,

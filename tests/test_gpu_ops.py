@@ -643,6 +643,48 @@ def test_fire_expand_from_squeeze_tensor(case):
     assert got.shape == want.shape and torch.equal(got, want)
 
 
+# (name, S, E, H, W, N, dbg): SqueezeDet+'s deep squeezes -- fire4 / fire5 (S = 192: 6 K chunks, two workgroups per CU) and fire9-11
+# (S = 384: 12 chunks resident, one workgroup per CU: taken where the launch has no more workgroups than CUs; "dbg" 94 forces it)
+PAIR_CASES = [("plus-fire4", 192, 128, 92, 61, 2, 0), ("plus-fire5-ragged", 192, 128, 13, 21, 3, 0), ("plus-fire9", 384, 256, 22, 76, 2, 0),
+              ("plus-fire9-ragged", 384, 256, 9, 31, 3, 94), ("one-pixel", 192, 128, 1, 1, 1, 0)]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES, ids=[c[0] for c in PAIR_CASES])
+def test_fire_expand_pair_tile_parity(case):
+    """sqdet_fire_expand_fwd on squeeze depths the streaming kernels do not cover (nets/squeezeDetPlus.py:46-73,81-106): expand1x1 and
+    expand3x3 from ONE staged squeeze tile in one launch of the tile kernel's PAIR form -- BITWISE the two separate convs (and "dbg" 93,
+    which switches the form off), and against the oracle in float16-storage mode."""
+    ops = _ops()
+    name, s, e, H, W, N, dbg = case
+    tdt = torch.float16
+    rs = np.random.RandomState(zlib.crc32(("pair" + name).encode()) % (2 ** 31))
+    mk = lambda k, ci, co: torch.from_numpy((rs.randn(k, k, ci, co) * (2.0 / (k * k * ci)) ** 0.5).astype(np.float32)).half().float()
+    w1, w3 = mk(1, s, e), mk(3, s, e)
+    b1 = torch.from_numpy(rs.uniform(-0.3, 0.3, e).astype(np.float32))
+    b3 = torch.from_numpy(rs.uniform(-0.3, 0.3, e).astype(np.float32))
+    sq = torch.from_numpy(np.maximum(rs.randn(N, H, W, s), 0).astype(np.float32)).half()
+    sqd = sq.to(DEV).contiguous()
+    p1, p3 = ops.pack_conv_weights(w1.to(DEV), tdt), ops.pack_conv_weights(w3.to(DEV), tdt)
+    ops.set_option("dbg", dbg)
+    try:
+        assert ops.lib().sqdet_fire_expand_pair_supported(N, H, W, s, e, e, 1) == 1
+        got = ops.fire_expand(sqd, p1, b1.to(DEV), p3, b3.to(DEV), pool=False)
+        ops.set_option("dbg", 93)
+        off = ops.fire_expand(sqd, p1, b1.to(DEV), p3, b3.to(DEV), pool=False)
+    finally:
+        ops.set_option("dbg", 0)
+    y_sep = torch.empty((N, H, W, 2 * e), dtype=tdt, device=DEV)
+    ops.conv2d_nhwc(sqd, p1, b1.to(DEV), 1, "SAME", True, out=y_sep, out_coffset=0)
+    ops.conv2d_nhwc(sqd, p3, b3.to(DEV), 1, "SAME", True, out=y_sep, out_coffset=e)
+    torch.cuda.synchronize()
+    assert torch.equal(off, y_sep), "two-launch fallback differs from the separate convs"
+    assert torch.equal(got[..., e:], y_sep[..., e:]), "PAIR form: expand3x3 half differs from the separate conv"
+    assert torch.equal(got[..., :e], y_sep[..., :e]), "PAIR form: expand1x1 half differs from the separate conv"
+    e1o = O.conv_layer(sq.float(), w1, b1, 1, "SAME", True, storage="fp16")
+    e3o = O.conv_layer(sq.float(), w3, b3, 1, "SAME", True, storage="fp16")
+    np.testing.assert_allclose(got.float().cpu().numpy(), torch.cat([e1o, e3o], dim=3).numpy(), rtol=2 ** -8, atol=2e-3)
+
+
 SQNEXT_CASES = [("fire2-3", 64, 16, 64, 16, 94, 311, 2), ("fire2-3-ragged", 64, 16, 64, 16, 19, 37, 3), ("fire4-5", 128, 32, 128, 32, 47, 156, 2),
                 ("fire4-5-small", 128, 32, 128, 32, 9, 15, 5)]
 
