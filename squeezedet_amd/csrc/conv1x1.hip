@@ -47,8 +47,29 @@ __global__ __launch_bounds__(256) void conv1x1_stream(C1Args a) {
   // stores of this stream run at 3.9 TB/s, the linear ones at 4.8 (tools/microbench/store_shape.hip: 38.4 against 31.4 us for fire2's
   // 150 MB).  No barrier: the wave reads back what it wrote itself (LDS executes a wave's instructions in order).
   constexpr bool LIN = PERM && sizeof(T) == 2 && NT == 4;
-  __shared__ __attribute__((aligned(16))) unsigned char lin_lds[LIN ? 4 * 2048 : 16];
-  unsigned char* const lin = lin_lds + (LIN ? (threadIdx.x >> 6) * 2048 : 0);
+  // LIN6 (round 6; float16, NT = 6, PERM: the 192- / 384-cout expand1x1 convs of fire6 / fire7 / fire10 / fire11 -- 96 couts = 192 bytes of
+  // a pixel's row per wave): the same bounce through 3 KiB of the wave's own LDS; a store instruction then covers 1 KiB of the tile in
+  // pixel-major order -- runs of 192 contiguous bytes (5.3 pixels) instead of 16 x 64 bytes with adjacent lanes 128 bytes apart.
+  // 16-byte piece q of pixel P sits in slot (q + P) mod 12 of its 192-byte row: the eight lanes a cycle serves hit eight different
+  // bank quads on the way in.
+  constexpr bool LIN6 = PERM && sizeof(T) == 2 && NT == 6;
+  __shared__ __attribute__((aligned(16))) unsigned char lin_lds[LIN ? 4 * 2048 : (LIN6 ? 4 * 3072 : 16)];
+  unsigned char* const lin = lin_lds + (LIN ? (threadIdx.x >> 6) * 2048 : (LIN6 ? (threadIdx.x >> 6) * 3072 : 0));
+  // LIN6: store k of a block moves 16-byte unit u = 64 k + lane of the tile: pixel u / 12, piece u % 12
+  [[maybe_unused]] int l6_pix[3], l6_lds[3];
+  [[maybe_unused]] unsigned l6_rel[3];
+  if constexpr (LIN6) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int u = 64 * k + lane;
+      const int P = (int)(__umul24((unsigned)u, 5462u) >> 16);       // u / 12 for u < 192
+      const int q = u - 12 * P;
+      const int sl = q + P >= 24 ? q + P - 24 : (q + P >= 12 ? q + P - 12 : q + P);
+      l6_pix[k] = P;
+      l6_lds[k] = P * 192 + sl * 16;
+      l6_rel[k] = (unsigned)q * 16u;
+    }
+  }
 
   // this wave's weights: [NCH][NT] fragments, resident in registers
   i32x4 af[NCH][NT];
@@ -167,6 +188,22 @@ __global__ __launch_bounds__(256) void conv1x1_stream(C1Args a) {
             __builtin_amdgcn_raw_buffer_store_b128(o, ry, pp < a.c.P ? (unsigned)pp * yrow + ybl + (unsigned)q * 16u : OOB, 0, 0);
           }
           asm volatile("" ::: "memory");               // (nor the next block's writes above these reads)
+        } else if constexpr (LIN6) {
+#pragma unroll
+          for (int pr = 0; pr < 3; ++pr) {
+            const f16x8 h = {(f16)v[2 * pr][0], (f16)v[2 * pr][1], (f16)v[2 * pr][2], (f16)v[2 * pr][3],
+                             (f16)v[2 * pr + 1][0], (f16)v[2 * pr + 1][1], (f16)v[2 * pr + 1][2], (f16)v[2 * pr + 1][3]};
+            const int sl = 4 * pr + g + j;             // slot (piece + pixel) mod 12, piece = 4 pr + g, pixel = j (< 27: at most two wraps)
+            *reinterpret_cast<f16x8*>(lin + j * 192 + ((sl >= 24 ? sl - 24 : (sl >= 12 ? sl - 12 : sl)) << 4)) = h;
+          }
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const i32x4 o = *reinterpret_cast<const i32x4*>(lin + l6_lds[k]);
+            const int pp = (tile * MT + m) * 16 + l6_pix[k];
+            __builtin_amdgcn_raw_buffer_store_b128(o, ry, pp < a.c.P ? (unsigned)pp * yrow + ybl + l6_rel[k] : OOB, 0, 0);
+          }
+          asm volatile("" ::: "memory");
         } else {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
