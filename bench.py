@@ -250,7 +250,8 @@ def rocprof_launch_ms(traffic_profile, layer, stats_suffix="_kernel_stats.txt"):
         with open(os.path.join(prof, traffic_profile)) as fh:
             d = json.load(fh)
         kname = next(k["kernel"] for k in d["kernels"] if k["layer"] == layer)
-        shared = sum(1 for k in d["kernels"] if k["kernel"] == kname)
+        shared_layers = [k["layer"] for k in d["kernels"] if k["kernel"] == kname]
+        shared = len(shared_layers)
         stats = traffic_profile.replace("_hbm_traffic_pmc.json", stats_suffix)
         fp_ok, avg = False, None
         with open(os.path.join(prof, stats)) as fh:
@@ -261,7 +262,7 @@ def rocprof_launch_ms(traffic_profile, layer, stats_suffix="_kernel_stats.txt"):
                     avg = float(line[90:].split()[2]) * 1e-3            # columns: calls, total_us, avg_us, %
         if not fp_ok or avg is None:
             return None
-        return {"ms": round(avg, 5), "profile": stats, "kernel_shared_by_launches": shared}
+        return {"ms": round(avg, 5), "profile": stats, "kernel_shared_by_launches": shared, "shared_layers": shared_layers}
     except (OSError, ValueError, KeyError, StopIteration, IndexError):
         return None
 
@@ -678,9 +679,17 @@ def run_infer(args, rank, local_rank, world, device):
         # below brackets the launch on its stream and reads ~4 us more than the kernel's own duration)
         rp = rocprof_launch_ms(tr[1], name)
         roof["rocprof_avg_launch_ms"] = rp["ms"] if rp else None
+        # (a kernel instantiation that serves SEVERAL launches of the forward has ONE average in the trace summary: the fraction is then
+        #  the launches' MEAN work over that mean duration, and the line says so)
+        def rocprof_frac_of(rp_):
+            sh = [l for l in layers if l[0] in (rp_.get("shared_layers") or [])] or [(name, flops, nbytes)]
+            return launch_roofline(float(np.mean([l[1] for l in sh])), float(np.mean([l[2] for l in sh])), rp_["ms"], args.dtype)["frac"]
         if rp:
             roof["rocprof_profile"] = rp["profile"]
-            roof["rocprof_frac"] = launch_roofline(flops, nbytes, rp["ms"], args.dtype)["frac"]
+            roof["rocprof_frac"] = rocprof_frac_of(rp)
+            if rp["kernel_shared_by_launches"] > 1:
+                roof["rocprof_note"] = ("the kernel instantiation serves %d launches of the forward (%s): rocprof_avg_launch_ms is their mean "
+                                        "duration, rocprof_frac their mean work over it" % (rp["kernel_shared_by_launches"], ", ".join(rp["shared_layers"])))
     roof["kernel"] = name
     roof["avg_launch_ms"] = round(avg_ms, 5)
     roof["algorithmic_bytes_per_launch"] = nbytes
@@ -696,8 +705,7 @@ def run_infer(args, rank, local_rank, world, device):
             sl.update(avg_launch_ms=round(single[0], 5), ms_per_step=round(single[1], 4))
             rp1 = rocprof_launch_ms(tr[1], name, "_kernel_stats_1lane.txt") if tr else None
             if rp1:      # the committed SQDET_SERVE_LANES=1 kernel trace of this build
-                sl.update(rocprof_avg_launch_ms=rp1["ms"], rocprof_profile=rp1["profile"],
-                          rocprof_frac=launch_roofline(flops, nbytes, rp1["ms"], args.dtype)["frac"])
+                sl.update(rocprof_avg_launch_ms=rp1["ms"], rocprof_profile=rp1["profile"], rocprof_frac=rocprof_frac_of(rp1))
             roof["single_lane"] = sl
     # the next largest launches (several are within a microsecond of each other, so which one is "dominant" can change from
     # run to run): durations from the untimed survey = one forward at a time, nothing else on the chip

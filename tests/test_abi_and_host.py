@@ -322,7 +322,7 @@ def test_bench_rocprof_launch_ms_reads_only_a_fingerprinted_profile(tmp_path, mo
     (prof / "rX_kernel_stats_1lane.txt").write_text("# x\n# build_fingerprint: OTHER\n" + row % (kname[:90], 100, 6000.0, 60.0, 10.0))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     got = bench.rocprof_launch_ms("rX_hbm_traffic_pmc.json", "conv12")
-    assert got == {"ms": 0.088, "profile": "rX_kernel_stats.txt", "kernel_shared_by_launches": 1}
+    assert got == {"ms": 0.088, "profile": "rX_kernel_stats.txt", "kernel_shared_by_launches": 1, "shared_layers": ["conv12"]}
     assert bench.rocprof_launch_ms("rX_hbm_traffic_pmc.json", "fire7")["kernel_shared_by_launches"] == 2
     assert bench.rocprof_launch_ms("rX_hbm_traffic_pmc.json", "conv12", "_kernel_stats_1lane.txt") is None     # another build's trace
     assert bench.rocprof_launch_ms("rX_hbm_traffic_pmc.json", "nope") is None

@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 FP=$(cd $R && python -c "import bench; print(bench.build_fingerprint())")
 sumstats() { python $R/profiles/summarize.py $(find $1 -name "*kernel_stats.csv" | head -1) $2 "$3" $FP >> $OUT/collect.log 2>&1; rm -rf $1; }
 if [ "$PHASE" = "A" ]; then
-  for c in sqdet_infer sqdetplus_infer; do
+  for c in sqdet_infer sqdetplus_infer sqdet_infer_384 sqdet_sample_b1; do
     P=$c; [ $c = sqdet_infer ] && P=""; PRE=${P:+${P}_}
     python $R/bench.py --config $c --no-cpu-baseline --layer-table $OUT/${PRE}layer_table.json > /dev/null 2>>$OUT/collect.log
     rocprofv3 --kernel-trace --stats -d $OUT/ks -o ks --output-format csv -- python $R/bench.py --config $c --no-cpu-baseline > /dev/null 2>&1
@@ -38,6 +38,10 @@ if [ "$PHASE" = "A" ]; then
     (cd $R && python profiles/pmc_kernels.py $OUT/pmc_kernels_$c.json $c $CSVS >> $OUT/collect.log 2>&1)
     rm -rf $OUT/pk_*
   done
+  # stand-alone tables: the fire modules' 1x1 convs (batch 32 and 128: events + copy column) and the deep 1x1 shapes A/B
+  (cd $R && python tools/fire1x1_standalone.py > $OUT/fire_1x1_standalone.txt 2>>$OUT/collect.log; python tools/fire1x1_standalone.py --batch 128 >> $OUT/fire_1x1_standalone.txt 2>>$OUT/collect.log)
+  (cd $R && python tools/ab_conv1x1_shapes.py > $OUT/conv1x1_shapes_ab.txt 2>>$OUT/collect.log)
+  sed -i '/amdgpu.ids/d' $OUT/fire_1x1_standalone.txt $OUT/conv1x1_shapes_ab.txt
   ls -la $OUT; tail -30 $OUT/collect.log
 else
   for c in sqdet_infer sqdet_infer_384 sqdet_sample_b1 sqdetplus_infer sqdet_train_fp32 res50_train_fp16 sqdet_train_fp16; do
