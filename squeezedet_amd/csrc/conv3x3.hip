@@ -54,6 +54,7 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
   a.pieces = c.Cin * esz / 16;
   a.stage_chunks = g.nchunk;
   a.wp1 = nullptr; a.bias1 = nullptr; a.y_coffset1 = 0;
+  a.dma = 0; a.chunk_pitch = CHUNK_BYTES;
   if ((long)c.N * a.tiles_x * a.tiles_y > 0x7fffffffL) return SQDET_OK;
 
   int ntw = g.nt, mt = 2;
@@ -74,7 +75,13 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
     // up to 6 K-chunks (192 fp16 channels) the whole halo tile is resident; deeper K (SqueezeDet+ fire6-11: 9 / 12 chunks,
     // ResNet50 res4 / res5: 8 / 16) is walked in stages of 4 chunks = 46 KB, three workgroups per CU hiding each other's staging
     a.stage_chunks = g.nchunk <= 6 ? g.nchunk : 4;
-    lds = (size_t)a.stage_chunks * CHUNK_BYTES;
+    // staging by LDS-DMA where the input fits 32-bit buffer offsets ("dbg" 97: through registers, the rounds 1-5 form -- A/B)
+    const long xs_bytes = (long)c.N * c.H * c.W * c.x_cstride * esz - (long)c.x_coffset * esz;
+    if (xs_bytes > 0 && xs_bytes < 0x7fffffffL && tune(TUNE_DBG) != 97) {
+      a.dma = 1; a.chunk_pitch = 12288;
+      a.x_bytes = (unsigned)xs_bytes;
+    }
+    lds = (size_t)a.stage_chunks * a.chunk_pitch;
     if (g.nt == 6 && g.ngroups >= 2 && g.nchunk >= 3) {
       mt = 8; ntw = 3;
       grid_y = (a.total_tiles + 11) / 12;
@@ -143,7 +150,9 @@ int conv3x3_pair_launch(const void* x, const void* w3, const float* b3, const vo
   a.stage_chunks = g.nchunk;                // resident
   a.x_bytes = (unsigned)(px * s * 2);
   a.wp1 = w1; a.bias1 = b1; a.y_coffset1 = 0;
-  const size_t lds = (size_t)g.nchunk * CHUNK_BYTES;
+  a.dma = tune(TUNE_DBG) != 97 ? 1 : 0;
+  a.chunk_pitch = a.dma ? 12288 : CHUNK_BYTES;
+  const size_t lds = (size_t)g.nchunk * a.chunk_pitch;
   launch_tile<f16, 4, 4, true>(a, (g.ngroups + 1) / 2, lds, st);
   SQDET_CHECK_HIP(hipGetLastError());
   *handled = true;

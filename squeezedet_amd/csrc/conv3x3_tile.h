@@ -39,12 +39,16 @@ struct TileArgs {
   const void* wp1;
   const float* bias1;
   int y_coffset1;
+  // staging: dma != 0: the halo tile arrives by LDS-DMA (stage_tile_dma), chunk pitch 12288 B = 192 pixels (whole 1-KiB DMA blocks);
+  // else through registers (stage_tile), chunk pitch CHUNK_BYTES
+  int dma, chunk_pitch;
 };
 
 // Stage `nload` K-chunks starting at chunk c0 of the halo tile into LDS.
 template <typename T>
 __device__ __forceinline__ void stage_tile(const TileArgs& a, unsigned char* lds, int n, int oy0, int ox0, int c0,
                                            int nload) {
+  const int CP = a.chunk_pitch;
   // the input may be a channel slice [x_coffset, x_coffset + Cin) of rows x_cstride channels wide (backward-data of a fire
   // module reads the expand3x3 half of dY)
   const unsigned char* x = reinterpret_cast<const unsigned char*>(a.c.x) + (size_t)a.c.x_coffset * sizeof(T);
@@ -68,11 +72,46 @@ __device__ __forceinline__ void stage_tile(const TileArgs& a, unsigned char* lds
       if (idx < total && gq < a.pieces && iy >= 0 && iy < a.c.H && ix >= 0 && ix < a.c.W)
         v[u] = *reinterpret_cast<const i32x4*>(x + (((size_t)n * a.c.H + iy) * a.c.W + ix) * row_bytes + gq * 16);
       const int c = q >> 2, g = q & 3;
-      off[u] = idx < total ? c * CHUNK_BYTES + P * 64 + ((g ^ ((P >> 1) & 3)) << 4) : -1;
+      off[u] = idx < total ? c * CP + P * 64 + ((g ^ ((P >> 1) & 3)) << 4) : -1;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (off[u] >= 0) *reinterpret_cast<i32x4*>(lds + off[u]) = v[u];
+  }
+}
+
+// The same stage by LDS-DMA (round 6): `buffer_load_dwordx4 ... lds` moves 16 pixels x 64 B = one 1-KiB block of a chunk straight into
+// LDS -- no staging registers, no ds_write pass, and ALL of a stage's blocks are in flight at once: the register path fetched 4 pieces
+// per thread at a time, i.e. a 6-chunk stage (69 KB) was four to five serialized global round trips, and two co-resident workgroups
+// that start together stage together (nothing computes meanwhile).  Block (chunk q, pixel block i): lane l = (pixel 16 i + l / 4,
+// LDS slot l & 3) requests the 16-byte piece whose slot it fills (the XOR of stage_tile applied on the SOURCE side); pixels outside the
+// image, pieces beyond Cin and the 12 pitch pixels are out-of-range offsets (bit 31) = zeros.  Wave w takes blocks w, w + 4, ...: three
+// distinct pixel blocks (12 = 3 x 4), whose pixel offsets are computed once per stage.  The caller waits (vmcnt(0)) before the barrier.
+__device__ __forceinline__ void tile_dma16(unsigned voff, const i32x4& rsrc, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_dst) : "memory", "m0");
+}
+template <typename T>
+__device__ __forceinline__ void stage_tile_dma(const TileArgs& a, unsigned lds_addr, const i32x4& rx, int n, int oy0, int ox0, int c0,
+                                               int nload, int wave, int lane) {
+  const int row_bytes = a.c.x_cstride * (int)sizeof(T);
+  unsigned rel[3];
+  int pc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int P = (wave + 4 * k) * 16 + (lane >> 2);
+    const int r = P / (TCOLS + 2), cc = P - r * (TCOLS + 2);
+    const int iy = oy0 - 1 + r, ix = ox0 - 1 + cc;
+    const bool ok = P < HP && iy >= 0 && iy < a.c.H && ix >= 0 && ix < a.c.W;
+    rel[k] = ok ? (unsigned)(((n * a.c.H + iy) * a.c.W + ix) * row_bytes) : 0x80000000u;
+    pc[k] = (lane & 3) ^ ((P >> 1) & 3);
+  }
+  for (int q = 0; q < nload; ++q) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int gq = (c0 + q) * 4 + pc[k];
+      const unsigned off = gq < a.pieces ? rel[k] + (unsigned)(gq * 16) : 0x80000000u;    // (rel's bit 31 survives the add: offsets < 2^31)
+      tile_dma16(off | (rel[k] & 0x80000000u), rx, lds_addr + (unsigned)(q * 12288 + (wave + 4 * k) * 1024));
+    }
   }
 }
 
@@ -115,6 +154,11 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
 
   const i32x4* wbase = reinterpret_cast<const i32x4*>(a.c.wp) + ((size_t)group * a.c.steps * a.nt_pack + n0) * 64 + lane;
   const int nstages = (a.nchunk + a.stage_chunks - 1) / a.stage_chunks;
+  const int CP = a.chunk_pitch;
+  const unsigned lds_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  // (DMA staging: the input as a buffer resource -- channel slice offset folded into the base, 32-bit offsets: checked by the launcher)
+  const unsigned long long xaddr = (unsigned long long)(uintptr_t)a.c.x + (unsigned long long)a.c.x_coffset * sizeof(T);
+  const i32x4 rx = {(int)(unsigned)xaddr, (int)(unsigned)((xaddr >> 32) & 0xffffu), (int)a.x_bytes, 0x00020000};
 
   i32x4 wq[3][NTW];   // cout-split mode: weight fragments of three consecutive steps
   for (int stage = 0; stage < nstages; ++stage) {
@@ -122,7 +166,12 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
     const int c0 = stage * sc;
     const int nload = a.nchunk - c0 < sc ? a.nchunk - c0 : sc;
     if (stage > 0) __syncthreads();  // everyone done reading the previous stage
-    stage_tile<T>(a, lds, n, oy0, ox0, c0, nload);
+    if (a.dma) {
+      stage_tile_dma<T>(a, lds_addr, rx, n, oy0, ox0, c0, nload, __builtin_amdgcn_readfirstlane(wave), lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's blocks (and the weight steps in flight) have landed
+    } else {
+      stage_tile<T>(a, lds, n, oy0, ox0, c0, nload);
+    }
     __syncthreads();
     if (!active) continue;
 
@@ -151,7 +200,7 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
       const int cl = ss / 9, t9 = ss - cl * 9;
       const int dy = t9 / 3, dx = t9 - dy * 3;
       // (16-byte pieces beyond Cin were zero-filled by stage_tile, so every read is unconditional)
-      const unsigned char* lchunk = lds + cl * CHUNK_BYTES;
+      const unsigned char* lchunk = lds + cl * CP;
       const int P0 = (dy + m0) * (TCOLS + 2) + j + dx;   // halo pixel of this wave's first row at this tap
       const int h0 = P0 >> 1;
 #pragma unroll
@@ -261,7 +310,7 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
 #pragma unroll
       for (int u = 0; u < CG; ++u) {
         if (c0 + u < a.nchunk) {             // wave-uniform
-          const unsigned char* lchunk = lds + (c0 + u) * CHUNK_BYTES;
+          const unsigned char* lchunk = lds + (c0 + u) * CP;
           i32x4 bf[MT];
 #pragma unroll
           for (int m = 0; m < MT; ++m)
