@@ -81,6 +81,15 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
       a.dma = 1; a.chunk_pitch = 12288;
       a.x_bytes = (unsigned)xs_bytes;
     }
+    // a launch with at most one workgroup per CU gains nothing from small stages: the whole tile resident (<= 13 chunks = 156 KiB),
+    // ONE burst of DMA blocks and no stage hand-overs ("dbg" 98: not)
+    {
+      const int wc_ = g.ngroups >= 2 ? 2 : 1;
+      const long wgs_ = (long)c.N * a.tiles_x * a.tiles_y * ((g.ngroups + wc_ - 1) / wc_);
+      const bool mt8_ = (g.nt == 6 && g.ngroups >= 2 && g.nchunk >= 3) || (g.nt == 4 && g.ngroups == 1) ||
+                        (g.nt == 4 && g.ngroups % 4 == 0 && g.nchunk >= 4 && (long)c.N * a.tiles_x * a.tiles_y * (g.ngroups / 4) >= 384);
+      if (a.dma && !mt8_ && g.nchunk > 6 && g.nchunk <= 13 && wgs_ <= cu_count() && tune(TUNE_DBG) != 98) a.stage_chunks = g.nchunk;
+    }
     lds = (size_t)a.stage_chunks * a.chunk_pitch;
     if (g.nt == 6 && g.ngroups >= 2 && g.nchunk >= 3) {
       mt = 8; ntw = 3;
