@@ -56,6 +56,7 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
   a.wp1 = nullptr; a.bias1 = nullptr; a.y_coffset1 = 0;
   a.dma = 0; a.chunk_pitch = CHUNK_BYTES;
   if ((long)c.N * a.tiles_x * a.tiles_y > 0x7fffffffL) return SQDET_OK;
+  if (a.total_tiles * 16 > 1024) return SQDET_OK;     // (the kernel keeps the bias in LDS: up to 1024 couts)
 
   int ntw = g.nt, mt = 2;
   bool splitk = false;
@@ -81,16 +82,16 @@ int conv3x3_tile_launch(const ConvArgs& c, const ConvGeom& g, int dtype, hipStre
       a.dma = 1; a.chunk_pitch = 12288;
       a.x_bytes = (unsigned)xs_bytes;
     }
-    // a launch with at most one workgroup per CU gains nothing from small stages: the whole tile resident (<= 13 chunks = 156 KiB),
+    // a launch with at most one workgroup per CU gains nothing from small stages: the whole tile resident (<= 12 chunks = 144 KiB),
     // ONE burst of DMA blocks and no stage hand-overs ("dbg" 98: not)
     {
       const int wc_ = g.ngroups >= 2 ? 2 : 1;
       const long wgs_ = (long)c.N * a.tiles_x * a.tiles_y * ((g.ngroups + wc_ - 1) / wc_);
       const bool mt8_ = (g.nt == 6 && g.ngroups >= 2 && g.nchunk >= 3) || (g.nt == 4 && g.ngroups == 1) ||
                         (g.nt == 4 && g.ngroups % 4 == 0 && g.nchunk >= 4 && (long)c.N * a.tiles_x * a.tiles_y * (g.ngroups / 4) >= 384);
-      if (a.dma && !mt8_ && g.nchunk > 6 && g.nchunk <= 13 && wgs_ <= cu_count() && tune(TUNE_DBG) != 98) a.stage_chunks = g.nchunk;
+      if (a.dma && !mt8_ && g.nchunk > 6 && g.nchunk <= 12 && wgs_ <= cu_count() && tune(TUNE_DBG) != 98) a.stage_chunks = g.nchunk;
     }
-    lds = (size_t)a.stage_chunks * a.chunk_pitch;
+    lds = (size_t)a.stage_chunks * a.chunk_pitch + (size_t)a.total_tiles * 16 * 4;   // + the bias
     if (g.nt == 6 && g.ngroups >= 2 && g.nchunk >= 3) {
       mt = 8; ntw = 3;
       grid_y = (a.total_tiles + 11) / 12;
@@ -161,7 +162,7 @@ int conv3x3_pair_launch(const void* x, const void* w3, const float* b3, const vo
   a.wp1 = w1; a.bias1 = b1; a.y_coffset1 = 0;
   a.dma = tune(TUNE_DBG) != 97 ? 1 : 0;
   a.chunk_pitch = a.dma ? 12288 : CHUNK_BYTES;
-  const size_t lds = (size_t)g.nchunk * a.chunk_pitch;
+  const size_t lds = (size_t)g.nchunk * a.chunk_pitch + (size_t)a.total_tiles * 16 * 4 * 2;   // + both biases
   launch_tile<f16, 4, 4, true>(a, (g.ngroups + 1) / 2, lds, st);
   SQDET_CHECK_HIP(hipGetLastError());
   *handled = true;
@@ -169,3 +170,9 @@ int conv3x3_pair_launch(const void* x, const void* w3, const float* b3, const vo
 }
 
 }  // namespace sqdet
+
+#ifdef SQDET_C3_TIMELINE
+extern "C" int sqdet_debug_c3_timeline(unsigned long long* host, int count) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sqdet::g_c3_tl), sizeof(unsigned long long) * count);
+}
+#endif

@@ -16,6 +16,8 @@
 //   * The ConvDet head (Cin = 768, 72 couts = 5 tiles) uses the same tile and LDS layout with K split over the waves:
 //     convdet.hip.
 #pragma once
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace sqdet {
@@ -120,9 +122,23 @@ __device__ __forceinline__ void stage_tile_dma(const TileArgs& a, unsigned lds_a
 // into its slice of the concat rows: one read and one staging of the squeeze tile for both expands, one launch instead of two.
 // The 1x1 weights (6 chunks per group of loads) are requested before the 3x3 epilogue's stores.  Accumulation order = chunk
 // ascending, as every 1x1 kernel: bitwise the separate conv.
+// -DSQDET_C3_TIMELINE (experiments only, tools/c3_timeline.py): 100 MHz s_memrealtime stamps per workgroup -- entry, first stage requested,
+// first stage landed, K loop done, epilogue issued -- plus the cumulated wait for the later stages' tiles
+#ifdef SQDET_C3_TIMELINE
+__device__ unsigned long long g_c3_tl[16384 * 8];
+#define C3TL(k) do { c3tl[k] = wall_clock64(); } while (0)
+#else
+#define C3TL(k) do {} while (0)
+#endif
+
+// (the <8, 3> float16 form -- SqueezeDet+ fire6 / fire7 -- runs three workgroups per CU: its register budget is 168; checked spill-free)
 template <typename T, int MT, int NTW, bool PAIR = false>
-__global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && MT == 8 && NTW == 3) ? 3 : 1) void conv3x3_tile(TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+#ifdef SQDET_C3_TIMELINE
+  unsigned long long c3tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  C3TL(0);
   constexpr int WR = TROWS / MT;   // waves along the tile rows
   constexpr int WC = 4 / WR;       // waves along the cout groups
   static_assert(WR * MT == TROWS && WR * WC == 4, "bad wave layout");
@@ -158,7 +174,28 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
   const unsigned lds_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
   // (DMA staging: the input as a buffer resource -- channel slice offset folded into the base, 32-bit offsets: checked by the launcher)
   const unsigned long long xaddr = (unsigned long long)(uintptr_t)a.c.x + (unsigned long long)a.c.x_coffset * sizeof(T);
-  const i32x4 rx = {(int)(unsigned)xaddr, (int)(unsigned)((xaddr >> 32) & 0xffffu), (int)a.x_bytes, 0x00020000};
+  // (readfirstlane: the descriptor must sit in SGPRs for the DMA's asm operand whatever the compiler thinks of its uniformity)
+  const i32x4 rx = {__builtin_amdgcn_readfirstlane((int)(unsigned)xaddr), __builtin_amdgcn_readfirstlane((int)(unsigned)((xaddr >> 32) & 0xffffu)),
+                    __builtin_amdgcn_readfirstlane((int)a.x_bytes), 0x00020000};
+
+  // The bias (both biases in the PAIR form) lives in LDS behind the tile, [total_tiles * 16] floats, zero beyond Cout (and all zero without
+  // a bias): 4-byte LDS-DMA pieces (256 B per wave instruction, out-of-range = zeros) issued with the first stage's blocks -- no
+  // registers.  (Loaded in the epilogue it cost every workgroup an exposed global round trip: tools/c3_timeline.py.)
+  const int ncb = a.total_tiles * 16;
+  float* const lbias = reinterpret_cast<float*>(lds + a.stage_chunks * CP);
+  {
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    auto bias_dma = [&](const float* bp, unsigned lds_off) {
+      const unsigned long long ba = (unsigned long long)(uintptr_t)bp;
+      const i32x4 rb = {__builtin_amdgcn_readfirstlane((int)(unsigned)ba), __builtin_amdgcn_readfirstlane((int)(unsigned)((ba >> 32) & 0xffffu)),
+                        __builtin_amdgcn_readfirstlane(bp ? a.c.Cout * 4 : 0), 0x00020000};
+      for (int i0 = wv * 64; i0 < ncb; i0 += 256)      // (wave-uniform)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %1, 0 offen lds" ::"v"((unsigned)(i0 + lane) * 4u), "s"(rb),
+                     "s"(__builtin_amdgcn_readfirstlane((int)(lds_addr + (unsigned)(a.stage_chunks * CP) + lds_off + (unsigned)i0 * 4u))) : "memory", "m0");
+    };
+    bias_dma(a.c.bias, 0u);
+    if constexpr (PAIR) bias_dma(a.bias1, (unsigned)ncb * 4u);
+  }
 
   i32x4 wq[3][NTW];   // cout-split mode: weight fragments of three consecutive steps
   for (int stage = 0; stage < nstages; ++stage) {
@@ -166,13 +203,21 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
     const int c0 = stage * sc;
     const int nload = a.nchunk - c0 < sc ? a.nchunk - c0 : sc;
     if (stage > 0) __syncthreads();  // everyone done reading the previous stage
+#ifdef SQDET_C3_TIMELINE
+    const unsigned long long st0 = wall_clock64();
+#endif
     if (a.dma) {
       stage_tile_dma<T>(a, lds_addr, rx, n, oy0, ox0, c0, nload, __builtin_amdgcn_readfirstlane(wave), lane);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's blocks (and the weight steps in flight) have landed
     } else {
       stage_tile<T>(a, lds, n, oy0, ox0, c0, nload);
+      if (stage == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the bias pieces)
     }
+    if (stage == 0) C3TL(1);
     __syncthreads();
+#ifdef SQDET_C3_TIMELINE
+    if (stage == 0) c3tl[2] = wall_clock64(); else c3tl[5] += wall_clock64() - st0;
+#endif
     if (!active) continue;
 
     // Flattened (chunk, tap) steps of this stage.  The weight fragments run TWO steps ahead over three statically named
@@ -215,11 +260,14 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
     constexpr bool BAHEAD = MT <= 4;
     i32x4 bq[BAHEAD ? 3 : 1][MT];
     if constexpr (BAHEAD) bread(0, bq[0]);
-#pragma unroll 1
-    for (int s = 0; s < nsteps; s += 3) {
+    // One trip = three steps over the three statically named sets.  The conv's LAST trip requests no fragments beyond the final step (PF1 /
+    // PF2 false): those re-reads were harmless but still in flight when the loop ended, and the epilogue -- which reuses their registers --
+    // began with `s_waitcnt vmcnt(0)`: an L2 round trip in every workgroup's epilogue (tools/c3_timeline.py).
+    auto trip = [&](int s, auto pf1, auto pf2) __attribute__((always_inline)) {
+      constexpr bool PF[3] = {true, decltype(pf1)::value, decltype(pf2)::value};
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
-        {
+        if (PF[u]) {
           const i32x4* wp = wptr(gs0 + s + u + 2);
 #pragma unroll
           for (int t = 0; t < NTW; ++t) wq[(u + 2) % 3][t] = wp[t * 64];
@@ -234,20 +282,29 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
 #pragma unroll
           for (int t = 0; t < NTW; ++t) mma16<T>(acc[m][t], wq[u][t], bq[BAHEAD ? u : 0][m]);
       }
-    }
+    };
+    const bool last_stage = stage == nstages - 1;
+    const int nfull = last_stage ? nsteps - 3 : nsteps;
+#pragma unroll 1
+    for (int s = 0; s < nfull; s += 3) trip(s, std::true_type{}, std::true_type{});
+    if (last_stage) trip(nsteps - 3, std::false_type{}, std::false_type{});
   }
 
+  C3TL(3);
   // epilogue: lane = pixel (row m0+m, col j); couts group*16*NTp + g*4*NTp + (n0+t)*4 .. +4 : 4*NTW consecutive
   T* y = reinterpret_cast<T*>(a.c.y);
   const int ox = ox0 + j;
   const int cb = group * 16 * a.nt_pack + g * 4 * a.nt_pack + n0 * 4;
-  auto epilogue = [&](const float* bias_p, int y_coffset) {
+  // (PLAIN: no `y +=`, no ReLU mask -- the forward convs: one wave-uniform test instead of two exec-masked blocks per row and tile)
+  // (always_inline: a lambda the inliner leaves out-of-line takes `acc` by reference, i.e. through SCRATCH -- the PAIR form's four copies did)
+  auto epilogue_t = [&](const float* bias_l, int y_coffset, auto plain_t) __attribute__((always_inline)) {
+  constexpr bool PLAIN = decltype(plain_t)::value;
   f32x4 bias[NTW];
   int nt_valid = 0;   // Cout is a multiple of 4: whole 4-cout pieces beyond Cout are skipped
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     const bool ok = cb + t * 4 < a.c.Cout;
-    bias[t] = ok && bias_p ? *reinterpret_cast<const f32x4*>(bias_p + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bias[t] = active ? *reinterpret_cast<const f32x4*>(bias_l + cb + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};   // (LDS: zeros beyond Cout)
     nt_valid += ok ? 1 : 0;
   }
 
@@ -263,7 +320,7 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
 #pragma unroll
       for (int t = 0; t < NTW; ++t) {
         v[t] = acc[m][t] + bias[t];
-        if (a.c.accum && t < nt_valid) {   // y += conv(x): d(squeeze) = dgrad_1x1(dY[:, :e1]) + dgrad_3x3(dY[:, e1:])
+        if (!PLAIN && a.c.accum && t < nt_valid) {   // y += conv(x): d(squeeze) = dgrad_1x1(dY[:, :e1]) + dgrad_3x3(dY[:, e1:])
           v[t][0] += (float)dst[t * 4 + 0]; v[t][1] += (float)dst[t * 4 + 1];
           v[t][2] += (float)dst[t * 4 + 2]; v[t][3] += (float)dst[t * 4 + 3];
         }
@@ -271,7 +328,7 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
           v[t][0] = fmaxf(v[t][0], 0.f); v[t][1] = fmaxf(v[t][1], 0.f);
           v[t][2] = fmaxf(v[t][2], 0.f); v[t][3] = fmaxf(v[t][3], 0.f);
         }
-        if (a.c.relu_of && t < nt_valid) {   // ReLU backward of the layer below (see ConvArgs)
+        if (!PLAIN && a.c.relu_of && t < nt_valid) {   // ReLU backward of the layer below (see ConvArgs)
           const T* r = reinterpret_cast<const T*>(a.c.relu_of) + (dst - y) + t * 4;
           v[t][0] = (float)r[0] > 0.f ? v[t][0] : 0.f; v[t][1] = (float)r[1] > 0.f ? v[t][1] : 0.f;
           v[t][2] = (float)r[2] > 0.f ? v[t][2] : 0.f; v[t][3] = (float)r[3] > 0.f ? v[t][3] : 0.f;
@@ -281,14 +338,28 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
     }
   }
   };
+  auto epilogue = [&](const float* bias_l, int y_coffset) __attribute__((always_inline)) {
+    if (!a.c.accum && !a.c.relu_of) epilogue_t(bias_l, y_coffset, std::true_type{});
+    else epilogue_t(bias_l, y_coffset, std::false_type{});
+  };
   if constexpr (!PAIR) {
-    epilogue(a.c.bias, a.c.y_coffset);
+    epilogue(lbias, a.c.y_coffset);
+#ifdef SQDET_C3_TIMELINE
+    C3TL(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    c3tl[6] = wall_clock64();
+    if (threadIdx.x == 0) {
+      const unsigned fid = blockIdx.y * gridDim.x + blockIdx.x;
+      if (fid < 16384)
+        for (int k = 0; k < 8; ++k) g_c3_tl[(size_t)fid * 8 + k] = c3tl[k];
+    }
+#endif
   } else {
     // ---- expand1x1 on the resident tile (a.stage_chunks == a.nchunk: one stage, the whole halo tile is still in LDS) ----
     constexpr int CG = 6;                    // chunks per group of weight loads (6 x NTW fragments in flight)
     const i32x4* w1base = reinterpret_cast<const i32x4*>(a.wp1) + ((size_t)group * a.nchunk * a.nt_pack + n0) * 64 + lane;
     i32x4 w1[CG][NTW];
-    auto load_w1 = [&](int c0) {
+    auto load_w1 = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < CG; ++u) {
         const int ch = c0 + u < a.nchunk ? c0 + u : a.nchunk - 1;      // (past the last chunk: a harmless re-read, never multiplied)
@@ -297,7 +368,7 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
       }
     };
     if (active) load_w1(0);                  // in flight under the 3x3 epilogue's stores
-    epilogue(a.c.bias, a.c.y_coffset);
+    epilogue(lbias, a.c.y_coffset);
     if (!active) return;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -322,7 +393,7 @@ __global__ __launch_bounds__(256) void conv3x3_tile(TileArgs a) {
         }
       }
     }
-    epilogue(a.bias1, a.y_coffset1);
+    epilogue(lbias + ncb, a.y_coffset1);
   }
 }
 

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 from squeezedet_amd import build as B  # noqa: E402
 from tools import wait_scan as W  # noqa: E402
 
-FILES = ["conv1x1.hip", "conv1x1k.hip", "fire3.hip", "convdet.hip", "chain.hip", "gemm1x1.hip"]
+FILES = ["conv1x1.hip", "conv1x1k.hip", "fire3.hip", "convdet.hip", "chain.hip", "gemm1x1.hip", "conv3x3.hip"]
 # the thresholds below were taken with this compiler; another version may schedule differently without anything being wrong
 HIPCC_SEEN = "7.2"
 
@@ -115,3 +115,17 @@ def test_conv1x1_pipe_loop_is_hand_counted_and_fragments_stay_untouched(asm):
             assert aw and set(aw) == {(ns - 3) * (q + ntw) + ntw}, (name, t, aw)
     bad = W.asm_load_violations(asm["gemm1x1.hip"], "conv1x1_pipe")
     assert not bad, bad[:5]
+
+
+def test_conv3x3_tile_forms_use_no_scratch(asm):
+    """every float16 instantiation of conv3x3_tile (incl. the PAIR form): private_segment_fixed_size == 0.  A lambda the inliner leaves
+    out of line takes the accumulators by reference, i.e. through scratch: round 6 shipped the PAIR form's epilogue that way for an
+    hour -- results right, launches 9x slower, nothing but a per-launch table showed it."""
+    import re
+    s = open(asm["conv3x3.hip"]).read()
+    seen = 0
+    for m in re.finditer(r"\.amdhsa_kernel (\S*conv3x3_tileIDF16_\S*)(.*?)\.end_amdhsa_kernel", s, re.S):
+        seen += 1
+        priv = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2)).group(1))
+        assert priv == 0, (m.group(1), priv)
+    assert seen >= 10, seen
